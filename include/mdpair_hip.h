@@ -1,0 +1,191 @@
+/*
+ * mdpair_hip.h -- C-ABI of libmdpair_hip.so, the MI355X (gfx950) device layer behind the
+ * LAMMPS pair styles `rebomos` and `aeam`.
+ *
+ * This is the "thin C-ABI layer" of the north star: plain pointers and sizes, no C++ or torch
+ * types.  Host code (the PairREBOMoS / PairAEAM plugin adapters in lammps-plugins_amd/plugin/,
+ * the mini-host, and the Python bench/test harness via ctypes) reaches the HIP kernels only
+ * through these entry points.  Every entry point names the reference interface it replaces
+ * (paths relative to the upstream repo lammps/lammps-plugins).
+ *
+ * Two ways to feed the hot path:
+ *   host mode     -- what a LAMMPS `Pair::compute()` has in hand: host pointers to atom->x/type/tag
+ *                    and the paged NeighList (SURVEY.md 8b "Data handed to compute").
+ *   resident mode -- atoms, ghosts, neighbor lists, integrator and thermo all live on the GPU
+ *                    (mdp_md_*); used by the mini-host and by bench.py.  Device buffers may be
+ *                    owned by the caller (e.g. torch tensors) -- see mdp_md_ptr().
+ *
+ * All functions return 0 on success or a negative MDP_E* code; mdp_last_error() gives the text.
+ * Nothing here falls back to the CPU: without a usable HIP device every call fails.
+ */
+#ifndef MDPAIR_HIP_H
+#define MDPAIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDP_ABI_VERSION 1
+
+enum {
+  MDP_OK = 0,
+  MDP_EINVAL = -1,    /* bad argument / call order                                   */
+  MDP_EHIP = -2,      /* HIP runtime error (text in mdp_last_error)                  */
+  MDP_ENOMEM = -3,
+  MDP_EOVERFLOW = -4, /* "Neighbor list overflow, boost neigh_modify one" (pair_rebomos.cpp:350) */
+  MDP_ENOTIMPL = -5,  /* e.g. per-atom virial (vflag&4) is not built yet             */
+  MDP_ESTATE = -6     /* potential / atoms / neighbors not set                       */
+};
+
+/* eflag / vflag bits follow LAMMPS ev_setup */
+#define MDP_EFLAG_GLOBAL 1
+#define MDP_EFLAG_ATOM 2
+#define MDP_VFLAG_GLOBAL 1 /* explicit pair virial -> virial[6]; set by either VIRIAL_PAIR or VIRIAL_FDOTR */
+#define MDP_VFLAG_ATOM 4
+
+typedef struct mdp_ctx mdp_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int mdp_abi_version(void);
+int mdp_device_count(void);
+int mdp_create(mdp_ctx **ctx, int device);
+int mdp_destroy(mdp_ctx *ctx);
+const char *mdp_last_error(const mdp_ctx *ctx);
+int mdp_set_stream(mdp_ctx *ctx, void *hip_stream); /* run everything on this hipStream_t (default: own stream) */
+int mdp_sync(mdp_ctx *ctx);
+
+/* ---- potentials --------------------------------------------------------------------------
+ * REBO Mo-S: the 61 scalars of MoS.REBO.set5b after mixing, i.e. the protected members of
+ * PairREBOMoS (USER-REBOMOS/pair_rebomos.h:54-60) as filled by read_file
+ * (pair_rebomos.cpp:964-1066) and init_one (pair_rebomos.cpp:262-265).  Element 0 = Mo, 1 = S. */
+typedef struct {
+  double rcmin[2][2], rcmax[2][2], rcmaxsq[2][2];
+  double Q[2][2], alpha[2][2], A[2][2], BIJc[2][2], Beta[2][2];
+  double b[7][2], bg[7][2], a[4][2];
+  double rcLJmin[2][2], rcLJmax[2][2], epsilon[2][2], sigma[2][2];
+  double lj1[2][2], lj2[2][2], lj3[2][2], lj4[2][2];
+} mdp_rebomos_params;
+
+int mdp_rebomos_set_params(mdp_ctx *ctx, const mdp_rebomos_params *p);
+
+/* AEAM: the spline tables PairAEAM::array2spline builds (USER-AEAM/pair_aeam.cpp:876-942) and
+ * the Setfl scalars (pair_aeam.h:66-76).  Tables are dense [table][row 0..nmax][7] doubles with
+ * 1-based rows exactly as the reference stores them; type maps are (ntypes+1)^2 / (ntypes+1),
+ * 1-based (pair_aeam.cpp:785-871). */
+typedef struct {
+  int ntypes, nelements, nnonangular;
+  int nrhomax, nrmax, nfrho, nrhor, nz2r;
+  const int *nrho;       /* [nelements]            */
+  const double *drho;    /* [nelements]            */
+  const int *nr;         /* [nelements*nelements]  */
+  const double *dr;      /* [nelements*nelements]  */
+  const double *cut;     /* [nelements*nelements]  */
+  const int *type2frho;  /* [ntypes+1]             */
+  const int *type2rhor;  /* [(ntypes+1)*(ntypes+1)]*/
+  const int *type2z2r;   /* [(ntypes+1)*(ntypes+1)]*/
+  const double *frho_spline; /* [nfrho][nrhomax+1][7] */
+  const double *rhor_spline; /* [nrhor][nrmax+1][7]   */
+  const double *z2r_spline;  /* [nz2r][nrmax+1][7]    */
+} mdp_aeam_tables;
+
+int mdp_aeam_set_tables(mdp_ctx *ctx, const mdp_aeam_tables *t);
+
+/* ---- host mode: the data a LAMMPS Pair::compute() holds ---------------------------------
+ * replaces the reads of atom->x/type/tag/nlocal/nghost (pair_rebomos.cpp:288-290,370-374;
+ * pair_aeam.cpp:141-145).  x is [nall][3] (LAMMPS double** is contiguous), type is 1-based,
+ * map[1..ntypes] = element index (REBO-MoS: pair_rebomos.cpp:168-179; AEAM: identity-1). */
+int mdp_set_atoms_host(mdp_ctx *ctx, int nlocal, int nghost, const double *x, const int *type, const int *tag,
+                       int ntypes, const int *map);
+int mdp_set_positions_host(mdp_ctx *ctx, const double *x); /* per step, same nlocal/nghost */
+
+/* replaces the reads of list->inum/gnum/ilist/numneigh/firstneigh (pair_rebomos.cpp:304-307,
+ * pair_aeam.cpp:150-153).  Call when the host has rebuilt its list (neighbor->ago == 0).
+ * firstneigh[i] points into LAMMPS' pages; entries are masked with NEIGHMASK here.
+ * skin = neighbor->skin: the list was built at r <= cut+skin and stays valid until the next call;
+ * the device repacks it (trimmed, coalesced) once per call. */
+int mdp_set_neighbors_host(mdp_ctx *ctx, int inum, int gnum, const int *ilist, const int *numneigh,
+                           int *const *firstneigh, double skin);
+/* same, from a CSR copy (tests / hosts that already hold a flat list): offset[nall+1] */
+int mdp_set_neighbors_csr_host(mdp_ctx *ctx, int nall, const int *numneigh, const long long *offset,
+                               const int *neigh, double skin);
+
+/* replaces PairREBOMoS::compute (pair_rebomos.cpp:102-111): REBO_neigh + FREBO + FLJ + virial.
+ * f[nlocal][3] and eatom[nlocal] are ACCUMULATED into (LAMMPS zeroes them); forces are complete
+ * for owned atoms (owner-computes: nothing is written to ghosts, so the host's reverse_comm adds
+ * zeros).  virial[6] is the explicit pair virial (xx,yy,zz,xy,xz,yz) of this rank's owned atoms,
+ * to be used with no_virial_fdotr = 1.  Any of eng/virial/eatom may be NULL. */
+int mdp_rebomos_compute_host(mdp_ctx *ctx, int eflag, int vflag, double *f, double *eng_vdwl, double *virial,
+                             double *eatom);
+
+/* replaces PairAEAM::compute (pair_aeam.cpp:110-479) in two halves around the style's own
+ * forward_comm (pair_aeam.cpp:307):
+ *   density:  passes 1+2 (rho, F, F'); writes fp[0..nlocal) (host) = F'(rho) chain factor the
+ *             neighbors need, adds the embedding energy to *eng_vdwl / eatom.
+ *   force:    pass 3; fp_all[nall] must hold the owners' values on ghosts (after forward_comm).
+ *             f[nall][3] is accumulated into: owned atoms fully, ghosts only with the angular
+ *             three-body terms (folded by the host's reverse_comm). */
+int mdp_aeam_density_host(mdp_ctx *ctx, int eflag, double *fp, double *rho, double *eng_vdwl, double *eatom);
+int mdp_aeam_force_host(mdp_ctx *ctx, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
+                        double *virial, double *eatom);
+
+/* ---- resident mode: device-side MD around the hot path -------------------------------------
+ * (neighbor build, integrator, thermo.)  One sub-domain per context. */
+typedef struct {
+  int style;          /* 1 = rebomos, 2 = aeam                                         */
+  int nlocal, nghost; /* owned atoms, ghost atoms (periodic self-images + remote halo) */
+  int ntypes;
+  double skin;
+  double dt;
+  double ftm2v, mvv2e;   /* unit constants (metal: SURVEY.md Appendix B)               */
+  double bbox_lo[3], bbox_hi[3]; /* Cartesian bounds of owned+ghost atoms, for binning  */
+} mdp_md_config;
+
+/* upload a sub-domain.  x/v/type/tag: owned atoms [nlocal]; ghosts: ghost_owner[g] = local index
+ * of the owner (>=0: periodic self-image, refreshed on the device each step) or -1 (remote: filled
+ * by mdp_md_unpack_ghosts), ghost_shift[g][3] Cartesian image shift, ghost_type/tag.
+ * mass[1..ntypes].  map as in mdp_set_atoms_host. */
+int mdp_md_setup(mdp_ctx *ctx, const mdp_md_config *cfg, const double *x, const double *v, const int *type,
+                 const int *tag, const double *mass, const int *map, const int *ghost_owner,
+                 const double *ghost_shift, const int *ghost_type, const int *ghost_tag);
+/* binned full(+ghost) neighbor list on the device with the cutoffs the style's init_one() returns
+ * (pair_rebomos.cpp:244-274, pair_aeam.cpp:615-621) + skin, then the style's repack. */
+int mdp_md_build_neighbors(mdp_ctx *ctx);
+int mdp_md_initial_integrate(mdp_ctx *ctx); /* fix nve: v += dt/2 f/m; x += dt v; refresh self-image ghosts */
+int mdp_md_final_integrate(mdp_ctx *ctx);   /* v += dt/2 f/m */
+int mdp_md_compute(mdp_ctx *ctx, int eflag, int vflag); /* force_clear + Pair::compute on the device */
+/* halo plumbing for multi-GPU: pack x (or the AEAM fp) of owned atoms sendlist[n] (+shift) into buf;
+ * unpack recv buffers into ghosts [first, first+n).  buf/sendlist/shift are DEVICE pointers. */
+int mdp_md_pack_x(mdp_ctx *ctx, int n, const int *d_sendlist, const double *d_shift, double *d_buf);
+int mdp_md_unpack_x(mdp_ctx *ctx, int first_ghost, int n, const double *d_buf);
+int mdp_md_pack_scalar(mdp_ctx *ctx, int which, int n, const int *d_sendlist, double *d_buf);
+int mdp_md_unpack_scalar(mdp_ctx *ctx, int which, int first_ghost, int n, const double *d_buf);
+int mdp_md_pack_ghost_f(mdp_ctx *ctx, int first_ghost, int n, double *d_buf);       /* reverse comm */
+int mdp_md_unpack_add_f(mdp_ctx *ctx, int n, const int *d_sendlist, const double *d_buf);
+int mdp_md_fold_self_ghost_f(mdp_ctx *ctx); /* reverse comm for periodic self-images */
+/* AEAM only: split compute around the fp halo */
+int mdp_md_aeam_density(mdp_ctx *ctx, int eflag);
+int mdp_md_aeam_force(mdp_ctx *ctx, int eflag, int vflag);
+/* thermo: out[0]=KE(owned), [1]=PE (eng_vdwl of last compute), [2..7]=virial of last compute,
+ * [8] = max squared displacement since the last neighbor build (neigh_modify check yes) */
+int mdp_md_thermo(mdp_ctx *ctx, double out[9]);
+int mdp_md_download(mdp_ctx *ctx, double *x, double *v, double *f, double *eatom); /* owned atoms; NULLs skipped */
+int mdp_md_upload_x(mdp_ctx *ctx, const double *x);                             /* owned atoms [nlocal][3] */
+/* device pointers of resident arrays for zero-copy plumbing (name: "x","v","f","fp","eatom") */
+void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
+/* statistics of the last neighbor build: out[0]=total master entries (owned), [1]=ghost-list entries,
+ * [2]=trimmed LJ entries (rebomos) , [3]=REBO candidate entries, [4]=#centres */
+int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
+
+/* per-phase device time of the last compute in ms (HIP events on the compute stream):
+ * rebomos: [0]=REBO centre kernels, [1]=LJ+gather kernel; aeam: [0]=density, [1]=embed, [2]=force.
+ * Enabled by mdp_set_timing(ctx,1). */
+int mdp_set_timing(mdp_ctx *ctx, int on);
+int mdp_get_timing(mdp_ctx *ctx, double ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDPAIR_HIP_H */

@@ -1,0 +1,182 @@
+// mdp_common.h -- internal context and helpers of libmdpair_hip.so (gfx950 only)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mdpair_hip.h"
+
+#define MDP_NEIGHMASK 0x1FFFFFFF
+
+// device buffer that only grows
+template <typename T> struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n, bool keep = false, hipStream_t s = nullptr)
+  {
+    if (n <= cap) return hipSuccess;
+    size_t ncap = n + n / 8 + 64;
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **) &q, ncap * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (keep && p && cap) {
+      e = hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+    }
+    if (p) (void) hipFree(p);
+    p = q;
+    cap = ncap;
+    return hipSuccess;
+  }
+  void release()
+  {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  size_t bytes() const { return cap * sizeof(T); }
+};
+
+// REBO-MoS parameters as the kernels see them: pair tables flattened [ti*2+tj]
+struct RebomosDev {
+  double rcmin[4], rcmax[4], rcmaxsq[4], rcinv[4]; // rcinv = 1/(rcmax-rcmin)
+  double Q[4], alpha[4], A[4], B[4], beta[4];
+  double b[2][7], bg[2][7], a[2][4];
+  // LJ: thresholds in rsq space chosen so that the branch taken is bit-identical to the
+  // reference's comparisons on rij = sqrt(rsq) (pair_rebomos.cpp:518-532)
+  double lj_rsq_lo[4];  // smallest rsq with sqrt(rsq) >= rcLJmin
+  double lj_rsq_hi[4];  // largest  rsq with sqrt(rsq) <= rcLJmax
+  double lj_rsq_sw[4];  // smallest rsq with sqrt(rsq) >= 0.95*sigma
+  double lj1[4], lj2[4], lj3[4], lj4[4];
+  double ljc2[4], ljc3[4], rcLJmin[4]; // cubic inner spline (pair_rebomos.cpp:533-543)
+  double cand_cutsq[4];                // (rcmax+skin)^2 : REBO candidate list
+  double ljlist_cutsq[4];              // (rcLJmax+skin)^2 : trimmed LJ list
+};
+
+struct AeamDev {
+  int ntypes, nelements, nnonangular, nrhomax, nrmax;
+  // per type pair [(ti-1)*ntypes + (tj-1)], ntypes <= 4
+  double cut[16], rdr[16];
+  int nr[16], t2rhor[16], t2z2r[16];
+  double rdrho[4];
+  int nrho[4], t2frho[4];
+  const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
+};
+
+struct mdp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // ---- potentials
+  bool have_rebomos = false, have_aeam = false;
+  mdp_rebomos_params rebomos_host;
+  RebomosDev rebomos;
+  AeamDev aeam;
+  DevBuf<double> aeam_frho, aeam_rhor, aeam_z2r;
+
+  // ---- atoms
+  int nlocal = 0, nghost = 0, nall = 0, ntypes = 0;
+  bool atoms_set = false;
+  int map[16];
+  DevBuf<double4> xq;   // x,y,z, w = element / type-1 as double
+  DevBuf<double> xraw;  // staging for host x [nall][3]
+  DevBuf<int> tag, type;
+  DevBuf<double> f;     // [nall][3]
+  DevBuf<double> eatom; // [nall]
+  DevBuf<double> acc;   // [16] eng, virial[6], flags...
+  DevBuf<int> flags;    // [4] overflow etc.
+  double *h_pinned = nullptr; // pinned staging for small results (32 doubles)
+
+  // ---- master neighbor list (CSR over nall atoms)
+  bool neigh_set = false;
+  double skin = 0.0;
+  DevBuf<long long> nb_off; // [nall+1]
+  DevBuf<int> nb;           // [total]
+  long long nb_total = 0, nb_owned_total = 0;
+  std::vector<long long> h_off;
+  std::vector<int> h_nb;
+
+  // ---- REBO-MoS repacked structures
+  bool rebo_packed = false;
+  DevBuf<int> cand_cnt, cand_off; // [nall+1]
+  DevBuf<int> cand;               // REBO candidates (r <= rcmax+skin)
+  int cand_total = 0;
+  DevBuf<long long> lj_off;       // [nlocal+1]
+  DevBuf<int> lj_cnt;             // [nlocal]
+  DevBuf<int> lj;                 // trimmed LJ list
+  long long lj_total = 0;
+  DevBuf<int> is_center;          // [nall]
+  DevBuf<int> class_list;         // [4][nall]
+  DevBuf<int> class_count;        // [4]
+  int h_class_count[4] = {0, 0, 0, 0};
+  DevBuf<int> rn_num;             // [nall]
+  DevBuf<int> rn_idx;             // [cand_total]
+  DevBuf<double> fnbr;            // [cand_total][3]
+  DevBuf<double> eslot;           // [cand_total]
+  DevBuf<char> scan_tmp;
+
+  // ---- AEAM work arrays
+  DevBuf<double> rho, fp;         // [nall]
+  DevBuf<int> ang_list;           // owned angular atoms
+  DevBuf<int> ang_count;
+  int h_ang_count = 0;
+
+  // ---- resident MD
+  bool md = false;
+  mdp_md_config cfg;
+  DevBuf<double> v;          // [nlocal][3]
+  DevBuf<double> xhold;      // [nlocal][3] positions at last build
+  DevBuf<double> rmass;      // [nlocal]
+  DevBuf<int> ghost_owner;   // [nghost]
+  DevBuf<double> ghost_shift;// [nghost][3]
+  DevBuf<double> mass_type;
+  // binning scratch
+  DevBuf<int> cell_of, cell_perm, cell_start;
+  DevBuf<unsigned> sort_keys_a, sort_keys_b;
+  DevBuf<int> sort_vals_b;
+  DevBuf<int> nb_cnt;
+  double last_eng = 0.0, last_virial[6] = {0, 0, 0, 0, 0, 0};
+
+  // ---- timing
+  bool timing = false;
+  hipEvent_t ev[8] = {};
+  bool ev_made = false;
+  double t_ms[8] = {};
+};
+
+int mdp_fail(mdp_ctx *c, int code, const char *fmt, ...);
+
+#define MDP_HIP(c, call)                                                                             \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return mdp_fail((c), MDP_EHIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define MDP_TRY(expr)                                                                                \
+  do {                                                                                               \
+    int rc_ = (expr);                                                                                \
+    if (rc_ != MDP_OK) return rc_;                                                                   \
+  } while (0)
+
+// modules
+int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null); // xraw/type -> xq
+int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // d_out[n] = total (n+1 entries)
+int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n);
+int mdp_rebomos_repack(mdp_ctx *c);
+int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
+int mdp_aeam_prepare(mdp_ctx *c);
+int mdp_aeam_run_density(mdp_ctx *c, int eflag);
+int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
+int mdp_md_build_master_list(mdp_ctx *c);
+void mdp_time_mark(mdp_ctx *c, int k);

@@ -1,0 +1,272 @@
+"""ctypes binding of libmdpair_hip.so (include/mdpair_hip.h).  Python never computes forces itself:
+every call here lands in the HIP kernels, and loading fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libmdpair_hip.so")
+
+D22 = (C.c_double * 2) * 2
+
+
+class RebomosParams(C.Structure):
+    """mirror of mdp_rebomos_params"""
+    _fields_ = [(n, D22) for n in ("rcmin", "rcmax", "rcmaxsq", "Q", "alpha", "A", "BIJc", "Beta")] + [
+        ("b", (C.c_double * 2) * 7), ("bg", (C.c_double * 2) * 7), ("a", (C.c_double * 2) * 4)] + [
+        (n, D22) for n in ("rcLJmin", "rcLJmax", "epsilon", "sigma", "lj1", "lj2", "lj3", "lj4")]
+
+
+class AeamTables(C.Structure):
+    """mirror of mdp_aeam_tables"""
+    _fields_ = [("ntypes", C.c_int), ("nelements", C.c_int), ("nnonangular", C.c_int),
+                ("nrhomax", C.c_int), ("nrmax", C.c_int), ("nfrho", C.c_int), ("nrhor", C.c_int), ("nz2r", C.c_int),
+                ("nrho", C.POINTER(C.c_int)), ("drho", C.POINTER(C.c_double)),
+                ("nr", C.POINTER(C.c_int)), ("dr", C.POINTER(C.c_double)), ("cut", C.POINTER(C.c_double)),
+                ("type2frho", C.POINTER(C.c_int)), ("type2rhor", C.POINTER(C.c_int)), ("type2z2r", C.POINTER(C.c_int)),
+                ("frho_spline", C.POINTER(C.c_double)), ("rhor_spline", C.POINTER(C.c_double)),
+                ("z2r_spline", C.POINTER(C.c_double))]
+
+
+class MdConfig(C.Structure):
+    """mirror of mdp_md_config"""
+    _fields_ = [("style", C.c_int), ("nlocal", C.c_int), ("nghost", C.c_int), ("ntypes", C.c_int),
+                ("skin", C.c_double), ("dt", C.c_double), ("ftm2v", C.c_double), ("mvv2e", C.c_double),
+                ("bbox_lo", C.c_double * 3), ("bbox_hi", C.c_double * 3)]
+
+
+STYLE_REBOMOS, STYLE_AEAM = 1, 2
+EXPORTS = [
+    "mdp_abi_version", "mdp_device_count", "mdp_create", "mdp_destroy", "mdp_last_error", "mdp_set_stream",
+    "mdp_sync", "mdp_rebomos_set_params", "mdp_aeam_set_tables", "mdp_set_atoms_host", "mdp_set_positions_host",
+    "mdp_set_neighbors_host", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
+    "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
+    "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
+    "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
+    "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
+    "mdp_md_neighbor_stats", "mdp_set_timing", "mdp_get_timing",
+]
+
+
+class MdpError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libmdpair_hip: error {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """load the C-ABI library; no fallback of any kind if it is missing"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python __graft_entry__.py` (make -C lammps-plugins_amd)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mdp_last_error.restype = C.c_char_p
+        _lib.mdp_md_ptr.restype = C.c_void_p
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def rebomos_params_from_oracle(P) -> RebomosParams:
+    """copy the (identically laid out) leading fields of the oracle's parameter struct"""
+    out = RebomosParams()
+    for name, _ in RebomosParams._fields_:
+        setattr(out, name, getattr(P, name))
+    return out
+
+
+class Context:
+    """one mdp_ctx (one GPU sub-domain)"""
+
+    def __init__(self, device: int = 0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.mdp_create(C.byref(self.h), C.c_int(device))
+        if rc:
+            raise MdpError(rc, "mdp_create failed (no usable HIP device?)")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.mdp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise MdpError(rc, self.L.mdp_last_error(self.h).decode())
+
+    # ---------------- potentials
+    def rebomos_set_params(self, params: RebomosParams):
+        self._ck(self.L.mdp_rebomos_set_params(self.h, C.byref(params)))
+
+    def aeam_set_tables(self, t: AeamTables):
+        self._ck(self.L.mdp_aeam_set_tables(self.h, C.byref(t)))
+
+    def set_stream(self, stream_ptr: int):
+        self._ck(self.L.mdp_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._ck(self.L.mdp_sync(self.h))
+
+    def set_timing(self, on=True):
+        self._ck(self.L.mdp_set_timing(self.h, C.c_int(1 if on else 0)))
+
+    def get_timing(self):
+        ms = (C.c_double * 8)()
+        self._ck(self.L.mdp_get_timing(self.h, ms))
+        return list(ms)
+
+    # ---------------- host mode
+    def set_atoms_host(self, nlocal, x_all, type_all, tag_all, ntypes, map_=None):
+        x_all = np.ascontiguousarray(x_all, dtype=np.float64)
+        type_all = np.ascontiguousarray(type_all, dtype=np.int32)
+        tag_all = None if tag_all is None else np.ascontiguousarray(tag_all, dtype=np.int32)
+        m = None if map_ is None else np.ascontiguousarray(map_, dtype=np.int32)
+        self._ck(self.L.mdp_set_atoms_host(self.h, C.c_int(nlocal), C.c_int(len(x_all) - nlocal), _dp(x_all),
+                                           _ip(type_all), _ip(tag_all), C.c_int(ntypes), _ip(m)))
+
+    def set_positions_host(self, x_all):
+        x_all = np.ascontiguousarray(x_all, dtype=np.float64)
+        self._ck(self.L.mdp_set_positions_host(self.h, _dp(x_all)))
+
+    def set_neighbors_csr_host(self, numneigh, offset, neigh, skin):
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        offset = np.ascontiguousarray(offset, dtype=np.int64)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        self._ck(self.L.mdp_set_neighbors_csr_host(self.h, C.c_int(len(numneigh)), _ip(numneigh),
+                                                   offset.ctypes.data_as(C.POINTER(C.c_longlong)), _ip(neigh),
+                                                   C.c_double(skin)))
+
+    def set_neighbors_paged_host(self, inum, gnum, ilist, numneigh, rows, skin):
+        """rows: list of int32 arrays (one per atom index) -- exercises the LAMMPS int** path"""
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        ptrs = (C.POINTER(C.c_int) * len(rows))()
+        for i, r in enumerate(rows):
+            ptrs[i] = r.ctypes.data_as(C.POINTER(C.c_int))
+        self._ck(self.L.mdp_set_neighbors_host(self.h, C.c_int(inum), C.c_int(gnum), _ip(ilist), _ip(numneigh), ptrs,
+                                               C.c_double(skin)))
+
+    def rebomos_compute_host(self, nlocal, eflag=3, vflag=1):
+        f = np.zeros((nlocal, 3))
+        eng = C.c_double(0.0)
+        vir = np.zeros(6)
+        eatom = np.zeros(nlocal)
+        self._ck(self.L.mdp_rebomos_compute_host(self.h, C.c_int(eflag), C.c_int(vflag), _dp(f), C.byref(eng),
+                                                 _dp(vir), _dp(eatom)))
+        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom)
+
+    def aeam_density_host(self, nlocal, eflag=3):
+        fp = np.zeros(nlocal)
+        rho = np.zeros(nlocal)
+        eng = C.c_double(0.0)
+        eatom = np.zeros(nlocal)
+        self._ck(self.L.mdp_aeam_density_host(self.h, C.c_int(eflag), _dp(fp), _dp(rho), C.byref(eng), _dp(eatom)))
+        return dict(fp=fp, rho=rho, eng=eng.value, eatom=eatom)
+
+    def aeam_force_host(self, nall, nlocal, fp_all, eflag=3, vflag=1):
+        fp_all = np.ascontiguousarray(fp_all, dtype=np.float64)
+        f = np.zeros((nall, 3))
+        eng = C.c_double(0.0)
+        vir = np.zeros(6)
+        eatom = np.zeros(nlocal)
+        self._ck(self.L.mdp_aeam_force_host(self.h, C.c_int(eflag), C.c_int(vflag), _dp(fp_all), _dp(f), C.byref(eng),
+                                            _dp(vir), _dp(eatom)))
+        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom)
+
+    # ---------------- resident mode
+    def md_setup(self, cfg: MdConfig, x, v, type_, tag, mass, map_, ghost_owner, ghost_shift, ghost_type, ghost_tag):
+        a = lambda arr, dt: np.ascontiguousarray(arr, dtype=dt)
+        x, v, ghost_shift, mass = a(x, np.float64), a(v, np.float64), a(ghost_shift, np.float64), a(mass, np.float64)
+        type_, tag, ghost_owner, ghost_type, ghost_tag = (a(type_, np.int32), a(tag, np.int32), a(ghost_owner, np.int32),
+                                                          a(ghost_type, np.int32), a(ghost_tag, np.int32))
+        m = None if map_ is None else a(map_, np.int32)
+        self._ck(self.L.mdp_md_setup(self.h, C.byref(cfg), _dp(x), _dp(v), _ip(type_), _ip(tag), _dp(mass), _ip(m),
+                                     _ip(ghost_owner), _dp(ghost_shift), _ip(ghost_type), _ip(ghost_tag)))
+
+    def md_build_neighbors(self):
+        self._ck(self.L.mdp_md_build_neighbors(self.h))
+
+    def md_initial_integrate(self):
+        self._ck(self.L.mdp_md_initial_integrate(self.h))
+
+    def md_final_integrate(self):
+        self._ck(self.L.mdp_md_final_integrate(self.h))
+
+    def md_compute(self, eflag=0, vflag=0):
+        self._ck(self.L.mdp_md_compute(self.h, C.c_int(eflag), C.c_int(vflag)))
+
+    def md_aeam_density(self, eflag=0):
+        self._ck(self.L.mdp_md_aeam_density(self.h, C.c_int(eflag)))
+
+    def md_aeam_force(self, eflag=0, vflag=0):
+        self._ck(self.L.mdp_md_aeam_force(self.h, C.c_int(eflag), C.c_int(vflag)))
+
+    def md_thermo(self):
+        out = (C.c_double * 9)()
+        self._ck(self.L.mdp_md_thermo(self.h, out))
+        o = list(out)
+        return dict(ke=o[0], pe=o[1], virial=np.array(o[2:8]), maxdisp2=o[8])
+
+    def md_download(self, nlocal, want=("x", "v", "f")):
+        arrs = {k: (np.zeros((nlocal, 3)) if k in want else None) for k in ("x", "v", "f")}
+        ea = np.zeros(nlocal) if "eatom" in want else None
+        self._ck(self.L.mdp_md_download(self.h, _dp(arrs["x"]), _dp(arrs["v"]), _dp(arrs["f"]), _dp(ea)))
+        arrs["eatom"] = ea
+        return arrs
+
+    def md_upload_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._ck(self.L.mdp_md_upload_x(self.h, _dp(x)))
+
+    def md_ptr(self, name: str) -> int:
+        p = self.L.mdp_md_ptr(self.h, name.encode())
+        if not p:
+            raise MdpError(-1, f"mdp_md_ptr({name}) returned NULL")
+        return int(p)
+
+    def md_neighbor_stats(self):
+        out = (C.c_longlong * 8)()
+        self._ck(self.L.mdp_md_neighbor_stats(self.h, out))
+        return list(out)
+
+    # halo plumbing (device pointers as ints)
+    def md_pack_x(self, n, d_sendlist, d_shift, d_buf):
+        self._ck(self.L.mdp_md_pack_x(self.h, C.c_int(n), C.c_void_p(d_sendlist), C.c_void_p(d_shift), C.c_void_p(d_buf)))
+
+    def md_unpack_x(self, first_ghost, n, d_buf):
+        self._ck(self.L.mdp_md_unpack_x(self.h, C.c_int(first_ghost), C.c_int(n), C.c_void_p(d_buf)))
+
+    def md_pack_scalar(self, which, n, d_sendlist, d_buf):
+        self._ck(self.L.mdp_md_pack_scalar(self.h, C.c_int(which), C.c_int(n), C.c_void_p(d_sendlist), C.c_void_p(d_buf)))
+
+    def md_unpack_scalar(self, which, first_ghost, n, d_buf):
+        self._ck(self.L.mdp_md_unpack_scalar(self.h, C.c_int(which), C.c_int(first_ghost), C.c_int(n), C.c_void_p(d_buf)))
+
+    def md_pack_ghost_f(self, first_ghost, n, d_buf):
+        self._ck(self.L.mdp_md_pack_ghost_f(self.h, C.c_int(first_ghost), C.c_int(n), C.c_void_p(d_buf)))
+
+    def md_unpack_add_f(self, n, d_sendlist, d_buf):
+        self._ck(self.L.mdp_md_unpack_add_f(self.h, C.c_int(n), C.c_void_p(d_sendlist), C.c_void_p(d_buf)))
+
+    def md_fold_self_ghost_f(self):
+        self._ck(self.L.mdp_md_fold_self_ghost_f(self.h))

@@ -1,0 +1,131 @@
+"""GPU parity: REBO-MoS through the C-ABI (libmdpair_hip.so, host mode = what a LAMMPS
+Pair::compute() hands over) against the CPU oracle on the same inputs.
+
+Tolerances (FP64 everywhere; the device sums in a different order and uses sincospi/FMA):
+  forces 1e-9 eV/A abs, per-atom energy 1e-9 eV (north star: 1e-6), PE 1e-10 rel, virial 1e-9 rel."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, POT_REBOMOS
+from lammps_plugins_amd.host import capi, system as S
+import mdref
+
+pytestmark = pytest.mark.gpu
+
+F_TOL, E_TOL = 1e-9, 1e-9
+
+
+@pytest.fixture(scope="module")
+def P(oracle):
+    return oracle.rebomos_params(POT_REBOMOS)
+
+
+@pytest.fixture(scope="module")
+def ctx(P):
+    c = capi.Context(0)
+    c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
+    yield c
+    c.close()
+
+
+def _gpu_compute(ctx, eng, x, first=True, eflag=3, vflag=1):
+    xa = eng.all_positions(x)
+    if first:
+        ctx.set_atoms_host(eng.nlocal, xa, eng.type_all, eng.tag_all, 2, map_=[0, 0, 1])
+        ctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, 2.0)
+    else:
+        ctx.set_positions_host(xa)
+    return ctx.rebomos_compute_host(eng.nlocal, eflag=eflag, vflag=vflag)
+
+
+def _compare(g, o):
+    assert np.abs(g["f"] - o["f_owned"]).max() < F_TOL
+    assert g["eng"] == pytest.approx(o["eng"], rel=1e-10)
+    assert np.abs(g["eatom"] - o["eatom_owned"]).max() < E_TOL
+    assert np.allclose(g["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    assert g["eatom"].sum() == pytest.approx(g["eng"], rel=1e-11)
+
+
+def test_bulk_cell_matches_oracle_and_log(ctx, oracle, P):
+    """config #2: the in.rebomos-bulk cell, step 0 (log.rebomos-bulk.1:54)"""
+    s = S.rebomos_bulk_cell()
+    eng = mdref.RebomosCPU(oracle, P, s)
+    g = _gpu_compute(ctx, eng, s.x)
+    _compare(g, eng.compute(s.x))
+    log = json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+    assert g["eng"] == pytest.approx(log["thermo"][0]["pe"], abs=5.1e-5)
+    press = S.pressure(0.0, g["virial"], s.n, s.box.volume)
+    assert press == pytest.approx(log["thermo"][0]["press"], abs=5.1e-3)
+
+
+@pytest.mark.parametrize("fac,amp,seed", [(1.12, 0.15, 1234), (0.93, 0.10, 77), (1.0, 0.15, 5), (1.0, 0.4, 9)])
+def test_all_branches_match_oracle(ctx, oracle, P, fac, amp, seed):
+    """strained / compressed / jittered cells: switching interior, LJ cubic branch, both gSpline
+    halves, denser REBO lists"""
+    s = S.jitter(S.scale(S.rebomos_bulk_cell(), fac), amp, seed=seed)
+    eng = mdref.RebomosCPU(oracle, P, s)
+    _compare(_gpu_compute(ctx, eng, s.x), eng.compute(s.x))
+
+
+def test_paged_list_entry_point_and_position_update(ctx, oracle, P):
+    """the LAMMPS int** path (with high bits set, masked by NEIGHMASK) and per-step position updates
+    with a list that stays valid inside the skin"""
+    s = S.jitter(S.rebomos_bulk_cell(), 0.05, seed=3)
+    eng = mdref.RebomosCPU(oracle, P, s)
+    xa = eng.all_positions(s.x)
+    ctx.set_atoms_host(eng.nlocal, xa, eng.type_all, eng.tag_all, 2, map_=[0, 0, 1])
+    nall = len(xa)
+    rows = [np.ascontiguousarray(eng.nb[eng.off[i]:eng.off[i + 1]] | (1 << 30)).astype(np.int32) for i in range(nall)]
+    listed = np.nonzero(eng.nn[eng.nlocal:] > 0)[0] + eng.nlocal
+    ilist = np.concatenate([np.arange(eng.nlocal), listed]).astype(np.int32)
+    ctx.set_neighbors_paged_host(eng.nlocal, len(listed), ilist, eng.nn, rows, 2.0)
+    _compare(ctx.rebomos_compute_host(eng.nlocal), eng.compute(s.x))
+    # move atoms by < skin/2 without telling the device about a new list
+    rng = np.random.default_rng(11)
+    x2 = s.x + rng.uniform(-0.45, 0.45, s.x.shape)
+    g2 = _gpu_compute(ctx, eng, x2, first=False)
+    # oracle with a fresh list at the new positions
+    s2 = S.System(s.box, x2, s.type, s.tag, s.mass)
+    eng2 = mdref.RebomosCPU(oracle, P, s2)
+    o2 = eng2.compute(x2)
+    assert np.abs(g2["f"] - o2["f_owned"]).max() < F_TOL
+    assert g2["eng"] == pytest.approx(o2["eng"], rel=1e-10)
+
+
+def test_force_only_call_leaves_energy_untouched(ctx, oracle, P):
+    s = S.rebomos_bulk_cell()
+    eng = mdref.RebomosCPU(oracle, P, s)
+    g = _gpu_compute(ctx, eng, s.x, eflag=0, vflag=0)
+    assert g["eng"] == 0.0 and not g["virial"].any() and not g["eatom"].any()
+    assert np.abs(g["f"] - eng.compute(s.x)["f_owned"]).max() < F_TOL
+
+
+def test_replicated_cell_and_nve_thermo_table(ctx, oracle, P):
+    """2x1x1 replica: PE = 2x (config #4 known answer at small scale); then 20 NVE steps of the
+    288-atom cell driven on the host with GPU forces reproduce log.rebomos-bulk.1:54-56"""
+    s2 = S.replicate(S.rebomos_bulk_cell(), (2, 1, 1))
+    eng2 = mdref.RebomosCPU(oracle, P, s2)
+    g = _gpu_compute(ctx, eng2, s2.x)
+    log = json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+    assert g["eng"] == pytest.approx(2 * log["thermo"][0]["pe"], abs=2e-4)
+    assert np.abs(g["f"].sum(axis=0)).max() < 1e-9
+
+    s = S.rebomos_bulk_cell()
+    eng = mdref.RebomosCPU(oracle, P, s)
+
+    class GpuEngine:
+        first = True
+
+        def compute(self, x):
+            r = _gpu_compute(ctx, eng, x, first=self.first)
+            self.first = False
+            return dict(f_owned=r["f"], eng=r["eng"], virial_fdotr=r["virial"])
+
+    rows, _, _ = mdref.nve(GpuEngine(), s, 20)
+    for got, ref in zip(rows, log["thermo"]):
+        assert got["pe"] == pytest.approx(ref["pe"], abs=5.1e-5)
+        assert got["ke"] == pytest.approx(ref["ke"], abs=5.1e-8)
+        assert got["press"] == pytest.approx(ref["press"], abs=5.1e-3)
