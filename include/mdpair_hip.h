@@ -70,6 +70,10 @@ typedef struct {
 } mdp_rebomos_params;
 
 int mdp_rebomos_set_params(mdp_ctx *ctx, const mdp_rebomos_params *p);
+/* replaces PairREBOMoS::read_file (pair_rebomos.cpp:857-1066): 61 scalars, one per non-comment line,
+ * then the mixing rules and lj1..lj4.  err receives a message shaped like pair_rebomos.cpp:955-957. */
+int mdp_rebomos_read_file(const char *path, mdp_rebomos_params *p, char *err, int errlen);
+int mdp_rebomos_params_from_scalars(const double *v61, mdp_rebomos_params *p);
 
 /* AEAM: the spline tables PairAEAM::array2spline builds (USER-AEAM/pair_aeam.cpp:876-942) and
  * the Setfl scalars (pair_aeam.h:66-76).  Tables are dense [table][row 0..nmax][7] doubles with
@@ -92,6 +96,14 @@ typedef struct {
 } mdp_aeam_tables;
 
 int mdp_aeam_set_tables(mdp_ctx *ctx, const mdp_aeam_tables *t);
+/* replaces PairAEAM::read_file (pair_aeam.cpp:627-746), file2array (:752-872) and array2spline /
+ * interpolate (:876-942).  map[1..ntypes] = element index of each atom type, -1 for NULL. */
+typedef struct mdp_aeam_file mdp_aeam_file;
+int mdp_aeam_file_read(const char *path, mdp_aeam_file **out, char *err, int errlen);
+int mdp_aeam_file_info(const mdp_aeam_file *f, int *nelements, int *nnonangular, int *nangular, double *mass4,
+                       char *names, int nameslen);
+int mdp_aeam_file_build(mdp_aeam_file *f, int ntypes, const int *map, mdp_aeam_tables *out); /* out points into f */
+void mdp_aeam_file_free(mdp_aeam_file *f);
 
 /* ---- host mode: the data a LAMMPS Pair::compute() holds ---------------------------------
  * replaces the reads of atom->x/type/tag/nlocal/nghost (pair_rebomos.cpp:288-290,370-374;

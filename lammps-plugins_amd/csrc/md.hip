@@ -1,25 +1,647 @@
-// md.hip -- resident-mode MD around the hot path (placeholder: lands in the next milestone)
+// md.hip -- resident mode: the LAMMPS host steps either side of Pair::compute(), kept on the GPU
+// so that x and f never cross PCIe inside the MD loop:
+//   * binned full(+ghost) neighbor-list build  (LAMMPS "pair build: full/bin/ghost",
+//     USER-REBOMOS/log.rebomos-bulk.1:40-51; per-type-pair cutoffs for AEAM, USER-AEAM/sample.in:17)
+//   * fix nve velocity-Verlet halves, periodic self-image ghost refresh (forward comm on one rank)
+//   * thermo reductions (KE, max displacement for `neigh_modify check yes`)
+//   * halo pack / unpack kernels for the multi-GPU exchange (transport is the caller's: RCCL)
 #include "mdp_common.h"
-#define NI(c) return mdp_fail(c, MDP_ENOTIMPL, "resident mode: not built yet")
-int mdp_md_build_master_list(mdp_ctx *c) { NI(c); }
-extern "C" {
-int mdp_md_setup(mdp_ctx *c, const mdp_md_config *, const double *, const double *, const int *, const int *, const double *, const int *, const int *, const double *, const int *, const int *) { NI(c); }
-int mdp_md_build_neighbors(mdp_ctx *c) { NI(c); }
-int mdp_md_initial_integrate(mdp_ctx *c) { NI(c); }
-int mdp_md_final_integrate(mdp_ctx *c) { NI(c); }
-int mdp_md_compute(mdp_ctx *c, int, int) { NI(c); }
-int mdp_md_pack_x(mdp_ctx *c, int, const int *, const double *, double *) { NI(c); }
-int mdp_md_unpack_x(mdp_ctx *c, int, int, const double *) { NI(c); }
-int mdp_md_pack_scalar(mdp_ctx *c, int, int, const int *, double *) { NI(c); }
-int mdp_md_unpack_scalar(mdp_ctx *c, int, int, int, const double *) { NI(c); }
-int mdp_md_pack_ghost_f(mdp_ctx *c, int, int, double *) { NI(c); }
-int mdp_md_unpack_add_f(mdp_ctx *c, int, const int *, const double *) { NI(c); }
-int mdp_md_fold_self_ghost_f(mdp_ctx *c) { NI(c); }
-int mdp_md_aeam_density(mdp_ctx *c, int) { NI(c); }
-int mdp_md_aeam_force(mdp_ctx *c, int, int) { NI(c); }
-int mdp_md_thermo(mdp_ctx *c, double *) { NI(c); }
-int mdp_md_download(mdp_ctx *c, double *, double *, double *, double *) { NI(c); }
-int mdp_md_upload_x(mdp_ctx *c, const double *) { NI(c); }
-void *mdp_md_ptr(mdp_ctx *, const char *) { return nullptr; }
-int mdp_md_neighbor_stats(mdp_ctx *c, long long *) { NI(c); }
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+
+void mdp_rebomos_fill_dev(mdp_ctx *c, double skin);
+
+namespace {
+
+struct CutTables {
+  double owned[16]; // cutneighsq[ei*4+ej]  element/type pair
+  double ghost[16]; // 0 => no ghost lists
+  int ne;           // table stride
+};
+
+struct Grid {
+  double lo[3], inv[3];
+  int n[3];
+  int range; // stencil half width in cells
+};
+
+__device__ __forceinline__ int cell_index(const Grid &g, const double4 &x, int &cx, int &cy, int &cz)
+{
+  cx = (int) ((x.x - g.lo[0]) * g.inv[0]);
+  cy = (int) ((x.y - g.lo[1]) * g.inv[1]);
+  cz = (int) ((x.z - g.lo[2]) * g.inv[2]);
+  cx = cx < 0 ? 0 : (cx >= g.n[0] ? g.n[0] - 1 : cx);
+  cy = cy < 0 ? 0 : (cy >= g.n[1] ? g.n[1] - 1 : cy);
+  cz = cz < 0 ? 0 : (cz >= g.n[2] ? g.n[2] - 1 : cz);
+  return cx + g.n[0] * (cy + g.n[1] * cz);
 }
+
+__global__ void cell_assign_kernel(const Grid g, int nall, const double4 *__restrict__ xq, unsigned *__restrict__ key,
+                                   int *__restrict__ val)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nall) return;
+  int cx, cy, cz;
+  key[i] = (unsigned) cell_index(g, xq[i], cx, cy, cz);
+  val[i] = i;
+}
+
+__global__ void cell_bounds_kernel(int nall, const unsigned *__restrict__ key_sorted, int *__restrict__ cell_start)
+{
+  // cell_start[c] .. cell_start[c+1] delimit cell c in the sorted order; filled for every cell
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= nall) return;
+  const unsigned k = key_sorted[p];
+  const unsigned kprev = p == 0 ? 0u : key_sorted[p - 1];
+  if (p == 0)
+    for (unsigned c = 0; c <= k; c++) cell_start[c] = 0;
+  else
+    for (unsigned c = kprev + 1; c <= k; c++) cell_start[c] = p;
+}
+
+__global__ void cell_tail_kernel(int nall, int ncell, const unsigned *__restrict__ key_sorted,
+                                 int *__restrict__ cell_start)
+{
+  const unsigned last = key_sorted[nall - 1];
+  for (int c = (int) last + 1 + threadIdx.x; c <= ncell; c += blockDim.x) cell_start[c] = nall;
+}
+
+// one thread per atom, threads walk the atoms in cell order so a wave shares its stencil
+template <bool FILL>
+__global__ __launch_bounds__(256) void nbuild_kernel(const Grid g, const CutTables ct, int nall, int nlocal,
+                                                     const double4 *__restrict__ xq, const int *__restrict__ perm,
+                                                     const int *__restrict__ cell_start, int *__restrict__ cnt,
+                                                     const long long *__restrict__ off, int *__restrict__ nb)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nall) return;
+  const int i = perm[t];
+  const double4 xi = xq[i];
+  const int ti = (int) xi.w;
+  const double *tab = (i < nlocal) ? ct.owned : ct.ghost;
+  if (i >= nlocal && ct.ghost[0] <= 0.0) {
+    if (!FILL) cnt[i] = 0;
+    return;
+  }
+  int cx, cy, cz;
+  cell_index(g, xi, cx, cy, cz);
+  // ghosts only need the short (rcmax+skin) range: one cell around is enough when range >= 1
+  int n = 0;
+  int *row = FILL ? nb + off[i] : nullptr;
+  const int R = g.range;
+  for (int z = max(cz - R, 0); z <= min(cz + R, g.n[2] - 1); z++)
+    for (int y = max(cy - R, 0); y <= min(cy + R, g.n[1] - 1); y++) {
+      const int c0 = max(cx - R, 0) + g.n[0] * (y + g.n[1] * z);
+      const int c1 = min(cx + R, g.n[0] - 1) + g.n[0] * (y + g.n[1] * z);
+      const int pb = cell_start[c0], pe = cell_start[c1 + 1]; // cells along x are contiguous in the sort
+      for (int p = pb; p < pe; p++) {
+        const int j = perm[p];
+        const double4 xj = xq[j];
+        const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        if (rsq <= tab[ti * ct.ne + (int) xj.w] && j != i) {
+          if (FILL) row[n] = j;
+          n++;
+        }
+      }
+    }
+  if (!FILL) cnt[i] = n;
+}
+
+__global__ void nve_initial_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
+                                   const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlocal) return;
+  const double s = dtf / rmass[i];
+  double vx = v[3 * (size_t) i] + s * f[3 * (size_t) i];
+  double vy = v[3 * (size_t) i + 1] + s * f[3 * (size_t) i + 1];
+  double vz = v[3 * (size_t) i + 2] + s * f[3 * (size_t) i + 2];
+  v[3 * (size_t) i] = vx;
+  v[3 * (size_t) i + 1] = vy;
+  v[3 * (size_t) i + 2] = vz;
+  double4 x = xq[i];
+  x.x += dt * vx;
+  x.y += dt * vy;
+  x.z += dt * vz;
+  xq[i] = x;
+}
+
+__global__ void nve_final_kernel(int nlocal, double dtf, const double *__restrict__ rmass,
+                                 const double *__restrict__ f, double *__restrict__ v)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlocal) return;
+  const double s = dtf / rmass[i];
+  v[3 * (size_t) i] += s * f[3 * (size_t) i];
+  v[3 * (size_t) i + 1] += s * f[3 * (size_t) i + 1];
+  v[3 * (size_t) i + 2] += s * f[3 * (size_t) i + 2];
+}
+
+__global__ void ghost_refresh_kernel(int nlocal, int nghost, const int *__restrict__ owner,
+                                     const double *__restrict__ shift, double4 *__restrict__ xq)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nghost) return;
+  const int o = owner[g];
+  if (o < 0) return;
+  const double4 xo = xq[o];
+  double4 x = xq[nlocal + g];
+  x.x = xo.x + shift[3 * (size_t) g];
+  x.y = xo.y + shift[3 * (size_t) g + 1];
+  x.z = xo.z + shift[3 * (size_t) g + 2];
+  xq[nlocal + g] = x;
+}
+
+__global__ void ghost_scalar_refresh_kernel(int nlocal, int nghost, const int *__restrict__ owner,
+                                            double *__restrict__ a)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nghost) return;
+  const int o = owner[g];
+  if (o >= 0) a[nlocal + g] = a[o];
+}
+
+__global__ void fold_self_ghost_f_kernel(int nlocal, int nghost, const int *__restrict__ owner, double *__restrict__ f)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nghost) return;
+  const int o = owner[g];
+  if (o < 0) return;
+  double *fg = f + 3 * (size_t) (nlocal + g);
+  if (fg[0] != 0.0 || fg[1] != 0.0 || fg[2] != 0.0) {
+    atomicAdd(&f[3 * (size_t) o], fg[0]);
+    atomicAdd(&f[3 * (size_t) o + 1], fg[1]);
+    atomicAdd(&f[3 * (size_t) o + 2], fg[2]);
+    fg[0] = fg[1] = fg[2] = 0.0;
+  }
+}
+
+__global__ void hold_kernel(int nlocal, const double4 *__restrict__ xq, double *__restrict__ xhold)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlocal) return;
+  const double4 x = xq[i];
+  xhold[3 * (size_t) i] = x.x;
+  xhold[3 * (size_t) i + 1] = x.y;
+  xhold[3 * (size_t) i + 2] = x.z;
+}
+
+// out[7] += KE, out[8] = max(out[8], disp^2)   (acc[7], acc[8])
+__global__ __launch_bounds__(256) void thermo_kernel(int nlocal, double half_mvv2e, const double *__restrict__ rmass,
+                                                     const double *__restrict__ v, const double4 *__restrict__ xq,
+                                                     const double *__restrict__ xhold, double *__restrict__ acc)
+{
+  double ke = 0.0, d2 = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nlocal; i += gridDim.x * 256) {
+    const double vx = v[3 * (size_t) i], vy = v[3 * (size_t) i + 1], vz = v[3 * (size_t) i + 2];
+    ke += rmass[i] * (vx * vx + vy * vy + vz * vz);
+    const double4 x = xq[i];
+    const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1],
+                 dz = x.z - xhold[3 * (size_t) i + 2];
+    d2 = fmax(d2, dx * dx + dy * dy + dz * dz);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ke += __shfl_xor(ke, o, 64);
+    d2 = fmax(d2, __shfl_xor(d2, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&acc[7], half_mvv2e * ke);
+    // d2 >= 0: compare as integers
+    atomicMax((unsigned long long *) &acc[8], (unsigned long long) __double_as_longlong(d2));
+  }
+}
+
+__global__ void pack_x_kernel(int n, const int *__restrict__ sendlist, const double *__restrict__ shift,
+                              const double4 *__restrict__ xq, double *__restrict__ buf)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const double4 x = xq[sendlist[k]];
+  buf[3 * (size_t) k] = x.x + (shift ? shift[3 * (size_t) k] : 0.0);
+  buf[3 * (size_t) k + 1] = x.y + (shift ? shift[3 * (size_t) k + 1] : 0.0);
+  buf[3 * (size_t) k + 2] = x.z + (shift ? shift[3 * (size_t) k + 2] : 0.0);
+}
+
+__global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf, double4 *__restrict__ xq)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  double4 x = xq[first + k];
+  x.x = buf[3 * (size_t) k];
+  x.y = buf[3 * (size_t) k + 1];
+  x.z = buf[3 * (size_t) k + 2];
+  xq[first + k] = x;
+}
+
+__global__ void pack_scalar_kernel(int n, const int *__restrict__ sendlist, const double *__restrict__ a,
+                                   double *__restrict__ buf)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) buf[k] = a[sendlist[k]];
+}
+
+__global__ void copy_kernel(int n, const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+
+__global__ void unpack_add_f_kernel(int n, const int *__restrict__ sendlist, const double *__restrict__ buf,
+                                    double *__restrict__ f)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int i = sendlist[k];
+  // several ghosts (images) may map to one owner
+  atomicAdd(&f[3 * (size_t) i], buf[3 * (size_t) k]);
+  atomicAdd(&f[3 * (size_t) i + 1], buf[3 * (size_t) k + 1]);
+  atomicAdd(&f[3 * (size_t) i + 2], buf[3 * (size_t) k + 2]);
+}
+
+__global__ void xq_to_x3_kernel(int n, const double4 *__restrict__ xq, double *__restrict__ x3)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double4 x = xq[i];
+  x3[3 * (size_t) i] = x.x;
+  x3[3 * (size_t) i + 1] = x.y;
+  x3[3 * (size_t) i + 2] = x.z;
+}
+
+__global__ void x3_to_xq_kernel(int n, const double *__restrict__ x3, double4 *__restrict__ xq)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double4 x = xq[i];
+  x.x = x3[3 * (size_t) i];
+  x.y = x3[3 * (size_t) i + 1];
+  x.z = x3[3 * (size_t) i + 2];
+  xq[i] = x;
+}
+
+inline int nblk(long long n) { return (int) ((n + 255) / 256); }
+
+} // namespace
+
+// ---- neighbor-list cutoffs the style's init_one() would hand the host ----------------------------
+static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
+{
+  memset(&ct, 0, sizeof ct);
+  maxcut = 0.0;
+  const double skin = c->cfg.skin;
+  if (c->cfg.style == 1) {
+    if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
+    ct.ne = 2;
+    const double cut3 = 3.0 * c->rebomos_host.rcmax[0][0] + skin; // pair_rebomos.cpp:257 (+ skin)
+    for (int a = 0; a < 2; a++)
+      for (int b = 0; b < 2; b++) {
+        ct.owned[a * 2 + b] = cut3 * cut3;
+        const double cg = c->rebomos_host.rcmax[a][b] + skin;     // cutghost, pair_rebomos.cpp:261
+        ct.ghost[a * 2 + b] = cg * cg;
+      }
+    maxcut = cut3;
+  } else if (c->cfg.style == 2) {
+    if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
+    const int nt = c->aeam.ntypes;
+    ct.ne = nt;
+    for (int a = 0; a < nt; a++)
+      for (int b = 0; b < nt; b++) {
+        const double cc = c->aeam.cut[a * nt + b] + skin;         // pair_aeam.cpp:618-620 (+ skin)
+        ct.owned[a * nt + b] = cc * cc;
+        if (cc > maxcut) maxcut = cc;
+      }
+  } else
+    return mdp_fail(c, MDP_EINVAL, "unknown style %d", c->cfg.style);
+  return MDP_OK;
+}
+
+int mdp_md_build_master_list(mdp_ctx *c)
+{
+  const int nall = c->nall, nlocal = c->nlocal;
+  hipStream_t st = c->stream;
+  CutTables ct;
+  double maxcut;
+  MDP_TRY(md_cut_tables(c, ct, maxcut));
+  Grid g;
+  const double binsize = 0.5 * maxcut; // LAMMPS default: half the master cutoff (log.rebomos-bulk.1:45)
+  g.range = 2;
+  long long ncell = 1;
+  for (int d = 0; d < 3; d++) {
+    const double len = c->cfg.bbox_hi[d] - c->cfg.bbox_lo[d];
+    if (!(len > 0.0)) return mdp_fail(c, MDP_EINVAL, "empty bounding box");
+    int n = (int) floor(len / binsize);
+    if (n < 1) n = 1;
+    g.n[d] = n;
+    g.lo[d] = c->cfg.bbox_lo[d];
+    g.inv[d] = n / len; // cells are >= binsize wide
+    ncell *= n;
+  }
+  if (ncell > (1ll << 30)) return mdp_fail(c, MDP_EINVAL, "too many bins");
+  MDP_HIP(c, c->sort_keys_a.reserve(nall + 1));
+  MDP_HIP(c, c->sort_keys_b.reserve(nall + 1));
+  MDP_HIP(c, c->cell_of.reserve(nall + 1));   // values in
+  MDP_HIP(c, c->cell_perm.reserve(nall + 1)); // values out
+  MDP_HIP(c, c->cell_start.reserve((size_t) ncell + 2));
+  MDP_HIP(c, c->nb_cnt.reserve(nall + 2));
+  MDP_HIP(c, c->nb_off.reserve(nall + 2));
+  cell_assign_kernel<<<nblk(nall), 256, 0, st>>>(g, nall, c->xq.p, c->sort_keys_a.p, c->cell_of.p);
+  MDP_HIP(c, hipGetLastError());
+  int bits = 1;
+  while ((1ll << bits) < ncell) bits++;
+  size_t tmp = 0;
+  MDP_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p, c->cell_perm.p,
+                                       (size_t) nall, 0, bits, st));
+  MDP_HIP(c, c->scan_tmp.reserve(tmp + 16));
+  MDP_HIP(c, rocprim::radix_sort_pairs(c->scan_tmp.p, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p,
+                                       c->cell_perm.p, (size_t) nall, 0, bits, st));
+  cell_bounds_kernel<<<nblk(nall), 256, 0, st>>>(nall, c->sort_keys_b.p, c->cell_start.p);
+  cell_tail_kernel<<<1, 256, 0, st>>>(nall, (int) ncell, c->sort_keys_b.p, c->cell_start.p);
+  MDP_HIP(c, hipGetLastError());
+  nbuild_kernel<false><<<nblk(nall), 256, 0, st>>>(g, ct, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
+                                                    c->nb_cnt.p, nullptr, nullptr);
+  MDP_HIP(c, hipGetLastError());
+  MDP_TRY(mdp_scan_exclusive_i64(c, c->nb_cnt.p, c->nb_off.p, nall));
+  long long tot[2] = {0, 0};
+  MDP_HIP(c, hipMemcpyAsync(&tot[0], c->nb_off.p + nall, sizeof(long long), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(&tot[1], c->nb_off.p + nlocal, sizeof(long long), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  c->nb_total = tot[0];
+  c->nb_owned_total = tot[1];
+  MDP_HIP(c, c->nb.reserve((size_t) tot[0] + 1));
+  nbuild_kernel<true><<<nblk(nall), 256, 0, st>>>(g, ct, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
+                                                   nullptr, c->nb_off.p, c->nb.p);
+  MDP_HIP(c, hipGetLastError());
+  c->skin = c->cfg.skin;
+  c->neigh_set = true;
+  c->rebo_packed = false;
+  return MDP_OK;
+}
+
+extern "C" {
+
+int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const double *v, const int *type,
+                 const int *tag, const double *mass, const int *map, const int *ghost_owner, const double *ghost_shift,
+                 const int *ghost_type, const int *ghost_tag)
+{
+  if (!c || !cfg || !x || !type || !mass) return MDP_EINVAL;
+  if (cfg->nlocal < 0 || cfg->nghost < 0 || cfg->ntypes < 1 || cfg->ntypes > 15)
+    return mdp_fail(c, MDP_EINVAL, "mdp_md_setup: bad sizes");
+  if (cfg->nghost > 0 && (!ghost_owner || !ghost_shift || !ghost_type))
+    return mdp_fail(c, MDP_EINVAL, "mdp_md_setup: ghost arrays missing");
+  MDP_HIP(c, hipSetDevice(c->device));
+  c->cfg = *cfg;
+  const int nlocal = cfg->nlocal, nghost = cfg->nghost, nall = nlocal + nghost;
+  if ((long long) nall >= (1ll << 29)) return mdp_fail(c, MDP_EINVAL, "too many atoms for NEIGHMASK");
+  // host-side assembly of the [nall] arrays, then the same upload path as host mode
+  std::vector<double> xa((size_t) 3 * nall);
+  std::vector<int> ta(nall), ga(nall, 0);
+  memcpy(xa.data(), x, sizeof(double) * 3 * nlocal);
+  memcpy(ta.data(), type, sizeof(int) * nlocal);
+  if (tag) memcpy(ga.data(), tag, sizeof(int) * nlocal);
+  for (int g = 0; g < nghost; g++) {
+    const int o = ghost_owner[g];
+    if (o >= nlocal) return mdp_fail(c, MDP_EINVAL, "ghost owner %d out of range", o);
+    for (int d = 0; d < 3; d++)
+      xa[3 * (size_t) (nlocal + g) + d] = (o >= 0 ? x[3 * (size_t) o + d] : 0.0) + ghost_shift[3 * (size_t) g + d];
+    ta[nlocal + g] = ghost_type[g];
+    if (ghost_tag) ga[nlocal + g] = ghost_tag[g];
+  }
+  MDP_TRY(mdp_set_atoms_host(c, nlocal, nghost, xa.data(), ta.data(), ga.data(), cfg->ntypes, map));
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->v.reserve((size_t) 3 * nlocal + 3));
+  MDP_HIP(c, c->xhold.reserve((size_t) 3 * nlocal + 3));
+  MDP_HIP(c, c->rmass.reserve(nlocal + 1));
+  MDP_HIP(c, c->ghost_owner.reserve(nghost + 1));
+  MDP_HIP(c, c->ghost_shift.reserve((size_t) 3 * nghost + 3));
+  MDP_HIP(c, c->rho.reserve(nall + 1));
+  MDP_HIP(c, c->fp.reserve(nall + 1));
+  std::vector<double> rm(nlocal);
+  for (int i = 0; i < nlocal; i++) {
+    if (type[i] < 1 || type[i] > cfg->ntypes) return mdp_fail(c, MDP_EINVAL, "atom type out of range");
+    rm[i] = mass[type[i]];
+  }
+  if (nlocal) MDP_HIP(c, hipMemcpyAsync(c->rmass.p, rm.data(), sizeof(double) * nlocal, hipMemcpyHostToDevice, st));
+  if (v && nlocal)
+    MDP_HIP(c, hipMemcpyAsync(c->v.p, v, sizeof(double) * 3 * nlocal, hipMemcpyHostToDevice, st));
+  else
+    MDP_HIP(c, hipMemsetAsync(c->v.p, 0, sizeof(double) * 3 * nlocal, st));
+  if (nghost) {
+    MDP_HIP(c, hipMemcpyAsync(c->ghost_owner.p, ghost_owner, sizeof(int) * nghost, hipMemcpyHostToDevice, st));
+    MDP_HIP(c, hipMemcpyAsync(c->ghost_shift.p, ghost_shift, sizeof(double) * 3 * nghost, hipMemcpyHostToDevice, st));
+  }
+  MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * nall, st));
+  MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * nall, st));
+  MDP_HIP(c, hipMemsetAsync(c->fp.p, 0, sizeof(double) * nall, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  c->md = true;
+  return MDP_OK;
+}
+
+int mdp_md_build_neighbors(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  MDP_HIP(c, hipSetDevice(c->device));
+  MDP_TRY(mdp_md_build_master_list(c));
+  hold_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, c->xq.p, c->xhold.p);
+  MDP_HIP(c, hipGetLastError());
+  if (c->cfg.style == 1) return mdp_rebomos_repack(c);
+  return mdp_aeam_prepare(c);
+}
+
+int mdp_md_initial_integrate(mdp_ctx *c)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
+  if (c->nlocal)
+    nve_initial_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p,
+                                                               c->xq.p);
+  if (c->nghost)
+    ghost_refresh_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
+                                                                 c->ghost_shift.p, c->xq.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_final_integrate(mdp_ctx *c)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
+  if (c->nlocal) nve_final_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->rmass.p, c->f.p, c->v.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_aeam_density(mdp_ctx *c, int eflag)
+{
+  if (!c || !c->md || c->cfg.style != 2) return MDP_EINVAL;
+  MDP_TRY(mdp_aeam_run_density(c, eflag));
+  // forward comm of fp on one rank: periodic self-images copy their owner's value
+  if (c->nghost)
+    ghost_scalar_refresh_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
+                                                                        c->fp.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_aeam_force(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c || !c->md || c->cfg.style != 2) return MDP_EINVAL;
+  return mdp_aeam_run_force(c, eflag, vflag);
+}
+
+int mdp_md_fold_self_ghost_f(mdp_ctx *c)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  if (c->nghost)
+    fold_self_ghost_f_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p, c->f.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_compute(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
+  if (c->cfg.style == 1) return mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true);
+  // single-rank AEAM: density, self-image fp refresh, force, fold angular ghost forces
+  MDP_TRY(mdp_md_aeam_density(c, eflag));
+  MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
+  return mdp_md_fold_self_ghost_f(c);
+}
+
+int mdp_md_thermo(mdp_ctx *c, double out[9])
+{
+  if (!c || !c->md || !out) return MDP_EINVAL;
+  hipStream_t st = c->stream;
+  MDP_HIP(c, hipMemsetAsync(c->acc.p + 7, 0, sizeof(double) * 2, st));
+  const int grid = c->nlocal > 0 ? (nblk(c->nlocal) < 1024 ? nblk(c->nlocal) : 1024) : 0;
+  if (grid)
+    thermo_kernel<<<grid, 256, 0, st>>>(c->nlocal, 0.5 * c->cfg.mvv2e, c->rmass.p, c->v.p, c->xq.p, c->xhold.p,
+                                         c->acc.p);
+  MDP_HIP(c, hipGetLastError());
+  MDP_HIP(c, hipMemcpyAsync(c->h_pinned, c->acc.p, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+  int *hflags = (int *) (c->h_pinned + 16);
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  if (hflags[0] & 1)
+    return mdp_fail(c, MDP_EOVERFLOW, "REBO neighbor count exceeds the lane-group capacity (Neighbor list overflow)");
+  out[0] = c->h_pinned[7];
+  out[1] = c->h_pinned[0];
+  for (int k = 0; k < 6; k++) out[2 + k] = c->h_pinned[1 + k];
+  out[8] = c->h_pinned[8];
+  return MDP_OK;
+}
+
+int mdp_md_download(mdp_ctx *c, double *x, double *v, double *f, double *eatom)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  hipStream_t st = c->stream;
+  const int n = c->nlocal;
+  if (x && n) {
+    xq_to_x3_kernel<<<nblk(n), 256, 0, st>>>(n, c->xq.p, c->xraw.p);
+    MDP_HIP(c, hipMemcpyAsync(x, c->xraw.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  }
+  if (v && n) MDP_HIP(c, hipMemcpyAsync(v, c->v.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  if (f && n) MDP_HIP(c, hipMemcpyAsync(f, c->f.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  if (eatom && n) MDP_HIP(c, hipMemcpyAsync(eatom, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  return MDP_OK;
+}
+
+int mdp_md_upload_x(mdp_ctx *c, const double *x)
+{
+  if (!c || !c->md || !x) return MDP_EINVAL;
+  hipStream_t st = c->stream;
+  const int n = c->nlocal;
+  if (n) {
+    MDP_HIP(c, hipMemcpyAsync(c->xraw.p, x, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    x3_to_xq_kernel<<<nblk(n), 256, 0, st>>>(n, c->xraw.p, c->xq.p);
+  }
+  if (c->nghost)
+    ghost_refresh_kernel<<<nblk(c->nghost), 256, 0, st>>>(c->nlocal, c->nghost, c->ghost_owner.p, c->ghost_shift.p,
+                                                          c->xq.p);
+  MDP_HIP(c, hipGetLastError());
+  MDP_HIP(c, hipStreamSynchronize(st));
+  return MDP_OK;
+}
+
+void *mdp_md_ptr(mdp_ctx *c, const char *name)
+{
+  if (!c || !name) return nullptr;
+  if (!strcmp(name, "x")) return c->xq.p; // double4 {x,y,z,element}
+  if (!strcmp(name, "v")) return c->v.p;
+  if (!strcmp(name, "f")) return c->f.p;
+  if (!strcmp(name, "fp")) return c->fp.p;
+  if (!strcmp(name, "eatom")) return c->eatom.p;
+  return nullptr;
+}
+
+int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
+{
+  if (!c || !out) return MDP_EINVAL;
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  out[0] = c->nb_owned_total;
+  out[1] = c->nb_total - c->nb_owned_total;
+  out[2] = c->lj_total;
+  out[3] = c->cand_total;
+  out[4] = (long long) c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
+  out[5] = c->h_class_count[0];
+  out[6] = c->h_class_count[2];
+  out[7] = c->h_ang_count;
+  return MDP_OK;
+}
+
+// ---- halo plumbing -----------------------------------------------------------------------------------
+int mdp_md_pack_x(mdp_ctx *c, int n, const int *d_sendlist, const double *d_shift, double *d_buf)
+{
+  if (!c || n < 0) return MDP_EINVAL;
+  if (n) pack_x_kernel<<<nblk(n), 256, 0, c->stream>>>(n, d_sendlist, d_shift, c->xq.p, d_buf);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_unpack_x(mdp_ctx *c, int first_ghost, int n, const double *d_buf)
+{
+  if (!c || n < 0 || first_ghost < 0 || first_ghost + n > c->nghost) return MDP_EINVAL;
+  if (n) unpack_x_kernel<<<nblk(n), 256, 0, c->stream>>>(n, c->nlocal + first_ghost, d_buf, c->xq.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_pack_scalar(mdp_ctx *c, int which, int n, const int *d_sendlist, double *d_buf)
+{
+  if (!c || n < 0 || which != 0) return MDP_EINVAL;
+  if (n) pack_scalar_kernel<<<nblk(n), 256, 0, c->stream>>>(n, d_sendlist, c->fp.p, d_buf);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_unpack_scalar(mdp_ctx *c, int which, int first_ghost, int n, const double *d_buf)
+{
+  if (!c || n < 0 || which != 0 || first_ghost < 0 || first_ghost + n > c->nghost) return MDP_EINVAL;
+  if (n) copy_kernel<<<nblk(n), 256, 0, c->stream>>>(n, d_buf, c->fp.p + c->nlocal + first_ghost);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_pack_ghost_f(mdp_ctx *c, int first_ghost, int n, double *d_buf)
+{
+  if (!c || n < 0 || first_ghost < 0 || first_ghost + n > c->nghost) return MDP_EINVAL;
+  if (n) copy_kernel<<<nblk(3ll * n), 256, 0, c->stream>>>(3 * n, c->f.p + 3 * (size_t) (c->nlocal + first_ghost), d_buf);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_unpack_add_f(mdp_ctx *c, int n, const int *d_sendlist, const double *d_buf)
+{
+  if (!c || n < 0) return MDP_EINVAL;
+  if (n) unpack_add_f_kernel<<<nblk(n), 256, 0, c->stream>>>(n, d_sendlist, d_buf, c->f.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+} // extern "C"

@@ -41,7 +41,8 @@ class MdConfig(C.Structure):
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
 EXPORTS = [
     "mdp_abi_version", "mdp_device_count", "mdp_create", "mdp_destroy", "mdp_last_error", "mdp_set_stream",
-    "mdp_sync", "mdp_rebomos_set_params", "mdp_aeam_set_tables", "mdp_set_atoms_host", "mdp_set_positions_host",
+    "mdp_sync", "mdp_rebomos_set_params", "mdp_rebomos_read_file", "mdp_rebomos_params_from_scalars",
+    "mdp_aeam_set_tables", "mdp_aeam_file_read", "mdp_aeam_file_info", "mdp_aeam_file_build", "mdp_aeam_file_free", "mdp_set_atoms_host", "mdp_set_positions_host",
     "mdp_set_neighbors_host", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
     "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
     "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
@@ -78,6 +79,59 @@ def _dp(a):
 
 def _ip(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def read_rebomos_file(path: str) -> RebomosParams:
+    """product-side parser (csrc/potfile.cpp), mirrors PairREBOMoS::read_file"""
+    p = RebomosParams()
+    err = C.create_string_buffer(512)
+    rc = lib().mdp_rebomos_read_file(path.encode(), C.byref(p), err, C.c_int(512))
+    if rc:
+        raise MdpError(rc, err.value.decode())
+    return p
+
+
+class AeamFile:
+    """product-side AEAM potential file (csrc/potfile.cpp), mirrors PairAEAM::read_file + array2spline"""
+
+    def __init__(self, path: str):
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().mdp_aeam_file_read(path.encode(), C.byref(self.h), err, C.c_int(512))
+        if rc:
+            raise MdpError(rc, err.value.decode())
+        ne, nn, na = C.c_int(), C.c_int(), C.c_int()
+        mass = (C.c_double * 4)()
+        names = C.create_string_buffer(128)
+        lib().mdp_aeam_file_info(self.h, C.byref(ne), C.byref(nn), C.byref(na), mass, names, C.c_int(128))
+        self.nelements, self.nnonangular, self.nangular = ne.value, nn.value, na.value
+        self.mass = list(mass)[:ne.value]
+        self.elements = names.value.decode().split()
+
+    def build(self, ntypes: int | None = None, map_=None) -> AeamTables:
+        ntypes = self.nelements if ntypes is None else ntypes
+        m = np.ascontiguousarray([0] + list(range(ntypes)) if map_ is None else map_, dtype=np.int32)
+        t = AeamTables()
+        rc = lib().mdp_aeam_file_build(self.h, C.c_int(ntypes), _ip(m), C.byref(t))
+        if rc:
+            raise MdpError(rc, "mdp_aeam_file_build failed")
+        return t
+
+    def cut_table(self, t: AeamTables) -> np.ndarray:
+        """(ntypes+1, ntypes+1) table of setfl->cut[i-1][j-1] (what init_one returns)"""
+        ne = t.nelements
+        cut = np.ctypeslib.as_array(t.cut, shape=(ne, ne))
+        out = np.zeros((t.ntypes + 1, t.ntypes + 1))
+        out[1:, 1:] = cut[:t.ntypes, :t.ntypes]
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mdp_aeam_file_free(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
 
 
 def rebomos_params_from_oracle(P) -> RebomosParams:

@@ -1,0 +1,93 @@
+"""GPU, resident mode: device neighbor build + device NVE + device thermo around the REBO-MoS hot
+path reproduce the reference log (config #2, in.rebomos-bulk) without x/f ever visiting the host."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, POT_REBOMOS
+from lammps_plugins_amd.host import capi, resident, system as S
+import mdref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def log():
+    return json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+
+
+def _domain(s, sort, v0=None, skin=2.0):
+    ctx = capi.Context(0)
+    p = capi.read_rebomos_file(POT_REBOMOS)
+    ctx.rebomos_set_params(p)
+    cutghost = 3.0 * p.rcmax[0][0] + skin
+    d = resident.Domain.single(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, map_=[0, 0, 1], v0=v0, sort=sort)
+    return ctx, d
+
+
+@pytest.mark.parametrize("sort", [False, True])
+def test_in_rebomos_bulk_on_device(log, sort):
+    s = S.rebomos_bulk_cell()
+    ctx, d = _domain(s, sort)
+    assert d.nghost == log["nghost"]
+    d.build_neighbors()
+    st = ctx.md_neighbor_stats()
+    assert st[0] == log["full_neighbors"]           # FullNghs 142848 (log.rebomos-bulk.1:82)
+    d.compute(eflag=1, vflag=1)
+    rows = [d.thermo()]
+    for step in range(1, 21):
+        ev = 1 if step % 10 == 0 else 0
+        d.step(eflag=ev, vflag=ev)
+        if ev:
+            rows.append(d.thermo())
+    for got, ref in zip(rows, log["thermo"]):
+        assert got["pe"] == pytest.approx(ref["pe"], abs=5.1e-5)
+        assert got["ke"] == pytest.approx(ref["ke"], abs=5.1e-8)
+        assert got["temp"] == pytest.approx(ref["temp"], abs=5.1e-5)
+        assert got["press"] == pytest.approx(ref["press"], abs=5.1e-3)
+    assert not d.needs_rebuild()                     # "Neighbor list builds = 0" (log.rebomos-bulk.1:83)
+    ctx.close()
+
+
+def test_device_list_forces_match_oracle(oracle):
+    """device-built list (different neighbor order than the host builder) gives the oracle's forces"""
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s = S.jitter(S.scale(S.rebomos_bulk_cell(), 1.12), 0.15, seed=1234)
+    ctx, d = _domain(s, sort=False)
+    d.build_neighbors()
+    d.compute(eflag=3, vflag=1)
+    t = d.thermo()
+    got = ctx.md_download(s.n, want=("x", "f", "eatom"))
+    o = mdref.RebomosCPU(oracle, P, S.System(s.box, got["x"], s.type, s.tag, s.mass)).compute(got["x"])
+    assert np.abs(got["f"] - o["f_owned"]).max() < 1e-9
+    assert np.abs(got["eatom"] - o["eatom_owned"]).max() < 1e-9
+    assert t["pe"] == pytest.approx(o["eng"], rel=1e-10)
+    assert np.allclose(t["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    ctx.close()
+
+
+def test_rebuild_after_motion_keeps_energy_conserved():
+    """hot start with a thin skin (0.3 A): atoms cross skin/2 every few dozen steps; rebuild on the
+    device when `check yes` fires and check NVE energy conservation across rebuilds"""
+    s = S.replicate(S.rebomos_bulk_cell(), (2, 1, 1))
+    v0 = S.gaussian_velocities(s, 900.0, seed=4)
+    ctx, d = _domain(s, sort=True, v0=v0, skin=0.3)
+    d.natoms_total = s.n
+    d.build_neighbors()
+    d.compute(eflag=1, vflag=1)
+    t0 = d.thermo()
+    e0 = t0["pe"] + t0["ke"]
+    builds0 = d.builds
+    for step in range(1, 401):
+        check = step % 5 == 0
+        d.ctx.md_initial_integrate()
+        if check and d.needs_rebuild():
+            d.build_neighbors()
+        d.ctx.md_compute(1 if check else 0, 0)
+        d.ctx.md_final_integrate()
+    t1 = d.thermo()
+    assert d.builds > builds0                      # the rebuild path really ran
+    assert abs((t1["pe"] + t1["ke"]) - e0) / s.n < 2e-5
+    ctx.close()
