@@ -27,6 +27,8 @@ void mdp_time_mark(mdp_ctx *c, int k)
     c->ev_made = true;
   }
   (void) hipEventRecord(c->ev[k], c->stream);
+  if (k == 0) c->ev_marks = 0;
+  if (k + 1 > c->ev_marks) c->ev_marks = k + 1;
 }
 
 namespace {
@@ -221,10 +223,11 @@ int mdp_get_timing(mdp_ctx *c, double ms[8])
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
   if (!c->timing || !c->ev_made) return MDP_OK;
   MDP_HIP(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i + 1 < c->ev_marks; i++) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) ms[i] = t;
   }
+  (void) hipGetLastError();
   return MDP_OK;
 }
 

@@ -151,6 +151,7 @@ struct mdp_ctx {
   bool timing = false;
   hipEvent_t ev[8] = {};
   bool ev_made = false;
+  int ev_marks = 0;
   double t_ms[8] = {};
 };
 

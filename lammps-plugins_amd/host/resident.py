@@ -104,3 +104,130 @@ class Domain:
         """`neigh_modify check yes`: any atom moved more than skin/2 since the last build"""
         t = self.ctx.md_thermo() if thermo is None else thermo
         return t["maxdisp2"] > (0.5 * self.skin) ** 2
+
+
+class RankDomain(Domain):
+    """one rank of a multi-GPU run: Domain + halo exchange over torch.distributed (RCCL on the GPU box)"""
+
+    @classmethod
+    def from_plan(cls, ctx, style, s: S.System, xw: np.ndarray, plan, skin, map_, v0=None, dt=0.001):
+        """xw: wrapped positions of all atoms (same array the Decomposition was built from)"""
+        own = plan.owned
+        x = np.ascontiguousarray(xw[own])
+        v = np.zeros_like(x) if v0 is None else np.ascontiguousarray(np.asarray(v0)[own])
+        gshift = plan.ghost_shift.copy()
+        remote = plan.ghost_owner_local < 0
+        # remote ghosts carry their absolute start position in the shift slot (mdp_md_setup contract)
+        gshift[remote] += xw[plan.ghost_global[remote]]
+        d = cls(ctx, style, s.box, x, v, s.type[own], s.tag[own], s.mass, map_, plan.ghost_owner_local,
+                np.ascontiguousarray(gshift), s.type[plan.ghost_global], s.tag[plan.ghost_global], skin, dt)
+        d.plan = plan
+        d.natoms_total = s.n
+        d.halo = None
+        return d
+
+    def attach_halo(self, halo):
+        self.halo = halo
+
+    def forward_positions(self):
+        h = self.halo
+        if h is None or (h.nsend == 0 and h.nrecv == 0):
+            return
+        self.ctx.md_pack_x(h.nsend, h.sendlist.data_ptr(), h.sendshift.data_ptr(), h.send3.data_ptr())
+        h.forward3()
+        self.ctx.md_unpack_x(self.plan.nself, h.nrecv, h.recv3.data_ptr())
+
+    def forward_fp(self):
+        h = self.halo
+        if h is None or (h.nsend == 0 and h.nrecv == 0):
+            return
+        self.ctx.md_pack_scalar(0, h.nsend, h.sendlist.data_ptr(), h.send1.data_ptr())
+        h.forward1()
+        self.ctx.md_unpack_scalar(0, self.plan.nself, h.nrecv, h.recv1.data_ptr())
+
+    def reverse_forces(self):
+        h = self.halo
+        self.ctx.md_fold_self_ghost_f()
+        if h is None or (h.nsend == 0 and h.nrecv == 0):
+            return
+        self.ctx.md_pack_ghost_f(self.plan.nself, h.nrecv, h.recv3.data_ptr())
+        h.reverse3()
+        self.ctx.md_unpack_add_f(h.nsend, h.sendlist.data_ptr(), h.send3.data_ptr())
+
+    def compute(self, eflag=0, vflag=0):
+        if self.style == capi.STYLE_REBOMOS:
+            self.ctx.md_compute(eflag, vflag)
+        else:
+            self.ctx.md_aeam_density(eflag)
+            self.forward_fp()
+            self.ctx.md_aeam_force(eflag, vflag)
+            self.reverse_forces()
+
+    def step(self, eflag=0, vflag=0):
+        self.ctx.md_initial_integrate()
+        self.forward_positions()
+        self.compute(eflag, vflag)
+        self.ctx.md_final_integrate()
+
+
+# ---------------------------------------------------------------------------------------------------
+# reneighboring with re-derived ghosts (LAMMPS: Comm::exchange + Comm::borders at every rebuild).
+# Rare (never in the 20-step reference run, log.rebomos-bulk.1:83) and therefore done the simple way:
+# positions/velocities come back to the host, atoms are re-wrapped, re-assigned to bricks, ghosts
+# re-derived and the sub-domain is uploaded again; the device then rebuilds and repacks its lists.
+# ---------------------------------------------------------------------------------------------------
+
+def gather_state(dom: Domain, s: S.System, dist=None, device=None):
+    """global (x, v) in tag order from the resident state of all ranks"""
+    got = dom.ctx.md_download(dom.nlocal, want=("x", "v"))
+    tags = dom.tags_local
+    x = np.zeros((s.n, 3))
+    v = np.zeros((s.n, 3))
+    if dist is None:
+        x[tags - 1] = got["x"]
+        v[tags - 1] = got["v"]
+        return x, v
+    import torch
+    world = dist.get_world_size()
+    nmax = torch.tensor([dom.nlocal], dtype=torch.int64, device=device)
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+    nmax = int(nmax.item())
+    mine = torch.zeros((nmax, 7), dtype=torch.float64, device=device)
+    mine[:dom.nlocal, 0] = torch.as_tensor(tags.astype(np.float64), device=device)
+    mine[:dom.nlocal, 1:4] = torch.as_tensor(got["x"], device=device)
+    mine[:dom.nlocal, 4:7] = torch.as_tensor(got["v"], device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    for p in parts:
+        a = p.cpu().numpy()
+        a = a[a[:, 0] > 0]
+        idx = a[:, 0].astype(np.int64) - 1
+        x[idx] = a[:, 1:4]
+        v[idx] = a[:, 4:7]
+    return x, v
+
+
+def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001, dist=None, device=None):
+    """(re)build the resident sub-domain of this rank from a global system"""
+    if dist is None:
+        d = Domain.single(ctx, style, s, cutghost, skin, map_, v0=v0, dt=dt)
+        d.tags_local = d.order_tag
+        d.natoms_total = s.n
+        return d
+    from . import decomp
+    xw = S.wrap(s.box, s.x)
+    dec = decomp.Decomposition(s.box, xw, dist.get_world_size(), cutghost)
+    plan = dec.plan(dist.get_rank())
+    d = RankDomain.from_plan(ctx, style, s, xw, plan, skin, map_, v0=v0, dt=dt)
+    d.tags_local = s.tag[plan.owned]
+    d.attach_halo(decomp.Halo(plan, device, dist))
+    return d
+
+
+def reneighbor(dom: Domain, s: S.System, cutghost, map_, dist=None, device=None) -> Domain:
+    x, v = gather_state(dom, s, dist, device)
+    s2 = S.System(s.box, x, s.type, s.tag, s.mass)
+    d = make_domain(dom.ctx, dom.style, s2, cutghost, dom.skin, map_, v0=v, dt=dom.dt, dist=dist, device=device)
+    d.builds = dom.builds
+    d.build_neighbors()
+    return d

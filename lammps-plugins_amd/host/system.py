@@ -175,19 +175,23 @@ def make_ghosts(box: Box, x: np.ndarray, cut: float, sublo=None, subhi=None, lam
     c = ghost_cut_lamda(box, cut)
     lo, hi = sublo - c, subhi + c
     owners, shifts = [], []
-    rng = [np.arange(int(np.floor(lo[d])) - 1, int(np.ceil(hi[d])) + 1) for d in range(3)]
-    for sx in rng[0]:
-        for sy in rng[1]:
-            for sz in rng[2]:
-                s = np.array([sx, sy, sz], dtype=float)
-                l = lam + s
-                inshell = np.all((l >= lo) & (l < hi), axis=1)
+    rng = [np.arange(int(np.floor(lo[d] - 1.0)), int(np.ceil(hi[d])) + 1) for d in range(3)]
+    # per-dimension masks once per shift value, then AND the three: 27 cheap passes for a big box
+    masks = [{int(sv): (lam[:, d] + sv >= lo[d]) & (lam[:, d] + sv < hi[d]) for sv in rng[d]} for d in range(3)]
+    masks = [{k: m for k, m in md.items() if m.any()} for md in masks]
+    for sx, mx in masks[0].items():
+        for sy, my in masks[1].items():
+            mxy = mx & my
+            if not mxy.any():
+                continue
+            for sz, mz in masks[2].items():
+                inshell = mxy & mz
                 if sx == 0 and sy == 0 and sz == 0:
-                    inshell &= ~owned_mask
+                    inshell = inshell & ~owned_mask
                 idx = np.nonzero(inshell)[0]
                 if len(idx):
                     owners.append(idx)
-                    shifts.append(np.broadcast_to(s, (len(idx), 3)))
+                    shifts.append(np.broadcast_to(np.array([sx, sy, sz], dtype=float), (len(idx), 3)))
     if not owners:
         return np.zeros(0, dtype=np.int64), np.zeros((0, 3))
     return np.concatenate(owners), np.concatenate(shifts)

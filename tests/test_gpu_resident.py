@@ -23,7 +23,11 @@ def _domain(s, sort, v0=None, skin=2.0):
     p = capi.read_rebomos_file(POT_REBOMOS)
     ctx.rebomos_set_params(p)
     cutghost = 3.0 * p.rcmax[0][0] + skin
-    d = resident.Domain.single(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, map_=[0, 0, 1], v0=v0, sort=sort)
+    if sort:
+        d = resident.make_domain(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, [0, 0, 1], v0=v0)
+    else:
+        d = resident.Domain.single(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, map_=[0, 0, 1], v0=v0, sort=False)
+    d.cutghost = cutghost
     return ctx, d
 
 
@@ -75,6 +79,7 @@ def test_rebuild_after_motion_keeps_energy_conserved():
     v0 = S.gaussian_velocities(s, 900.0, seed=4)
     ctx, d = _domain(s, sort=True, v0=v0, skin=0.3)
     d.natoms_total = s.n
+    d0 = d
     d.build_neighbors()
     d.compute(eflag=1, vflag=1)
     t0 = d.thermo()
@@ -84,7 +89,7 @@ def test_rebuild_after_motion_keeps_energy_conserved():
         check = step % 5 == 0
         d.ctx.md_initial_integrate()
         if check and d.needs_rebuild():
-            d.build_neighbors()
+            d = resident.reneighbor(d, s, d0.cutghost, [0, 0, 1])   # re-wrap, re-derive ghosts, rebuild
         d.ctx.md_compute(1 if check else 0, 0)
         d.ctx.md_final_integrate()
     t1 = d.thermo()
