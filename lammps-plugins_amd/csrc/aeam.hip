@@ -1,10 +1,627 @@
-// aeam.hip -- placeholder until the AEAM kernels land (next milestone)
+// aeam.hip -- angular-EAM hot path for gfx950 (wave64), FP64 throughout.
+//
+// Replaces PairAEAM::compute (USER-AEAM/pair_aeam.cpp:110-479): pass 1 density (:164-253),
+// pass 2 embedding (:264-303), pass 3 pair + embedding + angular forces (:309-476).
+//
+// The reference scatters every (i,j) visit onto f[i] AND f[j] (ghosts included).  On the GPU that
+// would be ~260 FP64 atomics per atom, so the two-body part is regrouped as a gather: an owned atom
+// a collects, from its own full list, both visits that touch it,
+//     F_a -= d (fpair_{a->j} + fpair_{j->a}),   d = x_j - x_a
+//     fpair_{i->j} = -[i metal] q_i f'_{ti,tj}(r)/r - 1/2 phi'_{ti,tj}(r)/r      (pair_aeam.cpp:371-376)
+// where q_i = Fptmp_i * F'_i.  q_j of ghost neighbours is the one quantity that has to be
+// communicated -- exactly the style's own forward_comm of fp (pair_aeam.cpp:307).
+// Angular (covalent) centres are rare (0.75 % in sample.in): each gets a whole wave, stages its
+// in-range neighbours in LDS, loops over the (j<k) triplets and scatters fj / fk with FP64 atomics
+// (these are the only forces that land on ghost atoms).
+//
+// aeam_density_kernel<L>   L lanes per owned metal atom: rho_i = sum_j f(r)            (A1)
+// aeam_density_ang_kernel  one wave per owned angular atom: triplet density             (A1)
+// aeam_embed_kernel        F, F', q_i, energy                                           (A2)
+// aeam_force_kernel<L>     L lanes per owned atom, both visits of every pair            (A3)
+// aeam_force_ang_kernel    one wave per owned angular atom, triplet forces              (A4)
 #include "mdp_common.h"
-int mdp_aeam_prepare(mdp_ctx *c) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
-int mdp_aeam_run_density(mdp_ctx *c, int) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
-int mdp_aeam_run_force(mdp_ctx *c, int, int) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
-extern "C" {
-int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
-int mdp_aeam_density_host(mdp_ctx *c, int, double *, double *, double *, double *) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
-int mdp_aeam_force_host(mdp_ctx *c, int, int, const double *, double *, double *, double *, double *) { return mdp_fail(c, MDP_ENOTIMPL, "aeam: not built yet"); }
+
+namespace {
+
+constexpr int AE_L = 8;      // lanes per atom in the list-streaming kernels
+constexpr int ANG_CAP = 160; // LDS slots per angular centre
+constexpr double kCutDec = 1.5; // pair_aeam.cpp:188
+
+template <int W> __device__ __forceinline__ double lane_sum(double v)
+{
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
+
+// spline row + fractional coordinate (pair_aeam.cpp:195-201)
+__device__ __forceinline__ const double *spline_row(const double *__restrict__ tab, int table, int nmax1, double r,
+                                                    double rdr, int nr, double &p)
+{
+  p = r * rdr + 1.0;
+  int m = (int) p;
+  m = m < nr - 1 ? m : nr - 1;
+  p -= m;
+  p = p < 1.0 ? p : 1.0;
+  return tab + ((size_t) table * nmax1 + m) * 7;
+}
+
+__device__ __forceinline__ double sp_val(const double *c, double p) { return ((c[3] * p + c[4]) * p + c[5]) * p + c[6]; }
+__device__ __forceinline__ double sp_der(const double *c, double p) { return (c[0] * p + c[1]) * p + c[2]; }
+
+// ---- pass 1, metal centres (pair_aeam.cpp:174-205) ---------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, const int nlocal,
+                                                           const double4 *__restrict__ xq,
+                                                           const long long *__restrict__ nb_off,
+                                                           const int *__restrict__ nb, double *__restrict__ rho)
+{
+  const int s = threadIdx.x % L;
+  const long long i64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = i64 < nlocal;
+  const int i = have ? (int) i64 : 0;
+  const double4 xi = xq[i];
+  const int ti = (int) xi.w;
+  double acc = 0.0;
+  const bool metal = ti < A.nnonangular;
+  if (have && metal) {
+    const long long b = nb_off[i], e = nb_off[i + 1];
+    for (long long k = b + s; k < e; k += L) {
+      const int j = nb[k];
+      const double4 xj = xq[j];
+      const double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      const int pt = ti * A.ntypes + (int) xj.w;
+      if (r <= A.cut[pt]) { // CutDec applies only when BOTH are angular (pair_aeam.cpp:187-190)
+        double p;
+        const double *c = spline_row(A.rhor, A.t2rhor[pt], A.nrmax + 1, r, A.rdr[pt], A.nr[pt], p);
+        acc += sp_val(c, p);
+      }
+    }
+  }
+  acc = lane_sum<L>(acc);
+  if (have && metal && s == 0) rho[i] = acc;
+}
+
+// ---- angular centres: one wave per centre, in-range neighbours staged in LDS (list order kept) ------
+// slot record: dx dy dz r rsq f df flag   (d = x_j - x_i; flag bit0: inside cut - CutDec, the range of
+// pass 1 and of the k loop of pass 3)
+constexpr int AREC = 8;
+
+template <bool PASS3>
+__device__ __forceinline__ int ang_stage(const AeamDev &A, const double4 *__restrict__ xq, const double4 xi,
+                                         const int ti, const long long b, const long long e,
+                                         const int *__restrict__ nb, double *rec, int *jdx, int *flags)
+{
+  const int lane = threadIdx.x & 63;
+  int n = 0;
+  for (long long base = b; base < e; base += 64) { // wave-uniform trip count
+    const long long k = base + lane;
+    bool keep = false;
+    int j = 0, inj1 = 0;
+    double dx = 0, dy = 0, dz = 0, r = 0, rsq = 0, fv = 0, dfv = 0;
+    if (k < e) {
+      j = nb[k];
+      const double4 xj = xq[j];
+      dx = xj.x - xi.x;
+      dy = xj.y - xi.y;
+      dz = xj.z - xi.z;
+      rsq = dx * dx + dy * dy + dz * dz;
+      r = sqrt(rsq);
+      const int tj = (int) xj.w;
+      const int pt = ti * A.ntypes + tj;
+      const double cdec = (tj >= A.nnonangular) ? kCutDec : 0.0; // i is angular here
+      inj1 = r <= A.cut[pt] - cdec;
+      keep = PASS3 ? (r <= A.cut[pt]) : (inj1 != 0); // pass 3's j loop has no CutDec (pair_aeam.cpp:350)
+      if (keep) {
+        double p;
+        const double *c = spline_row(A.rhor, A.t2rhor[pt], A.nrmax + 1, r, A.rdr[pt], A.nr[pt], p);
+        fv = sp_val(c, p);
+        dfv = sp_der(c, p);
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep && pos < ANG_CAP) {
+      double *q = rec + pos * AREC;
+      q[0] = dx;
+      q[1] = dy;
+      q[2] = dz;
+      q[3] = r;
+      q[4] = rsq;
+      q[5] = fv;
+      q[6] = dfv;
+      jdx[pos] = j | (inj1 << 30);
+    }
+    n += __popcll(bal);
+  }
+  if (n > ANG_CAP) {
+    if (lane == 0) atomicOr(&flags[0], 2);
+    n = ANG_CAP;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return n;
+}
+
+// pass 1, angular centres (pair_aeam.cpp:207-250)
+__global__ __launch_bounds__(256) void aeam_density_ang_kernel(const AeamDev A, const int nang,
+                                                               const int *__restrict__ ang_list,
+                                                               const double4 *__restrict__ xq,
+                                                               const long long *__restrict__ nb_off,
+                                                               const int *__restrict__ nb, double *__restrict__ rho,
+                                                               int *__restrict__ flags)
+{
+  __shared__ double s_rec[4][ANG_CAP * AREC];
+  __shared__ int s_j[4][ANG_CAP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + w;
+  if (g >= nang) return; // whole wave
+  const int i = ang_list[g];
+  const double4 xi = xq[i];
+  const int ti = (int) xi.w;
+  double *rec = s_rec[w];
+  const int n = ang_stage<false>(A, xq, xi, ti, nb_off[i], nb_off[i + 1], nb, rec, s_j[w], flags);
+  double acc = 0.0;
+  const double third = 1.0 / 3.0;
+  // unordered pairs a<b, flattened over b: lane takes (a,b) with b = a+1+..  (n <= 160 -> <= 12720 pairs)
+  for (int a = 0; a < n; a++) {
+    const double *qa = rec + a * AREC;
+    for (int bq = a + 1 + lane; bq < n; bq += 64) {
+      const double *qb = rec + bq * AREC;
+      const double ex = qb[0] - qa[0], ey = qb[1] - qa[1], ez = qb[2] - qa[2];
+      const double rsq3 = ex * ex + ey * ey + ez * ez;
+      const double cs = (qa[4] + qb[4] - rsq3) / (2 * qa[3] * qb[3]);
+      const double delcs = cs + third;
+      acc += 2 * qa[5] * qb[5] * (delcs * delcs);
+    }
+  }
+  acc = lane_sum<64>(acc);
+  if (lane == 0) rho[i] = acc;
+}
+
+// ---- pass 2 (pair_aeam.cpp:264-303, 329-332) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void aeam_embed_kernel(const AeamDev A, const int nlocal,
+                                                         const double4 *__restrict__ xq,
+                                                         const double *__restrict__ rho, double *__restrict__ fp,
+                                                         double *__restrict__ eatom, double *__restrict__ acc,
+                                                         const int eflag, const int accumulate)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double e = 0.0;
+  if (i < nlocal) {
+    const int ti = (int) xq[i].w;
+    const bool metal = ti < A.nnonangular;
+    const double rh = rho[i];
+    const double u = metal ? rh : sqrt(rh); // pow(rho, ni), ni = 1 or 1/2
+    double p = u * A.rdrho[ti] + 1.0;
+    int m = (int) p;
+    m = m < A.nrho[ti] - 1 ? m : A.nrho[ti] - 1;
+    m = m > 1 ? m : 1;
+    p -= m;
+    p = p < 1.0 ? p : 1.0;
+    const double *c = A.frho + ((size_t) A.t2frho[ti] * (A.nrhomax + 1) + m) * 7;
+    const double fprime = sp_der(c, p);
+    // Fptmp = ni rho^(ni-1) if rho > minrho else 0 (pair_aeam.cpp:329-332); the product is all
+    // pass 3 ever uses (Feam :373, FFij/FFik/FFjk :450-452)
+    double fptmp = 0.0;
+    if (rh > 0.0000000000001) fptmp = metal ? 1.0 : 0.5 / sqrt(rh);
+    fp[i] = fptmp * fprime;
+    if (eflag) {
+      const double F = sp_val(c, p);
+      e = F;
+      if (eflag & MDP_EFLAG_ATOM) {
+        const double ea = metal ? F : F * (1.0 / 3.0); // pair_aeam.cpp:294-300 (quirk kept)
+        if (accumulate)
+          eatom[i] += ea;
+        else
+          eatom[i] = ea;
+      }
+    }
+  }
+  if (eflag & MDP_EFLAG_GLOBAL) {
+    e = lane_sum<64>(e);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc[MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)))], e);
+  }
+}
+
+// ---- pass 3, two-body part for every owned atom (pair_aeam.cpp:337-393) ----------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const int nlocal,
+                                                         const double4 *__restrict__ xq,
+                                                         const long long *__restrict__ nb_off,
+                                                         const int *__restrict__ nb, const double *__restrict__ fp,
+                                                         double *__restrict__ f, double *__restrict__ eatom,
+                                                         double *__restrict__ acc, const int eflag, const int vflag)
+{
+  const int lane = threadIdx.x & 63;
+  const int s = lane % L;
+  const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = a64 < nlocal;
+  const int a = have ? (int) a64 : 0;
+  const double4 xa = xq[a];
+  const int ta = (int) xa.w;
+  const bool a_metal = ta < A.nnonangular;
+  const double qa = a_metal ? fp[a] : 0.0; // (1 - deli) Fptmp fp
+  double fx = 0, fy = 0, fz = 0, e = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  if (have) {
+    const long long b = nb_off[a], en = nb_off[a + 1];
+    const int nm1 = A.nrmax + 1;
+    for (long long k = b + s; k < en; k += L) {
+      const int j = nb[k];
+      const double4 xj = xq[j];
+      const double dx = xj.x - xa.x, dy = xj.y - xa.y, dz = xj.z - xa.z;
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      const int tj = (int) xj.w;
+      const int pa = ta * A.ntypes + tj, pj = tj * A.ntypes + ta;
+      const bool in_a = r <= A.cut[pa], in_j = r <= A.cut[pj];
+      if (!(in_a || in_j)) continue;
+      const double recip = 1.0 / r;
+      double fpair_a = 0.0, fpair_j = 0.0;
+      if (in_a) { // the visit (i=a, j)
+        double p;
+        const double *c = spline_row(A.rhor, A.t2rhor[pa], nm1, r, A.rdr[pa], A.nr[pa], p);
+        const double dfij = sp_der(c, p);
+        const double *z = A.z2r + ((c - A.rhor) + (long long) (A.t2z2r[pa] - A.t2rhor[pa]) * nm1 * 7); // same row m1
+        const double phip = sp_der(z, p);
+        fpair_a = -qa * dfij * recip + 0.5 * (-phip * recip);
+        if (eflag) e += 0.5 * sp_val(z, p); // credited to i only (pair_aeam.cpp:386-390)
+      }
+      if (in_j) { // the visit (i=j, neighbour a): only its action on a
+        double p;
+        const double *c = spline_row(A.rhor, A.t2rhor[pj], nm1, r, A.rdr[pj], A.nr[pj], p);
+        const double dfja = sp_der(c, p);
+        const double *z = A.z2r + ((c - A.rhor) + (long long) (A.t2z2r[pj] - A.t2rhor[pj]) * nm1 * 7);
+        const double phip = sp_der(z, p);
+        const double qj = (tj < A.nnonangular) ? fp[j] : 0.0;
+        fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
+      }
+      const double ft = fpair_a + fpair_j;
+      fx -= dx * ft;
+      fy -= dy * ft;
+      fz -= dz * ft;
+      if (vflag) { // ev_tally(i=a, j, ..., fpair_a, d): this rank tallies its own visits
+        v0 += dx * dx * fpair_a;
+        v1 += dy * dy * fpair_a;
+        v2 += dz * dz * fpair_a;
+        v3 += dx * dy * fpair_a;
+        v4 += dx * dz * fpair_a;
+        v5 += dy * dz * fpair_a;
+      }
+    }
+  }
+  fx = lane_sum<L>(fx);
+  fy = lane_sum<L>(fy);
+  fz = lane_sum<L>(fz);
+  if (have && s == 0) {
+    // plain += : this kernel is the only writer of owned f at this point (stream order); the angular
+    // kernel that follows uses atomics
+    double *fo = f + 3 * (size_t) a;
+    fo[0] += fx;
+    fo[1] += fy;
+    fo[2] += fz;
+  }
+  if (eflag & MDP_EFLAG_ATOM) {
+    const double ea = lane_sum<L>(e);
+    if (have && s == 0) eatom[a] += ea;
+  }
+  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+  if (eflag & MDP_EFLAG_GLOBAL) {
+    const double et = lane_sum<64>(e);
+    if (lane == 0) atomicAdd(&slot[0], et);
+  }
+  if (vflag & MDP_VFLAG_GLOBAL) {
+    v0 = lane_sum<64>(v0);
+    v1 = lane_sum<64>(v1);
+    v2 = lane_sum<64>(v2);
+    v3 = lane_sum<64>(v3);
+    v4 = lane_sum<64>(v4);
+    v5 = lane_sum<64>(v5);
+    if (lane == 0) {
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
+    }
+  }
+}
+
+// ---- pass 3, angular three-body part (pair_aeam.cpp:395-474) ----------------------------------------------
+__global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, const int nang,
+                                                             const int *__restrict__ ang_list,
+                                                             const double4 *__restrict__ xq,
+                                                             const long long *__restrict__ nb_off,
+                                                             const int *__restrict__ nb, const double *__restrict__ fp,
+                                                             double *__restrict__ f, double *__restrict__ acc,
+                                                             int *__restrict__ flags, const int vflag)
+{
+  __shared__ double s_rec[4][ANG_CAP * AREC];
+  __shared__ int s_j[4][ANG_CAP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + w;
+  if (g >= nang) return;
+  const int i = ang_list[g];
+  const double4 xi = xq[i];
+  const int ti = (int) xi.w;
+  double *rec = s_rec[w];
+  int *jdx = s_j[w];
+  const int n = ang_stage<true>(A, xq, xi, ti, nb_off[i], nb_off[i + 1], nb, rec, jdx, flags);
+  const double K = -fp[i]; // -Fptmp fp
+  const double third = 1.0 / 3.0;
+  double fix = 0, fiy = 0, fiz = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  for (int a = 0; a < n; a++) { // j = slot a (any staged neighbour), k = later slots inside cut-CutDec
+    const double *qa = rec + a * AREC;
+    const double r1 = qa[3], fij = qa[5], dfij = qa[6];
+    double fjx = 0, fjy = 0, fjz = 0;
+    for (int bq = a + 1 + lane; bq < n; bq += 64) {
+      if (!((unsigned) jdx[bq] >> 30)) continue;
+      const double *qb = rec + bq * AREC;
+      const double r2 = qb[3], fik = qb[5], dfik = qb[6];
+      const double ex = qb[0] - qa[0], ey = qb[1] - qa[1], ez = qb[2] - qa[2]; // x_k - x_j
+      const double rsq3 = ex * ex + ey * ey + ez * ez;
+      const double r3 = sqrt(rsq3);
+      const double cs = (qa[4] + qb[4] - rsq3) / (2 * r1 * r2);
+      const double dcosij = 1 / r2 - cs / r1;
+      const double dcosik = 1 / r1 - cs / r2;
+      const double dcosjk = -r3 / (r1 * r2);
+      const double delcs = cs + third;
+      const double ftet = delcs * delcs;
+      const double delcs2 = 2 * delcs;
+      const double DFij = 2.0 * (fik * dfij * ftet + fij * fik * delcs2 * dcosij); // ci = 2
+      const double DFik = 2.0 * (fij * dfik * ftet + fij * fik * delcs2 * dcosik);
+      const double DFjk = 2.0 * fij * fik * delcs2 * dcosjk;
+      const double FFij = K * DFij / r1, FFik = K * DFik / r2, FFjk = K * DFjk / r3;
+      const double gjx = qa[0] * FFij - ex * FFjk, gjy = qa[1] * FFij - ey * FFjk, gjz = qa[2] * FFij - ez * FFjk;
+      const double gkx = qb[0] * FFik + ex * FFjk, gky = qb[1] * FFik + ey * FFjk, gkz = qb[2] * FFik + ez * FFjk;
+      fjx += gjx;
+      fjy += gjy;
+      fjz += gjz;
+      const int kk = jdx[bq] & MDP_NEIGHMASK;
+      atomicAdd(&f[3 * (size_t) kk], gkx);
+      atomicAdd(&f[3 * (size_t) kk + 1], gky);
+      atomicAdd(&f[3 * (size_t) kk + 2], gkz);
+      fix -= gjx + gkx;
+      fiy -= gjy + gky;
+      fiz -= gjz + gkz;
+      if (vflag) { // ev_tally3(i,j,k,0,0,fj,fk,drji,drki)
+        v0 += qa[0] * gjx + qb[0] * gkx;
+        v1 += qa[1] * gjy + qb[1] * gky;
+        v2 += qa[2] * gjz + qb[2] * gkz;
+        v3 += qa[0] * gjy + qb[0] * gky;
+        v4 += qa[0] * gjz + qb[0] * gkz;
+        v5 += qa[1] * gjz + qb[1] * gkz;
+      }
+    }
+    fjx = lane_sum<64>(fjx);
+    fjy = lane_sum<64>(fjy);
+    fjz = lane_sum<64>(fjz);
+    if (lane == 0 && (fjx != 0.0 || fjy != 0.0 || fjz != 0.0)) {
+      const int jj = jdx[a] & MDP_NEIGHMASK;
+      atomicAdd(&f[3 * (size_t) jj], fjx);
+      atomicAdd(&f[3 * (size_t) jj + 1], fjy);
+      atomicAdd(&f[3 * (size_t) jj + 2], fjz);
+    }
+  }
+  fix = lane_sum<64>(fix);
+  fiy = lane_sum<64>(fiy);
+  fiz = lane_sum<64>(fiz);
+  if (lane == 0) {
+    atomicAdd(&f[3 * (size_t) i], fix);
+    atomicAdd(&f[3 * (size_t) i + 1], fiy);
+    atomicAdd(&f[3 * (size_t) i + 2], fiz);
+  }
+  if (vflag & MDP_VFLAG_GLOBAL) {
+    v0 = lane_sum<64>(v0);
+    v1 = lane_sum<64>(v1);
+    v2 = lane_sum<64>(v2);
+    v3 = lane_sum<64>(v3);
+    v4 = lane_sum<64>(v4);
+    v5 = lane_sum<64>(v5);
+    if (lane == 0) {
+      double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
+    }
+  }
+}
+
+__global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
+                                int *__restrict__ count)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlocal) return;
+  if ((int) xq[i].w >= A.nnonangular) list[atomicAdd(count, 1)] = i;
+}
+
+inline int nblk(long long n, int per) { return (int) ((n + per - 1) / per); }
+
+} // namespace
+
+int mdp_aeam_prepare(mdp_ctx *c)
+{
+  if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
+  if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->rho.reserve(c->nall + 1));
+  MDP_HIP(c, c->fp.reserve(c->nall + 1));
+  MDP_HIP(c, c->ang_list.reserve(c->nlocal + 1));
+  MDP_HIP(c, c->ang_count.reserve(4));
+  MDP_HIP(c, hipMemsetAsync(c->ang_count.p, 0, sizeof(int), st));
+  if (c->nlocal)
+    ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p);
+  MDP_HIP(c, hipGetLastError());
+  MDP_HIP(c, hipMemcpyAsync(&c->h_ang_count, c->ang_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  return MDP_OK;
+}
+
+// passes 1 + 2.  Leaves rho[], fp[] (= Fptmp*F') for owned atoms; embedding energy in the accumulators.
+int mdp_aeam_run_density(mdp_ctx *c, int eflag)
+{
+  if (!c->have_aeam || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "aeam: tables / neighbor list not set");
+  hipStream_t st = c->stream;
+  const int nlocal = c->nlocal;
+  MDP_TRY(mdp_acc_begin(c, true));
+  mdp_time_mark(c, 0);
+  if (nlocal)
+    aeam_density_kernel<AE_L><<<nblk(nlocal, 256 / AE_L), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p,
+                                                                        c->rho.p);
+  if (c->h_ang_count)
+    aeam_density_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
+                                                                     c->nb_off.p, c->nb.p, c->rho.p, c->flags.p);
+  MDP_HIP(c, hipGetLastError());
+  mdp_time_mark(c, 1);
+  if (nlocal)
+    aeam_embed_kernel<<<nblk(nlocal, 256), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->rho.p, c->fp.p, c->eatom.p,
+                                                         c->acc.p, eflag, /*accumulate=*/0);
+  MDP_HIP(c, hipGetLastError());
+  mdp_time_mark(c, 2);
+  return MDP_OK;
+}
+
+// pass 3.  f[0..nall) is zeroed first; owned forces complete except for the angular terms other ranks'
+// centres put on our atoms; ghost forces hold our angular centres' contributions.
+int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
+{
+  if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "aeam: per-atom virial is not implemented on the device");
+  hipStream_t st = c->stream;
+  const int nlocal = c->nlocal;
+  MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, st));
+  if (nlocal)
+    aeam_force_kernel<AE_L><<<nblk(nlocal, 256 / AE_L), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p,
+                                                                      c->fp.p, c->f.p, c->eatom.p, c->acc.p, eflag,
+                                                                      vflag);
+  if (c->h_ang_count)
+    aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
+                                                                   c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->acc.p,
+                                                                   c->flags.p, vflag);
+  MDP_HIP(c, hipGetLastError());
+  mdp_time_mark(c, 3);
+  return mdp_acc_end(c, true);
+}
+
+extern "C" {
+
+int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
+{
+  if (!c || !t) return MDP_EINVAL;
+  if (t->ntypes < 1 || t->ntypes > 4 || t->nelements < 1 || t->nelements > 4 || t->ntypes > t->nelements)
+    return mdp_fail(c, MDP_EINVAL, "aeam: 1..4 atom types/elements supported, ntypes <= nelements");
+  MDP_HIP(c, hipSetDevice(c->device));
+  AeamDev &A = c->aeam;
+  memset(&A, 0, sizeof A);
+  A.ntypes = t->ntypes;
+  A.nelements = t->nelements;
+  A.nnonangular = t->nnonangular;
+  A.nrhomax = t->nrhomax;
+  A.nrmax = t->nrmax;
+  const int nt = t->ntypes, ne = t->nelements;
+  for (int a = 0; a < nt; a++) {
+    // element of type a+1 is a (coeff() insists on file order, pair_aeam.cpp:568-572)
+    A.rdrho[a] = 1 / t->drho[a];
+    A.nrho[a] = t->nrho[a];
+    A.t2frho[a] = t->type2frho[a + 1];
+    for (int b = 0; b < nt; b++) {
+      const int k = a * nt + b;
+      A.cut[k] = t->cut[a * ne + b];
+      A.rdr[k] = 1 / t->dr[a * ne + b];
+      A.nr[k] = t->nr[a * ne + b];
+      A.t2rhor[k] = t->type2rhor[(size_t) (a + 1) * (nt + 1) + (b + 1)];
+      A.t2z2r[k] = t->type2z2r[(size_t) (a + 1) * (nt + 1) + (b + 1)];
+    }
+  }
+  const size_t nf = (size_t) t->nfrho * (t->nrhomax + 1) * 7, nr = (size_t) t->nrhor * (t->nrmax + 1) * 7,
+               nz = (size_t) t->nz2r * (t->nrmax + 1) * 7;
+  MDP_HIP(c, c->aeam_frho.reserve(nf));
+  MDP_HIP(c, c->aeam_rhor.reserve(nr));
+  MDP_HIP(c, c->aeam_z2r.reserve(nz));
+  MDP_HIP(c, hipMemcpyAsync(c->aeam_frho.p, t->frho_spline, nf * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipMemcpyAsync(c->aeam_rhor.p, t->rhor_spline, nr * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipMemcpyAsync(c->aeam_z2r.p, t->z2r_spline, nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipStreamSynchronize(c->stream));
+  A.frho = c->aeam_frho.p;
+  A.rhor = c->aeam_rhor.p;
+  A.z2r = c->aeam_z2r.p;
+  c->have_aeam = true;
+  return MDP_OK;
+}
+
+static int aeam_fetch(mdp_ctx *c, double *eng, double *virial)
+{
+  hipStream_t st = c->stream;
+  MDP_HIP(c, hipMemcpyAsync(c->h_pinned, c->acc.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+  int *hflags = (int *) (c->h_pinned + 16);
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  if (hflags[0] & 2) return mdp_fail(c, MDP_EOVERFLOW, "aeam: an angular atom has more in-range neighbours than the LDS tile holds");
+  if (eng) *eng += c->h_pinned[0];
+  if (virial)
+    for (int k = 0; k < 6; k++) virial[k] += c->h_pinned[1 + k];
+  return MDP_OK;
+}
+
+int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double *eng_vdwl, double *eatom)
+{
+  if (!c || !fp) return MDP_EINVAL;
+  if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
+  if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
+  MDP_HIP(c, hipSetDevice(c->device));
+  if (!c->rebo_packed) { // reuse the flag: "style structures follow the current list"
+    MDP_TRY(mdp_aeam_prepare(c));
+    c->rebo_packed = true;
+  }
+  if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
+  MDP_TRY(mdp_aeam_run_density(c, eflag));
+  MDP_TRY(mdp_acc_end(c, true));
+  hipStream_t st = c->stream;
+  const int n = c->nlocal;
+  std::vector<double> he;
+  MDP_HIP(c, hipMemcpyAsync(fp, c->fp.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (rho) MDP_HIP(c, hipMemcpyAsync(rho, c->rho.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) {
+    he.resize(n);
+    MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  }
+  MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, nullptr));
+  if (eflag & MDP_EFLAG_ATOM)
+    for (int i = 0; i < n; i++) eatom[i] += he[i];
+  return MDP_OK;
+}
+
+int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
+                        double *virial, double *eatom)
+{
+  if (!c || !fp_all || !f) return MDP_EINVAL;
+  if (!c->have_aeam || !c->atoms_set || !c->neigh_set || !c->rebo_packed)
+    return mdp_fail(c, MDP_ESTATE, "aeam: call mdp_aeam_density_host first");
+  MDP_HIP(c, hipSetDevice(c->device));
+  if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
+  hipStream_t st = c->stream;
+  const int n = c->nlocal, nall = c->nall;
+  // ghosts' fp come from the host's forward comm; owned values are already on the device
+  if (nall > n)
+    MDP_HIP(c, hipMemcpyAsync(c->fp.p + n, fp_all + n, sizeof(double) * (nall - n), hipMemcpyHostToDevice, st));
+  MDP_TRY(mdp_acc_begin(c, true));
+  MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * n, st));
+  MDP_TRY(mdp_aeam_run_force(c, eflag, vflag));
+  std::vector<double> hf((size_t) 3 * nall), he;
+  MDP_HIP(c, hipMemcpyAsync(hf.data(), c->f.p, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) {
+    he.resize(n);
+    MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  }
+  MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  for (size_t k = 0; k < (size_t) 3 * nall; k++) f[k] += hf[k];
+  if (eflag & MDP_EFLAG_ATOM)
+    for (int i = 0; i < n; i++) eatom[i] += he[i];
+  return MDP_OK;
+}
+
+} // extern "C"

@@ -54,7 +54,35 @@ __global__ void add_f_kernel(int n3, const double *__restrict__ src, double *__r
   if (i < n3) dst[i] += src[i];
 }
 
+__global__ void acc_reduce_kernel(double *__restrict__ acc)
+{
+  // one wave per quantity k = 0..6: sum the slots
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (k >= 7) return;
+  double s = 0.0;
+  for (int i = lane; i < MDP_ACC_SLOTS; i += 64) s += acc[MDP_ACC_STRIDE * (1 + i) + k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) acc[k] += s;
+}
+
 } // namespace
+
+int mdp_acc_begin(mdp_ctx *c, bool any)
+{
+  const size_t n = any ? (size_t) MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS) : (size_t) MDP_ACC_STRIDE;
+  MDP_HIP(c, hipMemsetAsync(c->acc.p, 0, sizeof(double) * n, c->stream));
+  MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, c->stream));
+  return MDP_OK;
+}
+
+int mdp_acc_end(mdp_ctx *c, bool any)
+{
+  if (any) {
+    acc_reduce_kernel<<<1, 512, 0, c->stream>>>(c->acc.p);
+    MDP_HIP(c, hipGetLastError());
+  }
+  return MDP_OK;
+}
 
 // xraw (device [n][3]) (+ device type[]) -> xq.  d_type null: keep the element already in xq.w
 int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type)
@@ -122,7 +150,7 @@ int mdp_create(mdp_ctx **out, int device)
     return MDP_EHIP;
   }
   c->own_stream = true;
-  if (c->acc.reserve(32) != hipSuccess || c->flags.reserve(8) != hipSuccess ||
+  if (c->acc.reserve((size_t) MDP_ACC_STRIDE * (2 + MDP_ACC_SLOTS)) != hipSuccess || c->flags.reserve(8) != hipSuccess ||
       hipHostMalloc((void **) &c->h_pinned, 64 * sizeof(double)) != hipSuccess) {
     mdp_destroy(c);
     return MDP_ENOMEM;

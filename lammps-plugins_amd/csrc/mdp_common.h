@@ -13,6 +13,10 @@
 #include "mdpair_hip.h"
 
 #define MDP_NEIGHMASK 0x1FFFFFFF
+// global energy/virial accumulators: acc[0..15] final values (0 eng, 1..6 virial, 7 KE, 8 maxdisp2),
+// followed by MDP_ACC_SLOTS partial slots of MDP_ACC_STRIDE doubles each
+#define MDP_ACC_SLOTS 512
+#define MDP_ACC_STRIDE 16
 
 // device buffer that only grows
 template <typename T> struct DevBuf {
@@ -181,3 +185,5 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag);
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
 void mdp_time_mark(mdp_ctx *c, int k);
+int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
+int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]

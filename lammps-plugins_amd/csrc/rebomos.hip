@@ -344,9 +344,12 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     }
   }
 
+  // partial sums go to one of MDP_ACC_SLOTS slots (by block) so that a million waves do not queue
+  // on seven addresses; acc_reduce_kernel folds the slots afterwards
+  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
   if (eflag & MDP_EFLAG_GLOBAL) {
     const double e = group_sum<64>(e_acc);
-    if (lane == 0) atomicAdd(&acc[0], e);
+    if (lane == 0) atomicAdd(&slot[0], e);
   }
   if (vflag & MDP_VFLAG_GLOBAL) {
     v0 = group_sum<64>(v0);
@@ -356,12 +359,12 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     v4 = group_sum<64>(v4);
     v5 = group_sum<64>(v5);
     if (lane == 0) {
-      atomicAdd(&acc[1], v0);
-      atomicAdd(&acc[2], v1);
-      atomicAdd(&acc[3], v2);
-      atomicAdd(&acc[4], v3);
-      atomicAdd(&acc[5], v4);
-      atomicAdd(&acc[6], v5);
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
     }
   }
 }
@@ -479,9 +482,10 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
         eatom[a] = ea;
     }
   }
+  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
   if (eflag & MDP_EFLAG_GLOBAL) {
     const double et = group_sum<64>(e_lj);
-    if (lane == 0) atomicAdd(&acc[0], et);
+    if (lane == 0) atomicAdd(&slot[0], et);
   }
   if (vflag & MDP_VFLAG_GLOBAL) {
     v0 = group_sum<64>(v0);
@@ -491,12 +495,12 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
     v4 = group_sum<64>(v4);
     v5 = group_sum<64>(v5);
     if (lane == 0) {
-      atomicAdd(&acc[1], v0);
-      atomicAdd(&acc[2], v1);
-      atomicAdd(&acc[3], v2);
-      atomicAdd(&acc[4], v3);
-      atomicAdd(&acc[5], v4);
-      atomicAdd(&acc[6], v5);
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
     }
   }
 }
@@ -765,8 +769,7 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
   if (!c->rebo_packed) return mdp_fail(c, MDP_ESTATE, "rebomos: neighbor list not repacked");
   if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "rebomos: per-atom virial is not implemented on the device");
   hipStream_t st = c->stream;
-  zero_small_kernel<<<1, 64, 0, st>>>(c->acc.p, 16);
-  MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, st));
+  MDP_TRY(mdp_acc_begin(c, eflag || vflag));
   mdp_time_mark(c, 0);
   launch_centre<4>(c, 0, eflag, vflag);
   launch_centre<8>(c, 1, eflag, vflag);
@@ -783,5 +786,5 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
                                                    c->f.p, c->eatom.p, c->acc.p, eflag, vflag, zero_f ? 0 : 1);
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 2);
-  return MDP_OK;
+  return mdp_acc_end(c, eflag || vflag);
 }
