@@ -1,0 +1,206 @@
+/* ------------------------------------------------------------------------------------------------
+   MI355X-native REBO Mo-S pair style: LAMMPS-facing adapter (host C++).
+
+   Mirrors the host-visible behaviour of lammps/lammps-plugins USER-REBOMOS/pair_rebomos.cpp:
+   constructor flags (:57-72), settings (:144-147), coeff (:153-203), init_style (:209-238),
+   init_one (:244-274), compute (:102-111) and the error messages of each.  The force/energy
+   arithmetic itself (REBO_neigh, FREBO, bondorder, FLJ) runs in hand-written HIP kernels behind the
+   C-ABI of include/mdpair_hip.h.
+
+   Differences a host can observe, by design:
+     * owner-computes: compute() adds complete forces to OWNED atoms and nothing to ghosts, so the
+       host's reverse_comm of f carries zeros for this style;
+     * the global virial is tallied explicitly on the device (no_virial_fdotr = 1), because
+       x.f over ghosts is only valid for the scatter formulation;
+     * per-atom virial (compute stress/atom) is not available yet: error->all.
+-------------------------------------------------------------------------------------------------- */
+#include "pair_rebomos.h"
+
+#include "atom.h"
+#include "comm.h"
+#include "error.h"
+#include "force.h"
+#include "memory.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "utils.h"
+
+#include <cstring>
+#include <string>
+
+using namespace LAMMPS_NS;
+
+PairREBOMoS::PairREBOMoS(LAMMPS *lmp) : Pair(lmp)
+{
+  // pair_rebomos.cpp:59-64
+  single_enable = 0;
+  restartinfo = 0;
+  one_coeff = 1;
+  ghostneigh = 1;
+  manybody_flag = 1;
+  centroidstressflag = CENTROID_NOTAVAIL;
+  // the device tallies the pair virial itself (see header comment)
+  no_virial_fdotr = 1;
+
+  dev = nullptr;
+  params_read = false;
+  cut3rebo = 0.0;
+  nall_uploaded = -1;
+  device_bytes = 0.0;
+  memset(&params, 0, sizeof params);
+}
+
+PairREBOMoS::~PairREBOMoS()
+{
+  if (dev) mdp_destroy(dev);
+  if (allocated) {
+    memory->destroy(setflag);
+    memory->destroy(cutsq);
+    memory->destroy(cutghost);
+    delete[] map;
+    map = nullptr;
+  }
+}
+
+void PairREBOMoS::fail_one(int code, const char *what)
+{
+  std::string msg = std::string("Pair style rebomos (MI355X): ") + what + " failed";
+  if (code == MDP_EOVERFLOW) msg = "Neighbor list overflow, boost neigh_modify one";    // pair_rebomos.cpp:350
+  if (dev) msg += std::string(": ") + mdp_last_error(dev);
+  error->one(FLERR, msg);
+}
+
+void PairREBOMoS::open_device()
+{
+  if (dev) return;
+  const int ndev = mdp_device_count();
+  if (ndev <= 0) error->all(FLERR, "Pair style rebomos (MI355X) needs a HIP device; there is no CPU fallback");
+  int id = comm->me % ndev;
+  if (const char *env = getenv("MDP_DEVICE")) id = atoi(env);
+  const int rc = mdp_create(&dev, id);
+  if (rc != MDP_OK) error->one(FLERR, "Pair style rebomos (MI355X): cannot create a device context");
+  if (params_read && mdp_rebomos_set_params(dev, &params) != MDP_OK) fail_one(MDP_EINVAL, "parameter upload");
+}
+
+void PairREBOMoS::allocate()
+{
+  allocated = 1;
+  const int n = atom->ntypes;
+  memory->create(setflag, n + 1, n + 1, "pair:setflag");
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++) setflag[i][j] = 0;
+  memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+  memory->create(cutghost, n + 1, n + 1, "pair:cutghost");
+  delete[] map;
+  map = new int[n + 1];
+}
+
+void PairREBOMoS::settings(int narg, char ** /*arg*/)
+{
+  if (narg != 0) error->all(FLERR, "Illegal pair_style command");
+}
+
+void PairREBOMoS::coeff(int narg, char **arg)
+{
+  if (!allocated) allocate();
+  const int n = atom->ntypes;
+
+  if (narg != 3 + n) error->all(FLERR, "Incorrect args for pair coefficients");
+  if (strcmp(arg[0], "*") != 0 || strcmp(arg[1], "*") != 0)
+    error->all(FLERR, "Incorrect args for pair coefficients");
+
+  // atom type -> element: Mo (or legacy M) = 0, S = 1, NULL = -1   (pair_rebomos.cpp:168-179)
+  map[0] = -1;
+  for (int i = 3; i < narg; i++) {
+    int el;
+    if (strcmp(arg[i], "NULL") == 0)
+      el = -1;
+    else if (strcmp(arg[i], "Mo") == 0 || strcmp(arg[i], "M") == 0)
+      el = 0;
+    else if (strcmp(arg[i], "S") == 0)
+      el = 1;
+    else
+      error->all(FLERR, "Incorrect args for pair coefficients");
+    map[i - 2] = el;
+  }
+
+  // potential file: 61 scalars + mixing rules, shared front end in libmdpair_hip.so
+  char why[512] = "";
+  const std::string path = utils::get_potential_file_path(arg[2]);
+  if (mdp_rebomos_read_file(path.empty() ? arg[2] : path.c_str(), &params, why, (int) sizeof why) != MDP_OK)
+    error->one(FLERR, why[0] ? why : "reading rebomos potential file failed");
+  params_read = true;
+  if (dev && mdp_rebomos_set_params(dev, &params) != MDP_OK) fail_one(MDP_EINVAL, "parameter upload");
+
+  int count = 0;
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++) {
+      setflag[i][j] = 0;
+      if (map[i] >= 0 && map[j] >= 0) {
+        setflag[i][j] = 1;
+        count++;
+      }
+    }
+  if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
+void PairREBOMoS::init_style()
+{
+  if (atom->tag_enable == 0) error->all(FLERR, "Pair style REBOMoS requires atom IDs");
+  if (force->newton_pair == 0) error->all(FLERR, "Pair style REBOMoS requires newton pair on");
+  for (int i = 1; i <= atom->ntypes; i++)
+    if (map[i] < 0) error->all(FLERR, "Pair style rebomos (MI355X) does not support NULL-mapped atom types yet");
+
+  // full neighbor list including neighbors of ghosts (pair_rebomos.cpp:218)
+  neighbor->add_request(this, NeighConst::REQ_FULL | NeighConst::REQ_GHOST);
+
+  open_device();
+  nall_uploaded = -1;
+}
+
+double PairREBOMoS::init_one(int i, int j)
+{
+  if (setflag[i][j] == 0) error->all(FLERR, "All pair coeffs are not set");
+  const int ii = map[i], jj = map[j];
+  // list cutoff = 3 REBO distances of the largest element; ghost-list cutoff = REBO cutoff
+  // (pair_rebomos.cpp:257-261)
+  cut3rebo = 3.0 * params.rcmax[0][0];
+  cutghost[i][j] = cutghost[j][i] = params.rcmax[ii][jj];
+  return cut3rebo;
+}
+
+void PairREBOMoS::compute(int eflag, int vflag)
+{
+  ev_init(eflag, vflag);
+  if (vflag_atom)
+    error->all(FLERR, "Pair style rebomos (MI355X) does not provide per-atom virial yet");
+
+  const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  int rc;
+  if (neighbor->ago == 0 || nall != nall_uploaded) {
+    // the host rebuilt its list this step: atoms may have migrated / been re-sorted
+    rc = mdp_set_atoms_host(dev, nlocal, atom->nghost, nall ? atom->x[0] : nullptr, atom->type, atom->tag,
+                            atom->ntypes, map);
+    if (rc != MDP_OK) fail_one(rc, "atom upload");
+    rc = mdp_set_neighbors_host(dev, list->inum, list->gnum, list->ilist, list->numneigh, list->firstneigh,
+                                neighbor->skin);
+    if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
+    nall_uploaded = nall;
+  } else {
+    rc = mdp_set_positions_host(dev, atom->x[0]);
+    if (rc != MDP_OK) fail_one(rc, "position upload");
+  }
+
+  const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
+  const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0);
+  rc = mdp_rebomos_compute_host(dev, ef, vf, nlocal ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom);
+  if (rc != MDP_OK) fail_one(rc, "compute");
+}
+
+double PairREBOMoS::memory_usage()
+{
+  // host side holds nothing per atom; report the staging copies the C-ABI layer keeps on the host
+  double bytes = 0.0;
+  bytes += (double) (atom->nlocal + atom->nghost) * (3 * sizeof(double) + sizeof(int));
+  return bytes;
+}
