@@ -21,11 +21,7 @@ struct CutTables {
   int ne;           // table stride
 };
 
-struct Grid {
-  double lo[3], inv[3];
-  int n[3];
-  int range; // stencil half width in cells
-};
+using Grid = MdpGrid;
 
 __device__ __forceinline__ int cell_index(const Grid &g, const double4 &x, int &cx, int &cy, int &cz)
 {
@@ -318,35 +314,31 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
   return MDP_OK;
 }
 
-int mdp_md_build_master_list(mdp_ctx *c)
+// bins of width >= cutoff/2 over [lo,hi], atoms sorted by bin (cell_perm), bin boundaries (cell_start)
+int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3])
 {
-  const int nall = c->nall, nlocal = c->nlocal;
+  const int nall = c->nall;
   hipStream_t st = c->stream;
-  CutTables ct;
-  double maxcut;
-  MDP_TRY(md_cut_tables(c, ct, maxcut));
-  Grid g;
-  const double binsize = 0.5 * maxcut; // LAMMPS default: half the master cutoff (log.rebomos-bulk.1:45)
+  Grid &g = c->grid;
+  const double binsize = 0.5 * cutoff; // LAMMPS default: half the cutoff (log.rebomos-bulk.1:45)
   g.range = 2;
   long long ncell = 1;
   for (int d = 0; d < 3; d++) {
-    const double len = c->cfg.bbox_hi[d] - c->cfg.bbox_lo[d];
+    const double len = hi[d] - lo[d];
     if (!(len > 0.0)) return mdp_fail(c, MDP_EINVAL, "empty bounding box");
     int n = (int) floor(len / binsize);
     if (n < 1) n = 1;
+    if (n > 1024) n = 1024; // wider cells are still correct
     g.n[d] = n;
-    g.lo[d] = c->cfg.bbox_lo[d];
+    g.lo[d] = lo[d];
     g.inv[d] = n / len; // cells are >= binsize wide
     ncell *= n;
   }
-  if (ncell > (1ll << 30)) return mdp_fail(c, MDP_EINVAL, "too many bins");
   MDP_HIP(c, c->sort_keys_a.reserve(nall + 1));
   MDP_HIP(c, c->sort_keys_b.reserve(nall + 1));
   MDP_HIP(c, c->cell_of.reserve(nall + 1));   // values in
   MDP_HIP(c, c->cell_perm.reserve(nall + 1)); // values out
   MDP_HIP(c, c->cell_start.reserve((size_t) ncell + 2));
-  MDP_HIP(c, c->nb_cnt.reserve(nall + 2));
-  MDP_HIP(c, c->nb_off.reserve(nall + 2));
   cell_assign_kernel<<<nblk(nall), 256, 0, st>>>(g, nall, c->xq.p, c->sort_keys_a.p, c->cell_of.p);
   MDP_HIP(c, hipGetLastError());
   int bits = 1;
@@ -360,6 +352,20 @@ int mdp_md_build_master_list(mdp_ctx *c)
   cell_bounds_kernel<<<nblk(nall), 256, 0, st>>>(nall, c->sort_keys_b.p, c->cell_start.p);
   cell_tail_kernel<<<1, 256, 0, st>>>(nall, (int) ncell, c->sort_keys_b.p, c->cell_start.p);
   MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_md_build_master_list(mdp_ctx *c)
+{
+  const int nall = c->nall, nlocal = c->nlocal;
+  hipStream_t st = c->stream;
+  CutTables ct;
+  double maxcut;
+  MDP_TRY(md_cut_tables(c, ct, maxcut));
+  MDP_TRY(mdp_bin_atoms(c, maxcut, c->cfg.bbox_lo, c->cfg.bbox_hi));
+  const Grid g = c->grid;
+  MDP_HIP(c, c->nb_cnt.reserve(nall + 2));
+  MDP_HIP(c, c->nb_off.reserve(nall + 2));
   nbuild_kernel<false><<<nblk(nall), 256, 0, st>>>(g, ct, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
                                                     c->nb_cnt.p, nullptr, nullptr);
   MDP_HIP(c, hipGetLastError());
@@ -410,6 +416,10 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
     if (ghost_tag) ga[nlocal + g] = ghost_tag[g];
   }
   MDP_TRY(mdp_set_atoms_host(c, nlocal, nghost, xa.data(), ta.data(), ga.data(), cfg->ntypes, map));
+  for (int d = 0; d < 3; d++) { // resident mode bins over the caller's box
+    c->bbox_lo[d] = cfg->bbox_lo[d];
+    c->bbox_hi[d] = cfg->bbox_hi[d];
+  }
   hipStream_t st = c->stream;
   MDP_HIP(c, c->v.reserve((size_t) 3 * nlocal + 3));
   MDP_HIP(c, c->xhold.reserve((size_t) 3 * nlocal + 3));

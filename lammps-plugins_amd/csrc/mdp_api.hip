@@ -183,12 +183,13 @@ int mdp_destroy(mdp_ctx *c)
   c->cand.release();
   c->lj_off.release();
   c->lj_cnt.release();
+  c->lj_split.release();
   c->lj.release();
   c->is_center.release();
   c->class_list.release();
   c->class_count.release();
-  c->rn_num.release();
-  c->rn_idx.release();
+  c->amask.release();
+  c->rev.release();
   c->fnbr.release();
   c->eslot.release();
   c->scan_tmp.release();
@@ -301,6 +302,19 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
   MDP_HIP(c, hipMemcpyAsync(c->type.p + nall, c->map, sizeof(int) * 16, hipMemcpyHostToDevice, st));
   if (tag) MDP_HIP(c, hipMemcpyAsync(c->tag.p, tag, sizeof(int) * nall, hipMemcpyHostToDevice, st));
   c->atoms_set = true;
+  if (!c->md) { // host mode: bounding box for the device binning, padded so that motion inside the skin stays inside
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < nall; i++)
+      for (int d = 0; d < 3; d++) {
+        const double v = x[3 * (size_t) i + d];
+        lo[d] = v < lo[d] ? v : lo[d];
+        hi[d] = v > hi[d] ? v : hi[d];
+      }
+    for (int d = 0; d < 3; d++) {
+      c->bbox_lo[d] = (nall ? lo[d] : 0.0) - 4.0;
+      c->bbox_hi[d] = (nall ? hi[d] : 1.0) + 4.0;
+    }
+  }
   MDP_TRY(mdp_pack_xq(c, c->xraw.p, c->type.p));
   MDP_HIP(c, hipStreamSynchronize(st)); // host buffers may change after return
   c->neigh_set = false;

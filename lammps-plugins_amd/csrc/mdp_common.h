@@ -15,6 +15,7 @@
 #define MDP_NEIGHMASK 0x1FFFFFFF
 // global energy/virial accumulators: acc[0..15] final values (0 eng, 1..6 virial, 7 KE, 8 maxdisp2),
 // followed by MDP_ACC_SLOTS partial slots of MDP_ACC_STRIDE doubles each
+#define MDP_CLUSTER 2
 #define MDP_ACC_SLOTS 512
 #define MDP_ACC_STRIDE 16
 
@@ -63,6 +64,13 @@ struct RebomosDev {
   double ljc2[4], ljc3[4], rcLJmin[4]; // cubic inner spline (pair_rebomos.cpp:533-543)
   double cand_cutsq[4];                // (rcmax+skin)^2 : REBO candidate list
   double ljlist_cutsq[4];              // (rcLJmax+skin)^2 : trimmed LJ list
+};
+
+// uniform Cartesian bin grid over the bounding box of owned+ghost atoms
+struct MdpGrid {
+  double lo[3], inv[3];
+  int n[3];
+  int range; // stencil half width in cells: range * cell width >= the cutoff the grid was made for
 };
 
 struct AeamDev {
@@ -115,16 +123,19 @@ struct mdp_ctx {
   DevBuf<int> cand_cnt, cand_off; // [nall+1]
   DevBuf<int> cand;               // REBO candidates (r <= rcmax+skin)
   int cand_total = 0;
-  DevBuf<long long> lj_off;       // [nlocal+1]
-  DevBuf<int> lj_cnt;             // [nlocal]
-  DevBuf<int> lj;                 // trimmed LJ list
+  // Lennard-Jones cluster pair list: MDP_CLUSTER consecutive owned atoms share one union list
+  DevBuf<long long> lj_off;       // [nclus+1]
+  DevBuf<int> lj_cnt;             // [nclus]
+  DevBuf<int> lj;                 // union neighbours (r <= rcLJmax+skin of ANY atom of the cluster)
   long long lj_total = 0;
+  int nclus = 0, cluster = MDP_CLUSTER;
+  DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
   DevBuf<int> is_center;          // [nall]
   DevBuf<int> class_list;         // [4][nall]
   DevBuf<int> class_count;        // [4]
   int h_class_count[4] = {0, 0, 0, 0};
-  DevBuf<int> rn_num;             // [nall]
-  DevBuf<int> rn_idx;             // [cand_total]
+  DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
+  DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<double> fnbr;            // [cand_total][3]
   DevBuf<double> eslot;           // [cand_total]
   DevBuf<char> scan_tmp;
@@ -134,6 +145,10 @@ struct mdp_ctx {
   DevBuf<int> ang_list;           // owned angular atoms
   DevBuf<int> ang_count;
   int h_ang_count = 0;
+
+  // ---- binning (shared by the master-list builder and the cluster-list builder)
+  MdpGrid grid;
+  double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0}; // of the atoms last uploaded (host mode)
 
   // ---- resident MD
   bool md = false;
@@ -184,6 +199,7 @@ int mdp_aeam_prepare(mdp_ctx *c);
 int mdp_aeam_run_density(mdp_ctx *c, int eflag);
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
+int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]

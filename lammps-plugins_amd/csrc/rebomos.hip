@@ -130,12 +130,12 @@ template <int G>
 __global__ __launch_bounds__(256) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
-    int *__restrict__ rn_num, int *__restrict__ rn_idx, double *__restrict__ fnbr, double *__restrict__ eslot,
+    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ eslot,
     double *__restrict__ acc, int *__restrict__ flags, const int eflag, const int vflag)
 {
   using C = CentreCfg<G>;
   __shared__ double s_rec[C::WPB * C::GPW * C::STRIDE];
-  __shared__ int s_je[C::WPB * C::GPW * C::CAP];
+  __shared__ int s_je[C::WPB * C::GPW * C::CAP]; // element (bit 30) | candidate slot of the neighbour
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   // ---- phase A: filter the candidates to the current REBO set (pair_rebomos.cpp:328-344) --------
   int n = 0;
   double nsum = 0.0;
+  unsigned long long active = 0ull; // bit t: candidate t is inside rcmax right now (group-uniform)
   const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
   const int ncw = wave_max_int(nc);
   for (int base = 0; base < ncw; base += G) {
@@ -195,17 +196,17 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
       q[3] = r;
       q[4] = w;
       q[5] = dw;
-      je[pos] = j | (tj << 30);
-      rn_idx[off + pos] = j;
+      je[pos] = t | (tj << 30);
       nsum += w; // nM + nS (pair_rebomos.cpp:339-342); only their sum is ever used (:628, h:175)
     }
     n += __popcll(gb);
+    if (base < 64) active |= gb << base;
   }
   if (n > C::CAP) {
     if (s == 0) atomicOr(&flags[0], 1);
     n = C::CAP;
   }
-  if (have && s == 0) rn_num[c] = n;
+  if (have && s == 0) amask[c] = active;
   const double Ntot = group_sum<G>(nsum);
   wave_lds_fence();
 
@@ -326,11 +327,14 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
       fx += radial * ux;
       fy += radial * uy;
       fz += radial * uz;
-      double *o = fnbr + 3 * (size_t) (off + m);
+      // slot forces are filed under the neighbour's (static) candidate slot: the gather finds the
+      // reverse slot through a table built once per list build
+      const int tslot = je[m] & 0x3FFFFFFF;
+      double *o = fnbr + 3 * (size_t) (off + tslot);
       o[0] = fx;
       o[1] = fy;
       o[2] = fz;
-      if (eflag & MDP_EFLAG_ATOM) eslot[off + m] = 0.5 * ehalf;
+      if (eflag & MDP_EFLAG_ATOM) eslot[off + tslot] = 0.5 * ehalf;
       if (owned) {
         e_acc += ehalf;
         // virial of the cluster: sum_m (x_m - x_c) (x) F_m = -sum_m d_m (x) F_m
@@ -370,117 +374,238 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lennard-Jones over the trimmed full list + gather of the REBO slot forces
+// Lennard-Jones over the cluster pair list + gather of the REBO slot forces
 // ------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
-    const RebomosDev P, const int nlocal, const double4 *__restrict__ xq, const long long *__restrict__ lj_off,
-    const int *__restrict__ lj_cnt, const int *__restrict__ lj, const int *__restrict__ cand_off,
-    const int *__restrict__ rn_num, const int *__restrict__ rn_idx, const double *__restrict__ fnbr,
-    const double *__restrict__ eslot, double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc,
-    const int eflag, const int vflag, const int accumulate)
+// The per-atom gather x[j] is what bounds this loop (one 32-byte gather feeds ~25 flops and the L1
+// tag rate saturates), so MDP_CLUSTER consecutive (Morton-ordered, hence adjacent) atoms share ONE
+// union neighbour list: every gathered x[j] is tested against all four cluster atoms from registers.
+// 1/x to ~1 ulp: hardware seed + two Newton steps (5 instructions instead of the ~12 of an IEEE divide;
+// the result feeds products whose tolerance is 1e-9 relative)
+__device__ __forceinline__ double fast_rcp(double x)
 {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// loop-invariant Lennard-Jones parameters of one (cluster atom, neighbour element) pair type
+struct LJPar {
+  double lo, hi, sw; // rsq windows (pair_rebomos.cpp:518-532 decided on rij, reproduced in rsq space)
+  double c1, c2, c3, c4; // lj1..lj4
+};
+
+__device__ __forceinline__ LJPar lj_load(const RebomosDev &P, const int pt)
+{
+  LJPar q;
+  q.lo = P.lj_rsq_lo[pt];
+  q.hi = P.lj_rsq_hi[pt];
+  q.sw = P.lj_rsq_sw[pt];
+  q.c1 = P.lj1[pt];
+  q.c2 = P.lj2[pt];
+  q.c3 = P.lj3[pt];
+  q.c4 = P.lj4[pt];
+  return q;
+}
+
+template <bool EV>
+__device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, const int pt, const double4 &xa,
+                                        const double4 &xj, double &fx, double &fy, double &fz, double &e,
+                                        const int vflag, double &v0, double &v1, double &v2, double &v3, double &v4,
+                                        double &v5)
+{
+  const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
+  const double rsq = dx * dx + dy * dy + dz * dz;
+  if (rsq >= q.lo && rsq <= q.hi) { // FLJ windows
+    double fpair, V = 0.0;
+    if (rsq >= q.sw) {
+      const double r2inv = fast_rcp(rsq);
+      const double r6inv = r2inv * r2inv * r2inv;
+      if (EV) V = r6inv * (q.c3 * r6inv - q.c4);
+      fpair = r6inv * (q.c1 * r6inv - q.c2) * r2inv;
+    } else { // cubic inner spline, rare: parameters fetched here
+      const double rij = sqrt(rsq);
+      const double drp = rij - P.rcLJmin[pt];
+      if (EV) V = drp * drp * (drp * P.ljc3[pt] + P.ljc2[pt]);
+      fpair = -drp * (3.0 * drp * P.ljc3[pt] + 2.0 * P.ljc2[pt]) / rij;
+    }
+    fx += dx * fpair;
+    fy += dy * fpair;
+    fz += dz * fpair;
+    if (EV) {
+      e += 0.5 * V; // both directions of every pair are visited: half the energy each
+      if (vflag) {
+        const double h = 0.5 * fpair;
+        v0 += dx * dx * h;
+        v1 += dy * dy * h;
+        v2 += dz * dz * h;
+        v3 += dx * dy * h;
+        v4 += dx * dz * h;
+        v5 += dy * dz * h;
+      }
+    }
+  }
+}
+
+template <int CL, int L, bool EV>
+__global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
+    const RebomosDev P, const int nlocal, const int nclus, const double4 *__restrict__ xq,
+    const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const int *__restrict__ lj,
+    const int *__restrict__ cand_off, const unsigned long long *__restrict__ amask, const int *__restrict__ rev,
+    const double *__restrict__ fnbr, const double *__restrict__ eslot, double *__restrict__ f,
+    double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag, const int accumulate)
+{
+  constexpr int U = 2; // list entries per lane in flight (x CL pair evaluations each)
+  static_assert(L % CL == 0, "lanes per cluster must be a multiple of the cluster size");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int s = lane % L;
-  const long long a64 = (long long) blockIdx.x * (256 / L) + tid / L;
-  const bool have = a64 < nlocal;
-  const int a = have ? (int) a64 : 0;
+  const long long k64 = (long long) blockIdx.x * (256 / L) + tid / L;
+  const bool have = k64 < nclus;
+  const int kc = have ? (int) k64 : 0;
 
-  double fx = 0, fy = 0, fz = 0, e = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-  const double4 xa = xq[a];
-  const int ta = (int) xa.w;
+  double4 xa[CL];
+  int ta[CL];
+  bool real[CL]; // the last cluster is padded with copies of its last atom
+  double fx[CL], fy[CL], fz[CL], ee[CL];
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    const int ia = kc * CL + c;
+    real[c] = have && ia < nlocal;
+    xa[c] = xq[ia < nlocal ? ia : nlocal - 1];
+    ta[c] = (int) xa[c].w;
+    fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
+  }
 
   if (have) {
-    // ---- FLJ (pair_rebomos.cpp:493-556), both directions of every pair, half the energy each
-    const int cnt = lj_cnt[a];
-    const int *row = lj + lj_off[a];
-    for (int k = s; k < cnt; k += L) {
-      const int j = row[k];
-      const double4 xj = xq[j];
-      const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      const int pt = ta * 2 + (int) xj.w;
-      if (rsq >= P.lj_rsq_lo[pt] && rsq <= P.lj_rsq_hi[pt]) {
-        double fpair, V;
-        if (rsq >= P.lj_rsq_sw[pt]) {
-          const double r2inv = 1.0 / rsq;
-          const double r6inv = r2inv * r2inv * r2inv;
-          V = r6inv * (P.lj3[pt] * r6inv - P.lj4[pt]);
-          fpair = r6inv * (P.lj1[pt] * r6inv - P.lj2[pt]) * r2inv;
+    const long long b = lj_off[kc];
+    const int cnt = (int) (lj_off[kc + 1] - b);
+    const int split = lj_split[kc]; // entries [0,split) are Mo, [split,cnt) are S
+    const int *row = lj + b;
+    const int self = kc * CL < nlocal ? kc * CL : nlocal - 1;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; seg++) { // neighbour element is uniform inside a segment
+      const int kb = seg ? split : 0, ke = seg ? cnt : split;
+      LJPar q[CL];
+#pragma unroll
+      for (int c = 0; c < CL; c++) q[c] = lj_load(P, ta[c] * 2 + seg);
+      // software pipeline: indices run two iterations ahead, coordinate gathers one iteration ahead of
+      // the arithmetic, so a lane always has 2U 16-byte gathers in flight while it computes
+      int j0[U], j1[U];
+      double4 x0[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = kb + u * L + s;
+        j0[u] = k < ke ? row[k] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) x0[u] = xq[j0[u] >= 0 ? j0[u] : self];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = kb + U * L + u * L + s;
+        j1[u] = k < ke ? row[k] : -1;
+      }
+      for (int k0 = kb; k0 < ke; k0 += U * L) {
+        double4 x1[U];
+        int j2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x1[u] = xq[j1[u] >= 0 ? j1[u] : self];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int k = k0 + 2 * U * L + u * L + s;
+          j2[u] = k < ke ? row[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (j0[u] < 0) continue;
+#pragma unroll
+          for (int c = 0; c < CL; c++)
+            if (real[c])
+              lj_pair<EV>(P, q[c], ta[c] * 2 + seg, xa[c], x0[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3,
+                          v4, v5);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          j0[u] = j1[u];
+          x0[u] = x1[u];
+          j1[u] = j2[u];
+        }
+      }
+    }
+  }
+  double e_lj = 0.0;
+#pragma unroll
+  for (int c = 0; c < CL; c++) e_lj += ee[c];
+
+  // ---- gather the REBO cluster forces: own centre (-sum of slot forces) + neighbour centres.
+  // Slot (a,t) is active iff bit t of amask[a]; the REBO relation is symmetric, so the reverse slot
+  // rev[a][t] (static between list builds) is active too and holds what centre j pushes onto a.
+  // L/CL lanes work on each atom of the cluster.
+  {
+    const int mine = s % CL;
+    const int ia = kc * CL + mine;
+    if (have && ia < nlocal) {
+      const int off = cand_off[ia];
+      const int nc = cand_off[ia + 1] - off;
+      const unsigned long long act = amask[ia];
+      double gx = 0, gy = 0, gz = 0, ge = 0;
+      for (int t = s / CL; t < nc; t += L / CL) {
+        if (!((act >> t) & 1ull)) continue;
+        const int ra = rev[off + t];
+        const double *o = fnbr + 3 * (size_t) (off + t);
+        gx -= o[0];
+        gy -= o[1];
+        gz -= o[2];
+        if (ra >= 0) {
+          const double *oj = fnbr + 3 * (size_t) ra;
+          gx += oj[0];
+          gy += oj[1];
+          gz += oj[2];
+          if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CL; c++)
+        if (c == mine) {
+          fx[c] += gx;
+          fy[c] += gy;
+          fz[c] += gz;
+          ee[c] += ge; // per-atom energy only (the centre kernel tallies the global REBO energy)
+        }
+    }
+  }
+
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    fx[c] = group_sum<L>(fx[c]);
+    fy[c] = group_sum<L>(fy[c]);
+    fz[c] = group_sum<L>(fz[c]);
+    if (eflag & MDP_EFLAG_ATOM) ee[c] = group_sum<L>(ee[c]);
+  }
+  if (have && s < CL) {
+#pragma unroll
+    for (int c = 0; c < CL; c++)
+      if (c == s && kc * CL + c < nlocal) {
+        const int ia = kc * CL + c;
+        double *fo = f + 3 * (size_t) ia;
+        if (accumulate) {
+          fo[0] += fx[c];
+          fo[1] += fy[c];
+          fo[2] += fz[c];
         } else {
-          const double rij = sqrt(rsq);
-          const double drp = rij - P.rcLJmin[pt];
-          V = drp * drp * (drp * P.ljc3[pt] + P.ljc2[pt]);
-          fpair = -drp * (3.0 * drp * P.ljc3[pt] + 2.0 * P.ljc2[pt]) / rij;
+          fo[0] = fx[c];
+          fo[1] = fy[c];
+          fo[2] = fz[c];
         }
-        fx += dx * fpair;
-        fy += dy * fpair;
-        fz += dz * fpair;
-        e += 0.5 * V;
-        if (vflag) {
-          const double h = 0.5 * fpair;
-          v0 += dx * dx * h;
-          v1 += dy * dy * h;
-          v2 += dz * dz * h;
-          v3 += dx * dy * h;
-          v4 += dx * dz * h;
-          v5 += dy * dz * h;
+        if (eflag & MDP_EFLAG_ATOM) {
+          if (accumulate)
+            eatom[ia] += ee[c];
+          else
+            eatom[ia] = ee[c];
         }
       }
-    }
-  }
-  const double e_lj = e; // LJ part goes to both the global and the per-atom energy
-  double e_rebo_atom = 0.0;
-
-  if (have) {
-    // ---- gather the REBO cluster forces: own centre (-sum of slot forces) + neighbour centres
-    const int off = cand_off[a];
-    const int n = rn_num[a];
-    for (int m = s; m < n; m += L) {
-      const double *o = fnbr + 3 * (size_t) (off + m);
-      fx -= o[0];
-      fy -= o[1];
-      fz -= o[2];
-      const int j = rn_idx[off + m];
-      const int offj = cand_off[j];
-      const int nj = rn_num[j];
-      for (int u = 0; u < nj; u++) {
-        if (rn_idx[offj + u] == a) {
-          const double *oj = fnbr + 3 * (size_t) (offj + u);
-          fx += oj[0];
-          fy += oj[1];
-          fz += oj[2];
-          if (eflag & MDP_EFLAG_ATOM) e_rebo_atom += eslot[off + m] + eslot[offj + u];
-          break;
-        }
-      }
-    }
-  }
-
-  fx = group_sum<L>(fx);
-  fy = group_sum<L>(fy);
-  fz = group_sum<L>(fz);
-  if (have && s == 0) {
-    double *fo = f + 3 * (size_t) a;
-    if (accumulate) {
-      fo[0] += fx;
-      fo[1] += fy;
-      fo[2] += fz;
-    } else {
-      fo[0] = fx;
-      fo[1] = fy;
-      fo[2] = fz;
-    }
-  }
-  if (eflag & MDP_EFLAG_ATOM) {
-    const double ea = group_sum<L>(e_lj + e_rebo_atom);
-    if (have && s == 0) {
-      if (accumulate)
-        eatom[a] += ea;
-      else
-        eatom[a] = ea;
-    }
   }
   double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
   if (eflag & MDP_EFLAG_GLOBAL) {
@@ -505,23 +630,90 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
   }
 }
 
+// cluster pair list straight from the bin grid: every atom j within rcLJmax+skin of ANY atom of the
+// cluster, Mo neighbours first, then S (so the LJ parameters are loop invariants of each segment).
+// One thread per cluster; consecutive clusters are spatial neighbours, so a wave shares its stencil.
+template <int CL, bool FILL>
+__global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, const RebomosDev P, const int nclus,
+                                                            const int nlocal, const double4 *__restrict__ xq,
+                                                            const int *__restrict__ perm,
+                                                            const int *__restrict__ cell_start, int *__restrict__ cnt,
+                                                            int *__restrict__ split, const long long *__restrict__ off,
+                                                            int *__restrict__ out)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nclus) return;
+  double4 xa[CL];
+  int ta[CL];
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    const int ia = k * CL + c < nlocal ? k * CL + c : nlocal - 1;
+    xa[c] = xq[ia];
+    ta[c] = (int) xa[c].w;
+    int cc[3];
+    cc[0] = (int) ((xa[c].x - g.lo[0]) * g.inv[0]);
+    cc[1] = (int) ((xa[c].y - g.lo[1]) * g.inv[1]);
+    cc[2] = (int) ((xa[c].z - g.lo[2]) * g.inv[2]);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      cc[d] = cc[d] < 0 ? 0 : (cc[d] >= g.n[d] ? g.n[d] - 1 : cc[d]);
+      lo[d] = cc[d] < lo[d] ? cc[d] : lo[d];
+      hi[d] = cc[d] > hi[d] ? cc[d] : hi[d];
+    }
+  }
+  const int R = g.range;
+  int n0 = 0, n1 = 0;
+  int *row0 = FILL ? out + off[k] : nullptr;
+  int *row1 = FILL ? row0 + split[k] : nullptr;
+  for (int z = max(lo[2] - R, 0); z <= min(hi[2] + R, g.n[2] - 1); z++)
+    for (int y = max(lo[1] - R, 0); y <= min(hi[1] + R, g.n[1] - 1); y++) {
+      const int c0 = max(lo[0] - R, 0) + g.n[0] * (y + g.n[1] * z);
+      const int c1 = min(hi[0] + R, g.n[0] - 1) + g.n[0] * (y + g.n[1] * z);
+      const int pb = cell_start[c0], pe = cell_start[c1 + 1];
+      for (int p = pb; p < pe; p++) {
+        const int j = perm[p];
+        const double4 xj = xq[j];
+        const int tj = (int) xj.w;
+        bool keep = false;
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dx = xa[c].x - xj.x, dy = xa[c].y - xj.y, dz = xa[c].z - xj.z;
+          keep = keep || (dx * dx + dy * dy + dz * dz <= P.ljlist_cutsq[ta[c] * 2 + tj]);
+        }
+        if (keep) {
+          if (tj == 0) {
+            if (FILL) row0[n0] = j;
+            n0++;
+          } else {
+            if (FILL) row1[n1] = j;
+            n1++;
+          }
+        }
+      }
+    }
+  if (!FILL) {
+    cnt[k] = n0 + n1;
+    split[k] = n0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // repack at every neighbor (re)build: master CSR list -> REBO candidates + trimmed LJ list
 // ------------------------------------------------------------------------------------------------
 constexpr int RP_L = 16; // lanes per atom in the repack kernels
 
-// counts per atom: cand_cnt[i] (all atoms), lj_cnt[i] (owned)
+// counts per atom: cand_cnt[i] (all atoms)
 __global__ __launch_bounds__(256) void repack_count_kernel(const RebomosDev P, const int nall, const int nlocal,
                                                            const double4 *__restrict__ xq,
                                                            const long long *__restrict__ nb_off,
-                                                           const int *__restrict__ nb, int *__restrict__ cand_cnt,
-                                                           int *__restrict__ lj_cnt)
+                                                           const int *__restrict__ nb, int *__restrict__ cand_cnt)
 {
   const int s = threadIdx.x % RP_L;
   const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
   const bool have = i64 < nall;
   const int i = have ? (int) i64 : 0;
-  int nc = 0, nl = 0;
+  int nc = 0;
   if (have) {
     const double4 xi = xq[i];
     const int ti = (int) xi.w;
@@ -531,28 +723,20 @@ __global__ __launch_bounds__(256) void repack_count_kernel(const RebomosDev P, c
       const double4 xj = xq[j];
       const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      const int pt = ti * 2 + (int) xj.w;
-      nc += rsq <= P.cand_cutsq[pt];
-      nl += rsq <= P.ljlist_cutsq[pt];
+      nc += rsq <= P.cand_cutsq[ti * 2 + (int) xj.w];
     }
   }
 #pragma unroll
-  for (int o = RP_L / 2; o > 0; o >>= 1) {
-    nc += __shfl_xor(nc, o, 64);
-    nl += __shfl_xor(nl, o, 64);
-  }
-  if (have && s == 0) {
-    cand_cnt[i] = nc;
-    if (i < nlocal) lj_cnt[i] = nl;
-  }
+  for (int o = RP_L / 2; o > 0; o >>= 1) nc += __shfl_xor(nc, o, 64);
+  if (have && s == 0) cand_cnt[i] = nc;
+  (void) nlocal;
 }
 
 __global__ __launch_bounds__(256) void repack_fill_kernel(const RebomosDev P, const int nall, const int nlocal,
                                                           const double4 *__restrict__ xq,
                                                           const long long *__restrict__ nb_off,
                                                           const int *__restrict__ nb, const int *__restrict__ cand_off,
-                                                          int *__restrict__ cand, const long long *__restrict__ lj_off,
-                                                          int *__restrict__ lj, int *__restrict__ is_centre)
+                                                          int *__restrict__ cand, int *__restrict__ is_centre)
 {
   const int lane = threadIdx.x & 63;
   const int s = lane % RP_L;
@@ -566,34 +750,52 @@ __global__ __launch_bounds__(256) void repack_fill_kernel(const RebomosDev P, co
   const int len = (int) (e - b);
   const int lenw = wave_max_int(len);
   const bool own = have && i < nlocal;
-  int nc = 0, nl = 0;
+  int nc = 0;
   const int coff = have ? cand_off[i] : 0;
-  const long long loff = own ? lj_off[i] : 0;
   for (int base = 0; base < lenw; base += RP_L) {
     const int k = base + s;
-    bool pc = false, pl = false;
+    bool pc = false;
     int j = 0;
     if (k < len) {
       j = nb[b + k];
       const double4 xj = xq[j];
       const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      const int pt = ti * 2 + (int) xj.w;
-      pc = rsq <= P.cand_cutsq[pt];
-      pl = own && rsq <= P.ljlist_cutsq[pt];
+      pc = rsq <= P.cand_cutsq[ti * 2 + (int) xj.w];
     }
     const unsigned long long bc = (__ballot(pc) >> glane0) & ((1ull << RP_L) - 1ull);
-    const unsigned long long bl = (__ballot(pl) >> glane0) & ((1ull << RP_L) - 1ull);
     const unsigned long long below = (1ull << s) - 1ull;
     if (pc) {
       cand[coff + nc + __popcll(bc & below)] = j;
       if (own && j >= nlocal) is_centre[j] = 1; // ghost neighbours of owned atoms are centres too
     }
-    if (pl) lj[loff + nl + __popcll(bl & below)] = j;
     nc += __popcll(bc);
-    nl += __popcll(bl);
   }
   if (own && s == 0) is_centre[i] = 1;
+}
+
+// rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
+__global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *__restrict__ cand_off,
+                                                  const int *__restrict__ cand, int *__restrict__ rev,
+                                                  int *__restrict__ flags)
+{
+  const int s = threadIdx.x % RP_L;
+  const long long a64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
+  if (a64 >= nlocal) return;
+  const int a = (int) a64;
+  const int off = cand_off[a], nc = cand_off[a + 1] - off;
+  if (nc > 64 && s == 0) atomicOr(&flags[1], 1); // the active mask holds 64 candidates
+  for (int t = s; t < nc; t += RP_L) {
+    const int j = cand[off + t];
+    const int oj = cand_off[j], nj = cand_off[j + 1] - oj;
+    int r = -1;
+    for (int u = 0; u < nj; u++)
+      if (cand[oj + u] == a) {
+        r = oj + u;
+        break;
+      }
+    rev[off + t] = r;
+  }
 }
 
 // current REBO coordination -> lane-group class, appended to the class lists
@@ -711,42 +913,79 @@ int mdp_rebomos_repack(mdp_ctx *c)
   hipStream_t st = c->stream;
   MDP_HIP(c, c->cand_cnt.reserve(nall + 1));
   MDP_HIP(c, c->cand_off.reserve(nall + 2));
-  MDP_HIP(c, c->lj_cnt.reserve(nlocal + 1));
-  MDP_HIP(c, c->lj_off.reserve(nlocal + 2));
+  int cl = MDP_CLUSTER;
+  if (const char *e = getenv("MDP_CLUSTER")) cl = atoi(e);
+  if (cl != 1 && cl != 2 && cl != 4) cl = MDP_CLUSTER;
+  c->cluster = cl;
+  const int nclus = (nlocal + cl - 1) / cl;
+  c->nclus = nclus;
+  MDP_HIP(c, c->lj_split.reserve(nclus + 1));
+  MDP_HIP(c, c->lj_cnt.reserve(nclus + 1));
+  MDP_HIP(c, c->lj_off.reserve(nclus + 2));
   MDP_HIP(c, c->is_center.reserve(nall + 1));
-  MDP_HIP(c, c->rn_num.reserve(nall + 1));
+  MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->class_list.reserve((size_t) 4 * nall + 4));
   MDP_HIP(c, c->class_count.reserve(4));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
-  MDP_HIP(c, hipMemsetAsync(c->rn_num.p, 0, sizeof(int) * nall, st));
+  MDP_HIP(c, hipMemsetAsync(c->amask.p, 0, sizeof(unsigned long long) * nall, st));
+  MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, st));
   MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * 4, st));
   const int per_block = 256 / RP_L;
   const int grid = (nall + per_block - 1) / per_block;
-  repack_count_kernel<<<grid, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_cnt.p,
-                                            c->lj_cnt.p);
+  repack_count_kernel<<<grid, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_cnt.p);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
-  MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nlocal));
+  // Lennard-Jones cluster pair list from the bin grid (cutoff rcLJmax + skin)
+  double ljcut = 0.0;
+  for (int k = 0; k < 4; k++) ljcut = ljcut > c->rebomos.ljlist_cutsq[k] ? ljcut : c->rebomos.ljlist_cutsq[k];
+  ljcut = sqrt(ljcut);
+  MDP_TRY(mdp_bin_atoms(c, ljcut, c->bbox_lo, c->bbox_hi));
+  if (nclus) {
+    const int gb = (nclus + 255) / 256;
+#define MDP_CB(CLV, FILLV, OFFP, OUTP)                                                                              \
+  cluster_build_kernel<CLV, FILLV><<<gb, 256, 0, st>>>(c->grid, c->rebomos, nclus, nlocal, c->xq.p, c->cell_perm.p, \
+                                                       c->cell_start.p, c->lj_cnt.p, c->lj_split.p, OFFP, OUTP)
+    if (cl == 1) MDP_CB(1, false, nullptr, nullptr);
+    else if (cl == 2) MDP_CB(2, false, nullptr, nullptr);
+    else MDP_CB(4, false, nullptr, nullptr);
+  }
+  MDP_HIP(c, hipGetLastError());
+  MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nclus));
   int cand_total = 0;
   long long lj_total = 0;
   MDP_HIP(c, hipMemcpyAsync(&cand_total, c->cand_off.p + nall, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipMemcpyAsync(&lj_total, c->lj_off.p + nlocal, sizeof(long long), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(&lj_total, c->lj_off.p + nclus, sizeof(long long), hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   c->cand_total = cand_total;
   c->lj_total = lj_total;
   MDP_HIP(c, c->cand.reserve((size_t) cand_total + 1));
   MDP_HIP(c, c->lj.reserve((size_t) lj_total + 1));
-  MDP_HIP(c, c->rn_idx.reserve((size_t) cand_total + 1));
+  MDP_HIP(c, c->rev.reserve((size_t) cand_total + 1));
   MDP_HIP(c, c->fnbr.reserve((size_t) 3 * cand_total + 3));
   MDP_HIP(c, c->eslot.reserve((size_t) cand_total + 1));
   repack_fill_kernel<<<grid, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_off.p,
-                                           c->cand.p, c->lj_off.p, c->lj.p, c->is_center.p);
+                                           c->cand.p, c->is_center.p);
+  if (nclus) {
+    const int gb = (nclus + 255) / 256;
+    if (cl == 1) MDP_CB(1, true, c->lj_off.p, c->lj.p);
+    else if (cl == 2) MDP_CB(2, true, c->lj_off.p, c->lj.p);
+    else MDP_CB(4, true, c->lj_off.p, c->lj.p);
+  }
+#undef MDP_CB
   MDP_HIP(c, hipGetLastError());
   classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, c->xq.p, c->cand_off.p, c->cand.p,
                                                       c->is_center.p, c->class_list.p, c->class_count.p);
   MDP_HIP(c, hipGetLastError());
+  if (nlocal)
+    rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
+                                                                     c->flags.p);
+  MDP_HIP(c, hipGetLastError());
+  int hflags[4] = {0, 0, 0, 0};
   MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
+  if (hflags[1])
+    return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
   c->rebo_packed = true;
   return MDP_OK;
 }
@@ -759,8 +998,8 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
   const int per_block = 256 / G;
   const int grid = (n + per_block - 1) / per_block;
   rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
-                                                     c->xq.p, c->cand_off.p, c->cand.p, c->rn_num.p, c->rn_idx.p,
-                                                     c->fnbr.p, c->eslot.p, c->acc.p, c->flags.p, eflag, vflag);
+                                                     c->xq.p, c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
+                                                     c->eslot.p, c->acc.p, c->flags.p, eflag, vflag);
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
@@ -779,11 +1018,19 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
   mdp_time_mark(c, 1);
   constexpr int L = 16;
   const int per_block = 256 / L;
-  const int grid = (c->nlocal + per_block - 1) / per_block;
-  if (grid > 0)
-    rebo_lj_gather_kernel<L><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj_cnt.p, c->lj.p,
-                                                   c->cand_off.p, c->rn_num.p, c->rn_idx.p, c->fnbr.p, c->eslot.p,
-                                                   c->f.p, c->eatom.p, c->acc.p, eflag, vflag, zero_f ? 0 : 1);
+  const int grid = (c->nclus + per_block - 1) / per_block;
+  if (grid > 0) {
+#define MDP_LJ(CLV, EVV)                                                                                            \
+  rebo_lj_gather_kernel<CLV, L, EVV><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->nclus, c->xq.p, c->lj_off.p,     \
+                                                           c->lj_split.p, c->lj.p, c->cand_off.p, c->amask.p,         \
+                                                           c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p,       \
+                                                           c->acc.p, eflag, vflag, zero_f ? 0 : 1)
+    const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
+    if (c->cluster == 1) { if (ev) MDP_LJ(1, true); else MDP_LJ(1, false); }
+    else if (c->cluster == 2) { if (ev) MDP_LJ(2, true); else MDP_LJ(2, false); }
+    else { if (ev) MDP_LJ(4, true); else MDP_LJ(4, false); }
+#undef MDP_LJ
+  }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 2);
   return mdp_acc_end(c, eflag || vflag);
