@@ -189,6 +189,7 @@ int mdp_destroy(mdp_ctx *c)
   c->class_list.release();
   c->class_count.release();
   c->amask.release();
+  c->ovf.release();
   c->rev.release();
   c->fnbr.release();
   c->eslot.release();

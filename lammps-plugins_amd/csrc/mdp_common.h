@@ -136,6 +136,7 @@ struct mdp_ctx {
   int h_class_count[4] = {0, 0, 0, 0};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
+  DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
   DevBuf<double> fnbr;            // [cand_total][3]
   DevBuf<double> eslot;           // [cand_total]
   DevBuf<char> scan_tmp;

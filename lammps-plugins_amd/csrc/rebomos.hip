@@ -98,6 +98,21 @@ __device__ __forceinline__ double poly6(const double *c, double x, double &d)
   return g;
 }
 
+__device__ __forceinline__ double poly6v(const double *c, double x)
+{
+  return (((((c[6] * x + c[5]) * x + c[4]) * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
+}
+
+// G(cos) only (first pass over the neighbour pairs)
+__device__ __forceinline__ double gspline_val(const double *cb, const double *cg, double c)
+{
+  const double gcos = poly6v(cb, c);
+  if (c < 0.5) return gcos;
+  const double gamma = poly6v(cg, c);
+  const double psi = 0.5 * (1.0 - cospi(2.0 * (c - 0.5)));
+  return gcos + psi * (gamma - gcos);
+}
+
 // G(cos) and dG/dcos, pair_rebomos.h:68-167.  cb/cg: the centre element's b0..b6 / bg0..bg6.
 __device__ __forceinline__ double gspline(const double *cb, const double *cg, double c, double &dgdc)
 {
@@ -118,23 +133,151 @@ __device__ __forceinline__ double gspline(const double *cb, const double *cg, do
 // ------------------------------------------------------------------------------------------------
 // centre kernel
 // ------------------------------------------------------------------------------------------------
-template <int G> struct CentreCfg {
-  static constexpr int CAP = 2 * G;     // LDS slots per centre
-  static constexpr int GPW = 64 / G;    // centres per wave
-  static constexpr int WPB = 4;         // waves per block
-  static constexpr int REC = 8;         // doubles per slot: dx dy dz r w dw C p
-  static constexpr int STRIDE = CAP * REC + REC; // +1 record of padding per centre
+// per-slot LDS record of a centre's neighbour: dx dy dz r w dw C p 1/r V_A   (d = x_c - x_m)
+constexpr int kRec = 10;
+
+struct CentreOut {
+  double e_acc, v0, v1, v2, v3, v4, v5;
 };
 
+// shared epilogue of a slot: radial terms (pair_rebomos.cpp:411-441, 683-725), store, tallies
+__device__ __forceinline__ void finish_slot(const RebomosDev &P, const int tc, const int je_m, const int off,
+                                            const double dp, const bool owned, const int eflag, const double mx,
+                                            const double my, const double mz, const double mr, const double mw,
+                                            const double mdw, const double mp, const double mrinv, const double mVA,
+                                            double fx, double fy, double fz, const double acc1, const double Csum,
+                                            double *__restrict__ fnbr, double *__restrict__ eslot, CentreOut &o)
+{
+  const int tm = ((unsigned) je_m) >> 30;
+  const int pt = tc * 2 + tm;
+  const double ux = mx * mrinv, uy = my * mrinv, uz = mz * mrinv;
+  double radial = (acc1 + Csum * dp) * mdw; // dw_cm [ sum_q C_q G + P'(N) sum_j C_j ]
+  double ehalf = 0.0;
+  if (mw > kTol) {
+    const double ex = exp(-P.alpha[pt] * mr);
+    const double pre = mw * P.A[pt] * ex;
+    const double VR = pre * (1.0 + P.Q[pt] * mrinv);
+    double dVR = pre * (-P.alpha[pt] - P.Q[pt] * mrinv * mrinv - P.Q[pt] * P.alpha[pt] * mrinv);
+    dVR += VR / mw * mdw;
+    double dVA = -P.beta[pt] * mVA;
+    dVA += mVA / mw * mdw;
+    radial += 0.5 * (dVR + mp * dVA);
+    ehalf = 0.5 * (VR + mp * mVA);
+  }
+  fx += radial * ux;
+  fy += radial * uy;
+  fz += radial * uz;
+  // slot forces are filed under the neighbour's (static) candidate slot: the gather finds the
+  // reverse slot through a table built once per list build
+  const int tslot = je_m & 0x3FFFFFFF;
+  double *out = fnbr + 3 * (size_t) (off + tslot);
+  out[0] = fx;
+  out[1] = fy;
+  out[2] = fz;
+  if (eflag & MDP_EFLAG_ATOM) eslot[off + tslot] = 0.5 * ehalf;
+  if (owned) {
+    o.e_acc += ehalf;
+    // virial of the cluster: sum_m (x_m - x_c) (x) F_m = -sum_m d_m (x) F_m
+    o.v0 -= mx * fx;
+    o.v1 -= my * fy;
+    o.v2 -= mz * fz;
+    o.v3 -= mx * fy;
+    o.v4 -= mx * fz;
+    o.v5 -= my * fz;
+  }
+}
+
+__device__ __forceinline__ void centre_tally(const CentreOut &o, double *__restrict__ acc, const int eflag,
+                                             const int vflag)
+{
+  // partial sums go to one of MDP_ACC_SLOTS slots (by block) so that a million waves do not queue
+  // on seven addresses; acc_reduce_kernel folds the slots afterwards
+  const int lane = threadIdx.x & 63;
+  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+  if (eflag & MDP_EFLAG_GLOBAL) {
+    const double e = group_sum<64>(o.e_acc);
+    if (lane == 0) atomicAdd(&slot[0], e);
+  }
+  if (vflag & MDP_VFLAG_GLOBAL) {
+    const double v0 = group_sum<64>(o.v0), v1 = group_sum<64>(o.v1), v2 = group_sum<64>(o.v2);
+    const double v3 = group_sum<64>(o.v3), v4 = group_sum<64>(o.v4), v5 = group_sum<64>(o.v5);
+    if (lane == 0) {
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
+    }
+  }
+}
+
+// phase A for one candidate: distance test against rcmax (pair_rebomos.cpp:337), ballot compaction into
+// the centre's LDS slots in candidate order.  Returns nothing; updates n / active / nsum.
+template <int G, int CAP>
+__device__ __forceinline__ void centre_take(const RebomosDev &P, const int tc, const double4 xc, const bool valid,
+                                            const int t, const double4 xj, const int s, const int glane0,
+                                            const int base, double *rec, int *je, int &n,
+                                            unsigned long long &active, double &nsum)
+{
+  const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  const double dx = xc.x - xj.x, dy = xc.y - xj.y, dz = xc.z - xj.z;
+  const double rsq = dx * dx + dy * dy + dz * dz;
+  const int tj = (int) xj.w;
+  const bool pred = valid && rsq < P.rcmaxsq[tc * 2 + tj];
+  const unsigned long long bal = __ballot(pred);
+  const unsigned long long gb = (bal >> glane0) & gmask;
+  const int pos = n + __popcll(gb & ((1ull << s) - 1ull));
+  if (pred && pos < CAP) {
+    const int pt = tc * 2 + tj;
+    const double r = sqrt(rsq);
+    double dw;
+    const double w = sp_switch(r, P.rcmin[pt], P.rcinv[pt], dw);
+    double *q = rec + pos * kRec;
+    q[0] = dx;
+    q[1] = dy;
+    q[2] = dz;
+    q[3] = r;
+    q[4] = w;
+    q[5] = dw;
+    q[8] = 1.0 / r;
+    je[pos] = t | (tj << 30);
+    nsum += w; // nM + nS (pair_rebomos.cpp:339-342); only their sum is ever used (:628, h:175)
+  }
+  n += __popcll(gb);
+  if (base < 64) active |= gb << base;
+}
+
+template <int G> struct CentreCfg {
+  static constexpr int CAP = G;          // fast kernel: every neighbour has its own lane
+  static constexpr int GPW = 64 / G;     // centres per wave
+  static constexpr int WPB = 4;          // waves per block
+  static constexpr int STRIDE = CAP * kRec + 2; // small pad: spreads the groups over the LDS banks
+  // {G(cos), G'(cos)} per unordered neighbour pair
+  static constexpr int NPAIR = G * (G - 1) / 2;
+  static constexpr int MSTRIDE = 2 * NPAIR + 2;
+  static constexpr int UA = G >= 32 ? 1 : (G >= 16 ? 2 : 4); // candidate chunks in flight in phase A
+};
+
+// slot of the unordered pair (a < b) in the triangular matrix of a G-slot group
+template <int G> __device__ __forceinline__ int tri_index(int a, int b)
+{
+  return a * (2 * G - a - 1) / 2 + (b - a - 1);
+}
+
+// ---- fast centre kernel: G lanes per centre, at most G neighbours (slot m = lane) --------------------
+// A centre whose coordination has outgrown its lane group since the last list build is handed to
+// rebo_centre_general_kernel through the overflow list.
 template <int G>
 __global__ __launch_bounds__(256) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ eslot,
-    double *__restrict__ acc, int *__restrict__ flags, const int eflag, const int vflag)
+    double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag)
 {
   using C = CentreCfg<G>;
   __shared__ double s_rec[C::WPB * C::GPW * C::STRIDE];
+  __shared__ double s_mat[C::WPB * C::GPW * C::MSTRIDE];
   __shared__ int s_je[C::WPB * C::GPW * C::CAP]; // element (bit 30) | candidate slot of the neighbour
 
   const int tid = threadIdx.x;
@@ -146,6 +289,7 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   const bool have = gid < ncent;
 
   double *rec = s_rec + (size_t) grp_in_block * C::STRIDE;
+  double *mat = s_mat + (size_t) grp_in_block * C::MSTRIDE;
   int *je = s_je + grp_in_block * C::CAP;
 
   int c = 0, off = 0, nc = 0, tc = 0;
@@ -158,55 +302,33 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     tc = (int) xc.w;
   }
 
-  // ---- phase A: filter the candidates to the current REBO set (pair_rebomos.cpp:328-344) --------
+  // ---- phase A: filter the candidates to the current REBO set (pair_rebomos.cpp:328-344);
+  // UA chunks of G candidates are loaded before the first is used
   int n = 0;
   double nsum = 0.0;
   unsigned long long active = 0ull; // bit t: candidate t is inside rcmax right now (group-uniform)
-  const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
   const int ncw = wave_max_int(nc);
-  for (int base = 0; base < ncw; base += G) {
-    const int t = base + s;
-    const bool valid = t < nc;
-    int j = c;
-    bool pred = false;
-    double dx = 0, dy = 0, dz = 0, rsq = 0;
-    int tj = 0;
-    if (valid) {
-      j = cand[off + t];
-      const double4 xj = xq[j];
-      dx = xc.x - xj.x;
-      dy = xc.y - xj.y;
-      dz = xc.z - xj.z;
-      rsq = dx * dx + dy * dy + dz * dz;
-      tj = (int) xj.w;
-      pred = rsq < P.rcmaxsq[tc * 2 + tj];
+  for (int base = 0; base < ncw; base += C::UA * G) {
+    int jj[C::UA];
+    double4 xj[C::UA];
+#pragma unroll
+    for (int u = 0; u < C::UA; u++) {
+      const int t = base + u * G + s;
+      jj[u] = t < nc ? cand[off + t] : c;
     }
-    const unsigned long long bal = __ballot(pred);
-    const unsigned long long gb = (bal >> glane0) & gmask;
-    const int pos = n + __popcll(gb & ((1ull << s) - 1ull));
-    if (pred && pos < C::CAP) {
-      const int pt = tc * 2 + tj;
-      const double r = sqrt(rsq);
-      double dw;
-      const double w = sp_switch(r, P.rcmin[pt], P.rcinv[pt], dw);
-      double *q = rec + pos * C::REC;
-      q[0] = dx;
-      q[1] = dy;
-      q[2] = dz;
-      q[3] = r;
-      q[4] = w;
-      q[5] = dw;
-      je[pos] = t | (tj << 30);
-      nsum += w; // nM + nS (pair_rebomos.cpp:339-342); only their sum is ever used (:628, h:175)
+#pragma unroll
+    for (int u = 0; u < C::UA; u++) xj[u] = xq[jj[u]];
+#pragma unroll
+    for (int u = 0; u < C::UA; u++) {
+      const int t = base + u * G + s;
+      centre_take<G, C::CAP>(P, tc, xc, t < nc, t, xj[u], s, glane0, base + u * G, rec, je, n, active, nsum);
     }
-    n += __popcll(gb);
-    if (base < 64) active |= gb << base;
-  }
-  if (n > C::CAP) {
-    if (s == 0) atomicOr(&flags[0], 1);
-    n = C::CAP;
   }
   if (have && s == 0) amask[c] = active;
+  if (n > C::CAP) { // outgrown: the general kernel takes this centre
+    if (s == 0) ovf[1 + atomicAdd(&ovf[0], 1)] = c;
+    n = 0;
+  }
   const double Ntot = group_sum<G>(nsum);
   wave_lds_fence();
 
@@ -223,154 +345,223 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   const double PS = -P.a[tc][0] * (Ntot - 1.0) - P.a[tc][1] * ea + P.a[tc][3];
 
   const int nw = wave_max_int(n);
-
-  // ---- phase B: p_cm and C_m = 1/2 V_A (-1/2 p^3) for every slot (pair_rebomos.cpp:607-630) ------
-  double csum_part = 0.0;
-  for (int mb = 0; mb < nw; mb += G) {
-    const int m = mb + s;
-    const bool act = m < n;
-    double mx = 0, my = 0, mz = 0, mr = 1, mw = 0;
-    if (act) {
-      const double *q = rec + m * C::REC;
-      mx = q[0];
-      my = q[1];
-      mz = q[2];
-      mr = q[3];
-      mw = q[4];
-    }
-    const double mrinv = 1.0 / mr;
-    double S = 0.0;
-    for (int qi = 0; qi < nw; qi++) {
-      if (act && qi < n && qi != m) {
-        const double *q = rec + qi * C::REC;
-        double cs = (mx * q[0] + my * q[1] + mz * q[2]) / (mr * q[3]);
-        cs = fmin(cs, 1.0);
-        cs = fmax(cs, -1.0);
-        double dg;
-        const double g = gspline(cb, cg, cs, dg);
-        S += q[4] * g;
-      }
-    }
-    if (act) {
-      const int tm = ((unsigned) je[m]) >> 30;
-      const int pt = tc * 2 + tm;
-      const double p = 1.0 / sqrt(1.0 + S + PS);
-      const double VA = -mw * P.B[pt] * exp(-P.beta[pt] * mr);
-      const double Cm = (mw > kTol) ? 0.5 * VA * (-0.5 * p * p * p) : 0.0;
-      double *q = rec + m * C::REC;
-      q[6] = Cm;
-      q[7] = p;
-      csum_part += Cm;
-    }
-    (void) mrinv;
-  }
-  const double Csum = group_sum<G>(csum_part);
-  wave_lds_fence();
-
-  // ---- phase C: force of E_c on every neighbour slot (pair_rebomos.cpp:411-441, 634-725) ----------
-  double e_acc = 0.0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  CentreOut o = {0, 0, 0, 0, 0, 0, 0};
   const bool owned = have && c < nlocal;
-  for (int mb = 0; mb < nw; mb += G) {
-    const int m = mb + s;
-    const bool act = m < n;
-    double mx = 0, my = 0, mz = 0, mr = 1, mw = 0, mdw = 0, mC = 0, mp = 0;
-    if (act) {
-      const double *q = rec + m * C::REC;
-      mx = q[0];
-      my = q[1];
-      mz = q[2];
-      mr = q[3];
-      mw = q[4];
-      mdw = q[5];
-      mC = q[6];
-      mp = q[7];
-    }
-    const double mrinv = 1.0 / mr;
-    const double ux = mx * mrinv, uy = my * mrinv, uz = mz * mrinv; // unit vector (x_c - x_m)/r
-    double fx = 0, fy = 0, fz = 0, acc1 = 0;
-    for (int qi = 0; qi < nw; qi++) {
-      if (act && qi < n && qi != m) {
-        const double *q = rec + qi * C::REC;
-        const double qrinv = 1.0 / q[3];
-        double cs = (mx * q[0] + my * q[1] + mz * q[2]) * (mrinv * qrinv);
-        cs = fmin(cs, 1.0);
-        cs = fmax(cs, -1.0);
-        double dg;
-        const double g = gspline(cb, cg, cs, dg);
-        // (C_m w_q + C_q w_m) G'(cos) d cos / d x_m ; d cos/d x_m = -(u_q - cos u_m)/r_m
-        // force = -gradient
-        const double coef = (mC * q[4] + q[6] * mw) * dg * mrinv;
-        fx += coef * (q[0] * qrinv - cs * ux);
-        fy += coef * (q[1] * qrinv - cs * uy);
-        fz += coef * (q[2] * qrinv - cs * uz);
-        acc1 += q[6] * g;
-      }
-    }
-    if (act) {
-      const int tm = ((unsigned) je[m]) >> 30;
-      const int pt = tc * 2 + tm;
-      double radial = (acc1 + Csum * dp) * mdw; // dw_cm [ sum_q C_q G + P'(N) sum_j C_j ]
-      double ehalf = 0.0;
-      if (mw > kTol) {
-        // pair_rebomos.cpp:418-427
-        const double ex = exp(-P.alpha[pt] * mr);
-        const double pre = mw * P.A[pt] * ex;
-        const double VR = pre * (1.0 + P.Q[pt] * mrinv);
-        double dVR = pre * (-P.alpha[pt] - P.Q[pt] * mrinv * mrinv - P.Q[pt] * P.alpha[pt] * mrinv);
-        dVR += VR / mw * mdw;
-        const double VA = -mw * P.B[pt] * exp(-P.beta[pt] * mr);
-        double dVA = -P.beta[pt] * VA;
-        dVA += VA / mw * mdw;
-        radial += 0.5 * (dVR + mp * dVA);
-        ehalf = 0.5 * (VR + mp * VA);
-      }
-      fx += radial * ux;
-      fy += radial * uy;
-      fz += radial * uz;
-      // slot forces are filed under the neighbour's (static) candidate slot: the gather finds the
-      // reverse slot through a table built once per list build
-      const int tslot = je[m] & 0x3FFFFFFF;
-      double *o = fnbr + 3 * (size_t) (off + tslot);
-      o[0] = fx;
-      o[1] = fy;
-      o[2] = fz;
-      if (eflag & MDP_EFLAG_ATOM) eslot[off + tslot] = 0.5 * ehalf;
-      if (owned) {
-        e_acc += ehalf;
-        // virial of the cluster: sum_m (x_m - x_c) (x) F_m = -sum_m d_m (x) F_m
-        v0 -= mx * fx;
-        v1 -= my * fy;
-        v2 -= mz * fz;
-        v3 -= mx * fy;
-        v4 -= mx * fz;
-        v5 -= my * fz;
-      }
-    }
-  }
 
-  // partial sums go to one of MDP_ACC_SLOTS slots (by block) so that a million waves do not queue
-  // on seven addresses; acc_reduce_kernel folds the slots afterwards
-  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
-  if (eflag & MDP_EFLAG_GLOBAL) {
-    const double e = group_sum<64>(e_acc);
-    if (lane == 0) atomicAdd(&slot[0], e);
+  const int m = s;
+  const bool act = m < n;
+  double mx = 0, my = 0, mz = 0, mr = 1, mw = 0, mdw = 0, mri = 1;
+  if (act) {
+    const double *q = rec + m * kRec;
+    mx = q[0];
+    my = q[1];
+    mz = q[2];
+    mr = q[3];
+    mw = q[4];
+    mdw = q[5];
+    mri = q[8];
   }
-  if (vflag & MDP_VFLAG_GLOBAL) {
-    v0 = group_sum<64>(v0);
-    v1 = group_sum<64>(v1);
-    v2 = group_sum<64>(v2);
-    v3 = group_sum<64>(v3);
-    v4 = group_sum<64>(v4);
-    v5 = group_sum<64>(v5);
-    if (lane == 0) {
-      atomicAdd(&slot[1], v0);
-      atomicAdd(&slot[2], v1);
-      atomicAdd(&slot[3], v2);
-      atomicAdd(&slot[4], v3);
-      atomicAdd(&slot[5], v4);
-      atomicAdd(&slot[6], v5);
+  const double ux = mx * mri, uy = my * mri, uz = mz * mri;
+  // -- every unordered pair (m,q) ONCE: circulant enumeration q = (m+d) mod n, d = 1..n/2 (for even n
+  //    the distance-n/2 pairs are taken by the lower half of the lanes); G and G' go to the LDS matrix
+  for (int d = 1; d <= nw / 2; d++) {
+    const bool mine = act && (2 * d < n || (2 * d == n && m < d));
+    if (mine) {
+      int qi = m + d;
+      qi = qi >= n ? qi - n : qi;
+      const double *q = rec + qi * kRec;
+      double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * q[8];
+      cs = fmin(cs, 1.0);
+      cs = fmax(cs, -1.0);
+      double dg;
+      const double g = gspline(cb, cg, cs, dg);
+      double *e = mat + 2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m);
+      e[0] = g;
+      e[1] = dg;
     }
   }
+  wave_lds_fence();
+  // -- phase B: p_cm, C_m (pair_rebomos.cpp:607-630)
+  double S = 0.0;
+  for (int qi = 0; qi < nw; qi++)
+    if (act && qi < n && qi != m) S += rec[qi * kRec + 4] * mat[2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m)];
+  double mC = 0.0, mp = 0.0, mVA = 0.0;
+  if (act) {
+    const int pt = tc * 2 + (((unsigned) je[m]) >> 30);
+    mp = 1.0 / sqrt(1.0 + S + PS);
+    mVA = -mw * P.B[pt] * exp(-P.beta[pt] * mr);
+    mC = (mw > kTol) ? 0.5 * mVA * (-0.5 * mp * mp * mp) : 0.0;
+    rec[m * kRec + 6] = mC;
+  }
+  const double Csum = group_sum<G>(mC);
+  wave_lds_fence();
+  // -- phase C: forces on the slots (pair_rebomos.cpp:634-725)
+  double fx = 0, fy = 0, fz = 0, acc1 = 0;
+  for (int qi = 0; qi < nw; qi++) {
+    if (act && qi < n && qi != m) {
+      const double *q = rec + qi * kRec;
+      const double qrinv = q[8];
+      double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * qrinv;
+      cs = fmin(cs, 1.0);
+      cs = fmax(cs, -1.0);
+      const double *e = mat + 2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m);
+      const double g = e[0], dg = e[1];
+      // (C_m w_q + C_q w_m) G'(cos) d cos / d x_m ; d cos/d x_m = -(u_q - cos u_m)/r_m ; force = -gradient
+      const double coef = (mC * q[4] + q[6] * mw) * dg * mri;
+      fx += coef * (q[0] * qrinv - cs * ux);
+      fy += coef * (q[1] * qrinv - cs * uy);
+      fz += coef * (q[2] * qrinv - cs * uz);
+      acc1 += q[6] * g;
+    }
+  }
+  if (act)
+    finish_slot(P, tc, je[m], off, dp, owned, eflag, mx, my, mz, mr, mw, mdw, mp, mri, mVA, fx, fy, fz, acc1, Csum,
+                fnbr, eslot, o);
+  centre_tally(o, acc, eflag, vflag);
+}
+
+// ---- general centre kernel: 32 lanes per centre, up to 64 neighbours, no pair matrix ------------------
+// Works through the overflow list of the fast kernels (normally empty).
+__global__ __launch_bounds__(256) void rebo_centre_general_kernel(
+    const RebomosDev P, const int *__restrict__ ovf, const int nlocal, const double4 *__restrict__ xq,
+    const int *__restrict__ cand_off, const int *__restrict__ cand, unsigned long long *__restrict__ amask,
+    double *__restrict__ fnbr, double *__restrict__ eslot, double *__restrict__ acc, int *__restrict__ flags,
+    const int eflag, const int vflag)
+{
+  constexpr int G = 32, CAP = 64, STRIDE = CAP * kRec + 2;
+  __shared__ double s_rec[8 * STRIDE];
+  __shared__ int s_je[8 * CAP];
+  const int ncent = ovf[0];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int s = lane % G;
+  const int glane0 = lane - s;
+  const int grp_in_block = tid / G;
+  double *rec = s_rec + (size_t) grp_in_block * STRIDE;
+  int *je = s_je + grp_in_block * CAP;
+  CentreOut o = {0, 0, 0, 0, 0, 0, 0};
+  // wave-uniform trip count: both groups of a wave iterate together
+  for (long long g0 = (long long) blockIdx.x * 8; g0 < ncent; g0 += (long long) gridDim.x * 8) {
+    const long long gid = g0 + grp_in_block;
+    const bool have = gid < ncent;
+    int c = 0, off = 0, nc = 0, tc = 0;
+    double4 xc = make_double4(0, 0, 0, 0);
+    if (have) {
+      c = ovf[1 + gid];
+      off = cand_off[c];
+      nc = cand_off[c + 1] - off;
+      xc = xq[c];
+      tc = (int) xc.w;
+    }
+    int n = 0;
+    double nsum = 0.0;
+    unsigned long long active = 0ull;
+    const int ncw = wave_max_int(nc);
+    for (int base = 0; base < ncw; base += G) {
+      const int t = base + s;
+      const int j = t < nc ? cand[off + t] : c;
+      const double4 xj = xq[j];
+      centre_take<G, CAP>(P, tc, xc, t < nc, t, xj, s, glane0, base, rec, je, n, active, nsum);
+    }
+    if (n > CAP) {
+      if (s == 0) atomicOr(&flags[0], 1);
+      n = CAP;
+    }
+    if (have && s == 0) amask[c] = active;
+    const double Ntot = group_sum<G>(nsum);
+    wave_lds_fence();
+    double cb[7], cg[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      cb[k] = P.b[tc][k];
+      cg[k] = P.bg[tc][k];
+    }
+    const double ea = exp(-P.a[tc][2] * Ntot);
+    const double dp = -P.a[tc][0] + P.a[tc][1] * P.a[tc][2] * ea;
+    const double PS = -P.a[tc][0] * (Ntot - 1.0) - P.a[tc][1] * ea + P.a[tc][3];
+    const int nw = wave_max_int(n);
+    const bool owned = have && c < nlocal;
+    double csum_part = 0.0;
+    for (int mb = 0; mb < nw; mb += G) {
+      const int m = mb + s;
+      const bool act = m < n;
+      double mx = 0, my = 0, mz = 0, mr = 1, mw = 0, mri = 1;
+      if (act) {
+        const double *q = rec + m * kRec;
+        mx = q[0];
+        my = q[1];
+        mz = q[2];
+        mr = q[3];
+        mw = q[4];
+        mri = q[8];
+      }
+      const double ux = mx * mri, uy = my * mri, uz = mz * mri;
+      double S = 0.0;
+      for (int qi = 0; qi < nw; qi++) {
+        if (act && qi < n && qi != m) {
+          const double *q = rec + qi * kRec;
+          double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * q[8];
+          cs = fmin(cs, 1.0);
+          cs = fmax(cs, -1.0);
+          S += q[4] * gspline_val(cb, cg, cs);
+        }
+      }
+      if (act) {
+        const int pt = tc * 2 + (((unsigned) je[m]) >> 30);
+        const double p = 1.0 / sqrt(1.0 + S + PS);
+        const double VA = -mw * P.B[pt] * exp(-P.beta[pt] * mr);
+        const double Cm = (mw > kTol) ? 0.5 * VA * (-0.5 * p * p * p) : 0.0;
+        double *q = rec + m * kRec;
+        q[6] = Cm;
+        q[7] = p;
+        q[9] = VA;
+        csum_part += Cm;
+      }
+    }
+    const double Csum = group_sum<G>(csum_part);
+    wave_lds_fence();
+    for (int mb = 0; mb < nw; mb += G) {
+      const int m = mb + s;
+      const bool act = m < n;
+      double mx = 0, my = 0, mz = 0, mr = 1, mw = 0, mdw = 0, mC = 0, mp = 0, mri = 1, mVA = 0;
+      if (act) {
+        const double *q = rec + m * kRec;
+        mx = q[0];
+        my = q[1];
+        mz = q[2];
+        mr = q[3];
+        mw = q[4];
+        mdw = q[5];
+        mC = q[6];
+        mp = q[7];
+        mri = q[8];
+        mVA = q[9];
+      }
+      const double ux = mx * mri, uy = my * mri, uz = mz * mri;
+      double fx = 0, fy = 0, fz = 0, acc1 = 0;
+      for (int qi = 0; qi < nw; qi++) {
+        if (act && qi < n && qi != m) {
+          const double *q = rec + qi * kRec;
+          const double qrinv = q[8];
+          double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * qrinv;
+          cs = fmin(cs, 1.0);
+          cs = fmax(cs, -1.0);
+          double dg;
+          const double g = gspline(cb, cg, cs, dg);
+          const double coef = (mC * q[4] + q[6] * mw) * dg * mri;
+          fx += coef * (q[0] * qrinv - cs * ux);
+          fy += coef * (q[1] * qrinv - cs * uy);
+          fz += coef * (q[2] * qrinv - cs * uz);
+          acc1 += q[6] * g;
+        }
+      }
+      if (act)
+        finish_slot(P, tc, je[m], off, dp, owned, eflag, mx, my, mz, mr, mw, mdw, mp, mri, mVA, fx, fy, fz, acc1,
+                    Csum, fnbr, eslot, o);
+    }
+    wave_lds_fence();
+  }
+  centre_tally(o, acc, eflag, vflag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -818,7 +1009,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
   const int ncand = cand_off[i + 1] - cand_off[i];
   if (ncand == 0) return;
   // smallest lane group that holds the current coordination with one slot to spare
-  const int k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 15) ? 2 : 3;
+  const int k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 14) ? 2 : 3;
   const int pos = atomicAdd(&class_count[k], 1);
   class_list[(size_t) k * nall + pos] = i;
 }
@@ -924,6 +1115,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->lj_off.reserve(nclus + 2));
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
+  MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
   MDP_HIP(c, c->class_list.reserve((size_t) 4 * nall + 4));
   MDP_HIP(c, c->class_count.reserve(4));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
@@ -999,7 +1191,7 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
   const int grid = (n + per_block - 1) / per_block;
   rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
                                                      c->xq.p, c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
-                                                     c->eslot.p, c->acc.p, c->flags.p, eflag, vflag);
+                                                     c->eslot.p, c->acc.p, c->ovf.p, eflag, vflag);
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
@@ -1009,11 +1201,22 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
   if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "rebomos: per-atom virial is not implemented on the device");
   hipStream_t st = c->stream;
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
+  MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));
   mdp_time_mark(c, 0);
   launch_centre<4>(c, 0, eflag, vflag);
   launch_centre<8>(c, 1, eflag, vflag);
   launch_centre<16>(c, 2, eflag, vflag);
   launch_centre<32>(c, 3, eflag, vflag);
+  {
+    // centres that outgrew their lane group since the last build (normally none: the kernel reads the
+    // count from the device and exits)
+    const int total = c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
+    const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
+    if (grid)
+      rebo_centre_general_kernel<<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, c->nlocal, c->xq.p, c->cand_off.p,
+                                                       c->cand.p, c->amask.p, c->fnbr.p, c->eslot.p, c->acc.p,
+                                                       c->flags.p, eflag, vflag);
+  }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 1);
   constexpr int L = 16;

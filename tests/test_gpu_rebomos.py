@@ -129,3 +129,29 @@ def test_replicated_cell_and_nve_thermo_table(ctx, oracle, P):
         assert got["pe"] == pytest.approx(ref["pe"], abs=5.1e-5)
         assert got["ke"] == pytest.approx(ref["ke"], abs=5.1e-8)
         assert got["press"] == pytest.approx(ref["press"], abs=5.1e-3)
+
+
+def test_centres_that_outgrow_their_lane_group_between_list_builds(ctx, oracle, P):
+    """lists and lane-group classes are made on an expanded cell (S atoms: 3 REBO neighbours -> 4-lane
+    groups); the same list then serves a uniformly compressed cell where S atoms have ~10 neighbours,
+    which sends them through the overflow list to the general centre kernel"""
+    skin = 3.0
+    s_lo = S.jitter(S.scale(S.rebomos_bulk_cell(), 1.04), 0.03, seed=17)
+    eng = mdref.RebomosCPU(oracle, P, s_lo, skin=skin)
+    xa = eng.all_positions(s_lo.x)
+    ctx.set_atoms_host(eng.nlocal, xa, eng.type_all, eng.tag_all, 2, map_=[0, 0, 1])
+    ctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, skin)
+    g_lo = ctx.rebomos_compute_host(eng.nlocal)
+    o_lo = eng.compute(s_lo.x)
+    assert np.abs(g_lo["f"] - o_lo["f_owned"]).max() < F_TOL
+    assert int(o_lo["rebo_numneigh"][:eng.nlocal][s_lo.type == 2].max()) <= 3
+    f = 0.93 / 1.04
+    ctx.set_positions_host(xa * f)                     # pure scaling: every pair distance shrinks by f
+    g_hi = ctx.rebomos_compute_host(eng.nlocal)
+    s_hi = S.scale(s_lo, f)
+    eng_hi = mdref.RebomosCPU(oracle, P, s_hi)
+    o_hi = eng_hi.compute(s_hi.x)
+    assert int(o_hi["rebo_numneigh"][:eng.nlocal][s_hi.type == 2].min()) > 4
+    assert np.abs(g_hi["f"] - o_hi["f_owned"]).max() < 1e-8
+    assert g_hi["eng"] == pytest.approx(o_hi["eng"], rel=1e-10)
+    assert np.abs(g_hi["eatom"] - o_hi["eatom_owned"]).max() < 1e-8
