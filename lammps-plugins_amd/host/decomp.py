@@ -99,9 +99,12 @@ class Decomposition:
 class Halo:
     """per-step exchanges on top of a RankPlan; buffers are torch tensors on `device`"""
 
-    def __init__(self, plan: RankPlan, device, dist_module):
+    def __init__(self, plan: RankPlan, device, dist_module, stage_host: bool = False):
+        """stage_host: move the buffers through host memory around each collective (lets a `gloo` group
+        drive GPU-resident domains -- used by the 2-process single-GPU test; RCCL runs use device buffers)"""
         import torch
         self.torch, self.dist, self.plan = torch, dist_module, plan
+        self.stage_host = stage_host
         self.nsend = int(plan.send_counts.sum())
         self.nrecv = int(plan.recv_counts.sum())
         f64 = dict(dtype=torch.float64, device=device)
@@ -116,13 +119,23 @@ class Halo:
         self.in1 = [int(c) for c in plan.send_counts]
         self.out1 = [int(c) for c in plan.recv_counts]
 
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if not self.stage_host:
+            self.dist.all_to_all_single(out, inp, out_splits, in_splits)
+            return
+        self.torch.cuda.synchronize()
+        o, i = out.cpu(), inp.cpu()
+        self.dist.all_to_all_single(o, i, out_splits, in_splits)
+        out.copy_(o)
+        self.torch.cuda.synchronize()
+
     def forward3(self):
         """send3 (packed owned positions+shift) -> recv3 (remote ghosts)"""
-        self.dist.all_to_all_single(self.recv3[:self.nrecv * 3], self.send3[:self.nsend * 3], self.out3, self.in3)
+        self._a2a(self.recv3[:self.nrecv * 3], self.send3[:self.nsend * 3], self.out3, self.in3)
 
     def forward1(self):
-        self.dist.all_to_all_single(self.recv1[:self.nrecv], self.send1[:self.nsend], self.out1, self.in1)
+        self._a2a(self.recv1[:self.nrecv], self.send1[:self.nsend], self.out1, self.in1)
 
     def reverse3(self):
         """recv3 (ghost forces, ghost order) -> send3 (contributions for my owned atoms, sendlist order)"""
-        self.dist.all_to_all_single(self.send3[:self.nsend * 3], self.recv3[:self.nrecv * 3], self.in3, self.out3)
+        self._a2a(self.send3[:self.nsend * 3], self.recv3[:self.nrecv * 3], self.in3, self.out3)

@@ -189,13 +189,15 @@ def gather_state(dom: Domain, s: S.System, dist=None, device=None):
         return x, v
     import torch
     world = dist.get_world_size()
-    nmax = torch.tensor([dom.nlocal], dtype=torch.int64, device=device)
+    nmax = torch.tensor([dom.nlocal], dtype=torch.int64, device="cpu" if getattr(dom, "stage_host", False) else device)
     dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
     nmax = int(nmax.item())
     mine = torch.zeros((nmax, 7), dtype=torch.float64, device=device)
     mine[:dom.nlocal, 0] = torch.as_tensor(tags.astype(np.float64), device=device)
     mine[:dom.nlocal, 1:4] = torch.as_tensor(got["x"], device=device)
     mine[:dom.nlocal, 4:7] = torch.as_tensor(got["v"], device=device)
+    if getattr(dom, "stage_host", False):
+        mine = mine.cpu()
     parts = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     for p in parts:
@@ -207,7 +209,8 @@ def gather_state(dom: Domain, s: S.System, dist=None, device=None):
     return x, v
 
 
-def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001, dist=None, device=None):
+def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001, dist=None, device=None,
+                stage_host=False):
     """(re)build the resident sub-domain of this rank from a global system"""
     if dist is None:
         d = Domain.single(ctx, style, s, cutghost, skin, map_, v0=v0, dt=dt)
@@ -220,14 +223,16 @@ def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001
     plan = dec.plan(dist.get_rank())
     d = RankDomain.from_plan(ctx, style, s, xw, plan, skin, map_, v0=v0, dt=dt)
     d.tags_local = s.tag[plan.owned]
-    d.attach_halo(decomp.Halo(plan, device, dist))
+    d.attach_halo(decomp.Halo(plan, device, dist, stage_host=stage_host))
+    d.stage_host = stage_host
     return d
 
 
 def reneighbor(dom: Domain, s: S.System, cutghost, map_, dist=None, device=None) -> Domain:
     x, v = gather_state(dom, s, dist, device)
     s2 = S.System(s.box, x, s.type, s.tag, s.mass)
-    d = make_domain(dom.ctx, dom.style, s2, cutghost, dom.skin, map_, v0=v, dt=dom.dt, dist=dist, device=device)
+    d = make_domain(dom.ctx, dom.style, s2, cutghost, dom.skin, map_, v0=v, dt=dom.dt, dist=dist, device=device,
+                    stage_host=getattr(dom, "stage_host", False))
     d.builds = dom.builds
     d.build_neighbors()
     return d

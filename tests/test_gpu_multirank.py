@@ -1,0 +1,124 @@
+"""GPU, N>1 path: two processes share cuda:0, each owns one brick of the box (RankDomain), ghost
+positions travel through pack_x_kernel -> all_to_all -> unpack_x_kernel every step.  The transport
+here is gloo staged through the host (one GPU cannot host two RCCL ranks); everything else -- plan,
+device pack/unpack, owner-computes forces, AEAM's fp forward and force reverse exchanges, thermo
+reduction -- is the code bench.py runs with RCCL.  Checked against the single-domain GPU run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import POT_AEAM, POT_REBOMOS
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(style):
+    from lammps_plugins_amd.host import capi, system as S
+    if style == "rebomos":
+        s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (2, 1, 1)), 0.05, seed=3)
+        v0 = S.gaussian_velocities(s, 300.0, seed=5)
+        return s, v0
+    s = S.jitter(S.fcc_cell(4.045, (8, 6, 6), frac_type2=0.03, seed=12), 0.03, seed=13)
+    af = capi.AeamFile(POT_AEAM)
+    s.mass[1:3] = af.mass
+    return s, S.gaussian_velocities(s, 500.0, seed=7)
+
+
+def _setup_ctx(style):
+    from lammps_plugins_amd.host import capi
+    ctx = capi.Context(0)
+    keep = None
+    if style == "rebomos":
+        p = capi.read_rebomos_file(POT_REBOMOS)
+        ctx.rebomos_set_params(p)
+        return ctx, capi.STYLE_REBOMOS, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1], keep
+    af = capi.AeamFile(POT_AEAM)
+    tabs = af.build()
+    ctx.aeam_set_tables(tabs)
+    return ctx, capi.STYLE_AEAM, float(af.cut_table(tabs).max()) + 1.0, 1.0, None, (af, tabs)
+
+
+def _run(dom, nsteps, dist_mod=None):
+    dom.build_neighbors()
+    dom.compute(eflag=1, vflag=1)
+    rows = [dom.ctx.md_thermo()]
+    for k in range(nsteps):
+        dom.step(0, 0)
+    dom.compute(eflag=1, vflag=1)
+    rows.append(dom.ctx.md_thermo())
+    return rows
+
+
+def _worker(rank, world, port, style, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import conftest  # noqa: F401
+    from lammps_plugins_amd.host import resident
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        s, v0 = _build(style)
+        ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
+        dom = resident.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0, dist=dist,
+                                   device=torch.device("cuda", 0), stage_host=True)
+        rows = _run(dom, 25)
+        tot = []
+        for r in rows:
+            t = torch.tensor([r["ke"], r["pe"]] + list(r["virial"]), dtype=torch.float64)
+            dist.all_reduce(t)
+            tot.append(t.numpy())
+        got = ctx.md_download(dom.nlocal, want=("x", "f"))
+        q.put((rank, dom.tags_local, got["x"], got["f"], tot, dom.nlocal, dom.nghost))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_two_ranks_on_one_gpu_match_single_domain(style):
+    from lammps_plugins_amd.host import resident
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, style, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-domain reference on the same GPU
+    s, v0 = _build(style)
+    ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
+    dom = resident.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0)
+    rows = _run(dom, 25)
+    got = ctx.md_download(dom.nlocal, want=("x", "f"))
+    x1 = np.zeros((s.n, 3)); f1 = np.zeros((s.n, 3))
+    x1[dom.tags_local - 1] = got["x"]; f1[dom.tags_local - 1] = got["f"]
+    x2 = np.zeros((s.n, 3)); f2 = np.zeros((s.n, 3))
+    assert sum(r[5] for r in res) == s.n
+    for rank, tags, x, f, tot, nloc, ngh in res:
+        x2[tags - 1] = x
+        f2[tags - 1] = f
+    tot = res[0][4]
+    for k in range(2):
+        assert tot[k][1] == pytest.approx(rows[k]["pe"], rel=1e-11)            # PE
+        assert tot[k][0] == pytest.approx(rows[k]["ke"], rel=1e-9, abs=1e-12)  # KE
+        assert np.allclose(tot[k][2:], rows[k]["virial"], rtol=1e-8, atol=1e-6)
+    assert np.abs(x2 - x1).max() < 1e-9     # 25 steps of identical dynamics
+    assert np.abs(f2 - f1).max() < 1e-7
+    ctx.close()
