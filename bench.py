@@ -93,10 +93,15 @@ def main():
     ap.add_argument("--temp", type=float, default=0.0, help="initial temperature (in.rebomos-bulk: 0 K)")
     ap.add_argument("--check-every", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inner-skin", type=float, default=None,
+                    help="skin of the style's own device-built lists in A (default: library default 1.0, capped by "
+                         "the host skin); they are rebuilt on the device when an atom has moved half of it")
     args = ap.parse_args()
     if args.replicate is None:
         args.replicate = [24, 24, 24] if args.workload == "rebomos" else [63, 63, 63]
 
+    if args.inner_skin is not None:
+        os.environ["MDP_INNER_SKIN"] = str(args.inner_skin)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,10 +181,12 @@ def main():
 
     run(args.warmup, 0)
     sync_all()
+    style_builds0 = ctx.md_neighbor_stats()[7]
     t0 = time.perf_counter()
     rebuilds = run(args.steps, args.warmup)
     sync_all()
     elapsed = time.perf_counter() - t0
+    style_builds = ctx.md_neighbor_stats()[7] - style_builds0 if args.workload == "rebomos" else 0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -234,6 +241,8 @@ def main():
         "ns_per_day": round(args.steps / elapsed * 0.001 * 86.4, 4),
         "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}",
                    "initial_temp_K": args.temp, "skin": skin, "neighbor_rebuilds_in_timed_region": rebuilds,
+                   "inner_skin": float(os.environ.get("MDP_INNER_SKIN", "1.0")) if args.workload == "rebomos" else None,
+                   "style_list_builds_in_timed_region_rank0": int(style_builds),
                    "pe_per_atom_start_eV": round(pe0 / s.n, 6)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel": knames[kdom],

@@ -120,7 +120,13 @@ int mdp_set_positions_host(mdp_ctx *ctx, const double *x); /* per step, same nlo
  * the device repacks it (trimmed, coalesced) once per call. */
 int mdp_set_neighbors_host(mdp_ctx *ctx, int inum, int gnum, const int *ilist, const int *numneigh,
                            int *const *firstneigh, double skin);
-/* same, from a CSR copy (tests / hosts that already hold a flat list): offset[nall+1] */
+/* replaces the read of neighbor->skin alone.  The REBO-MoS device path derives its own trimmed lists
+ * (REBO candidates, Lennard-Jones cluster pair lists) from the positions, as LAMMPS' own GPU/KOKKOS
+ * packages do with `neigh yes`; the host's list is requested for API parity and for the ghost shell it
+ * implies but its entries are not read, so a rebomos host only reports the skin (at every reneighboring,
+ * after mdp_set_atoms_host).  neigh_modify exclusions are therefore not honoured. */
+int mdp_set_skin(mdp_ctx *ctx, double skin);
+/* same as mdp_set_neighbors_host, from a CSR copy (tests / hosts that already hold a flat list): offset[nall+1] */
 int mdp_set_neighbors_csr_host(mdp_ctx *ctx, int nall, const int *numneigh, const long long *offset,
                                const int *neigh, double skin);
 
@@ -153,6 +159,9 @@ typedef struct {
   double dt;
   double ftm2v, mvv2e;   /* unit constants (metal: SURVEY.md Appendix B)               */
   double bbox_lo[3], bbox_hi[3]; /* Cartesian bounds of owned+ghost atoms, for binning  */
+  int master_list;    /* rebomos only: 1 = also build the LAMMPS-style full list at 3*rcmax+skin
+                         (log.rebomos-bulk.1:43, for its statistics); the kernels never need it.
+                         aeam always builds its (86-entry) list: the kernels stream it.          */
 } mdp_md_config;
 
 /* upload a sub-domain.  x/v/type/tag: owned atoms [nlocal]; ghosts: ghost_owner[g] = local index
@@ -187,8 +196,10 @@ int mdp_md_download(mdp_ctx *ctx, double *x, double *v, double *f, double *eatom
 int mdp_md_upload_x(mdp_ctx *ctx, const double *x);                             /* owned atoms [nlocal][3] */
 /* device pointers of resident arrays for zero-copy plumbing (name: "x","v","f","fp","eatom") */
 void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
-/* statistics of the last neighbor build: out[0]=total master entries (owned), [1]=ghost-list entries,
- * [2]=trimmed LJ entries (rebomos) , [3]=REBO candidate entries, [4]=#centres */
+/* statistics of the last neighbor build: out[0]=total master entries (owned; 0 if not built),
+ * [1]=ghost-list entries, [2]=LJ cluster-list entries (rebomos), [3]=REBO candidate entries, [4]=#centres,
+ * [5]=#centres in 4-lane groups, [6]=#centres in 16-lane groups, [7]=style-list builds so far (rebomos) /
+ * #angular atoms (aeam) */
 int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):

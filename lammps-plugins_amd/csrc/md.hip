@@ -455,10 +455,19 @@ int mdp_md_build_neighbors(mdp_ctx *c)
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   MDP_HIP(c, hipSetDevice(c->device));
-  MDP_TRY(mdp_md_build_master_list(c));
+  if (c->cfg.style == 2 || c->cfg.master_list) {
+    MDP_TRY(mdp_md_build_master_list(c));
+  } else {
+    c->nb_total = c->nb_owned_total = 0;
+    c->skin = c->cfg.skin;
+    c->neigh_set = true; // rebomos builds its own lists from the bin grid
+  }
   hold_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, c->xq.p, c->xhold.p);
   MDP_HIP(c, hipGetLastError());
-  if (c->cfg.style == 1) return mdp_rebomos_repack(c);
+  if (c->cfg.style == 1) {
+    c->rebo_packed = false;
+    return mdp_rebomos_repack(c);
+  }
   return mdp_aeam_prepare(c);
 }
 
@@ -601,7 +610,7 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
   out[4] = (long long) c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
   out[5] = c->h_class_count[0];
   out[6] = c->h_class_count[2];
-  out[7] = c->h_ang_count;
+  out[7] = c->cfg.style == 1 ? c->style_builds : c->h_ang_count;
   return MDP_OK;
 }
 

@@ -189,6 +189,7 @@ int mdp_destroy(mdp_ctx *c)
   c->class_list.release();
   c->class_count.release();
   c->amask.release();
+  c->xhold_all.release();
   c->ovf.release();
   c->rev.release();
   c->fnbr.release();
@@ -384,6 +385,14 @@ int mdp_set_neighbors_host(mdp_ctx *c, int inum, int gnum, const int *ilist, con
   return upload_csr(c, skin);
 }
 
+int mdp_set_skin(mdp_ctx *c, double skin)
+{
+  if (!c || !(skin >= 0.0)) return MDP_EINVAL;
+  c->skin = skin;
+  c->rebo_packed = false;
+  return MDP_OK;
+}
+
 int mdp_set_neighbors_csr_host(mdp_ctx *c, int nall, const int *numneigh, const long long *offset, const int *neigh,
                                double skin)
 {
@@ -429,9 +438,8 @@ int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double
 {
   if (!c || !f) return MDP_EINVAL;
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
-  if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
+  if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
   MDP_HIP(c, hipSetDevice(c->device));
-  if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   MDP_TRY(mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true));
   hipStream_t st = c->stream;

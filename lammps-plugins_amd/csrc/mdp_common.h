@@ -137,6 +137,9 @@ struct mdp_ctx {
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
+  DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
+  double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
+  long long style_builds = 0;     // number of style-list builds so far
   DevBuf<double> fnbr;            // [cand_total][3]
   DevBuf<double> eslot;           // [cand_total]
   DevBuf<char> scan_tmp;

@@ -823,7 +823,8 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
 
 // cluster pair list straight from the bin grid: every atom j within rcLJmax+skin of ANY atom of the
 // cluster, Mo neighbours first, then S (so the LJ parameters are loop invariants of each segment).
-// One thread per cluster; consecutive clusters are spatial neighbours, so a wave shares its stencil.
+// 16 lanes per cluster sweep the stencil cells (each x-run of cells is contiguous in the sorted order),
+// ballot-compacting the hits; consecutive clusters are spatial neighbours and share their stencil in cache.
 template <int CL, bool FILL>
 __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, const RebomosDev P, const int nclus,
                                                             const int nlocal, const double4 *__restrict__ xq,
@@ -832,8 +833,13 @@ __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, con
                                                             int *__restrict__ split, const long long *__restrict__ off,
                                                             int *__restrict__ out)
 {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nclus) return;
+  constexpr int L = 16;
+  const int lane = threadIdx.x & 63;
+  const int s = lane % L;
+  const int glane0 = lane - s;
+  const long long k64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = k64 < nclus;
+  const int k = have ? (int) k64 : 0;
   double4 xa[CL];
   int ta[CL];
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
@@ -854,36 +860,63 @@ __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, con
     }
   }
   const int R = g.range;
-  int n0 = 0, n1 = 0;
-  int *row0 = FILL ? out + off[k] : nullptr;
-  int *row1 = FILL ? row0 + split[k] : nullptr;
-  for (int z = max(lo[2] - R, 0); z <= min(hi[2] + R, g.n[2] - 1); z++)
-    for (int y = max(lo[1] - R, 0); y <= min(hi[1] + R, g.n[1] - 1); y++) {
-      const int c0 = max(lo[0] - R, 0) + g.n[0] * (y + g.n[1] * z);
-      const int c1 = min(hi[0] + R, g.n[0] - 1) + g.n[0] * (y + g.n[1] * z);
-      const int pb = cell_start[c0], pe = cell_start[c1 + 1];
-      for (int p = pb; p < pe; p++) {
-        const int j = perm[p];
-        const double4 xj = xq[j];
-        const int tj = (int) xj.w;
-        bool keep = false;
+  // wave-uniform stencil bounds (the 4 clusters of a wave may differ by a cell): loop the union
+  int zlo = max(lo[2] - R, 0), zhi = min(hi[2] + R, g.n[2] - 1);
+  int ylo = max(lo[1] - R, 0), yhi = min(hi[1] + R, g.n[1] - 1);
+  const int xlo = max(lo[0] - R, 0), xhi = min(hi[0] + R, g.n[0] - 1);
+  if (!have) {
+    zlo = ylo = 1 << 30;
+    zhi = yhi = -1;
+  }
+  int wzlo = zlo, wzhi = zhi, wylo = ylo, wyhi = yhi;
 #pragma unroll
-        for (int c = 0; c < CL; c++) {
-          const double dx = xa[c].x - xj.x, dy = xa[c].y - xj.y, dz = xa[c].z - xj.z;
-          keep = keep || (dx * dx + dy * dy + dz * dz <= P.ljlist_cutsq[ta[c] * 2 + tj]);
-        }
-        if (keep) {
-          if (tj == 0) {
-            if (FILL) row0[n0] = j;
-            n0++;
-          } else {
-            if (FILL) row1[n1] = j;
-            n1++;
+  for (int o = 32; o >= L; o >>= 1) {
+    wzlo = min(wzlo, __shfl_xor(wzlo, o, 64));
+    wzhi = max(wzhi, __shfl_xor(wzhi, o, 64));
+    wylo = min(wylo, __shfl_xor(wylo, o, 64));
+    wyhi = max(wyhi, __shfl_xor(wyhi, o, 64));
+  }
+  int n0 = 0, n1 = 0;
+  int *row0 = (FILL && have) ? out + off[k] : nullptr;
+  int *row1 = (FILL && have) ? row0 + split[k] : nullptr;
+  const unsigned long long below = (1ull << s) - 1ull;
+  for (int z = wzlo; z <= wzhi; z++)
+    for (int y = wylo; y <= wyhi; y++) {
+      const bool rowin = have && z >= zlo && z <= zhi && y >= ylo && y <= yhi;
+      int pb = 0, pe = 0;
+      if (rowin) {
+        pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
+        pe = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1];
+      }
+      const int lenw = wave_max_int(pe - pb);
+      for (int base = 0; base < lenw; base += L) {
+        const int p = pb + base + s;
+        bool k0 = false, k1 = false;
+        int j = 0;
+        if (p < pe) {
+          j = perm[p];
+          const double4 xj = xq[j];
+          const int tj = (int) xj.w;
+          bool keep = false;
+#pragma unroll
+          for (int c = 0; c < CL; c++) {
+            const double dx = xa[c].x - xj.x, dy = xa[c].y - xj.y, dz = xa[c].z - xj.z;
+            keep = keep || (dx * dx + dy * dy + dz * dz <= P.ljlist_cutsq[ta[c] * 2 + tj]);
           }
+          k0 = keep && tj == 0;
+          k1 = keep && tj != 0;
         }
+        const unsigned long long b0 = (__ballot(k0) >> glane0) & 0xFFFFull;
+        const unsigned long long b1 = (__ballot(k1) >> glane0) & 0xFFFFull;
+        if (FILL) {
+          if (k0) row0[n0 + __popcll(b0 & below)] = j;
+          if (k1) row1[n1 + __popcll(b1 & below)] = j;
+        }
+        n0 += __popcll(b0);
+        n1 += __popcll(b1);
       }
     }
-  if (!FILL) {
+  if (!FILL && have && s == 0) {
     cnt[k] = n0 + n1;
     split[k] = n0;
   }
@@ -892,77 +925,105 @@ __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, con
 // ------------------------------------------------------------------------------------------------
 // repack at every neighbor (re)build: master CSR list -> REBO candidates + trimmed LJ list
 // ------------------------------------------------------------------------------------------------
-constexpr int RP_L = 16; // lanes per atom in the repack kernels
+constexpr int RP_L = 16; // lanes per atom in the list-building kernels
 
-// counts per atom: cand_cnt[i] (all atoms)
-__global__ __launch_bounds__(256) void repack_count_kernel(const RebomosDev P, const int nall, const int nlocal,
-                                                           const double4 *__restrict__ xq,
-                                                           const long long *__restrict__ nb_off,
-                                                           const int *__restrict__ nb, int *__restrict__ cand_cnt)
-{
-  const int s = threadIdx.x % RP_L;
-  const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
-  const bool have = i64 < nall;
-  const int i = have ? (int) i64 : 0;
-  int nc = 0;
-  if (have) {
-    const double4 xi = xq[i];
-    const int ti = (int) xi.w;
-    const long long b = nb_off[i], e = nb_off[i + 1];
-    for (long long k = b + s; k < e; k += RP_L) {
-      const int j = nb[k];
-      const double4 xj = xq[j];
-      const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      nc += rsq <= P.cand_cutsq[ti * 2 + (int) xj.w];
-    }
-  }
-#pragma unroll
-  for (int o = RP_L / 2; o > 0; o >>= 1) nc += __shfl_xor(nc, o, 64);
-  if (have && s == 0) cand_cnt[i] = nc;
-  (void) nlocal;
-}
-
-__global__ __launch_bounds__(256) void repack_fill_kernel(const RebomosDev P, const int nall, const int nlocal,
-                                                          const double4 *__restrict__ xq,
-                                                          const long long *__restrict__ nb_off,
-                                                          const int *__restrict__ nb, const int *__restrict__ cand_off,
-                                                          int *__restrict__ cand, int *__restrict__ is_centre)
+// REBO candidate lists (r <= rcmax + inner skin) straight from the bin grid.
+// MODE 0: count for owned atoms and mark the ghost atoms that neighbour them (they are centres too)
+// MODE 1: count for the marked ghosts            MODE 2: fill (all atoms with a non-empty row)
+template <int MODE>
+__global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const int R, const RebomosDev P,
+                                                         const int nall, const int nlocal,
+                                                         const double4 *__restrict__ xq, const int *__restrict__ perm,
+                                                         const int *__restrict__ cell_start, int *__restrict__ cnt,
+                                                         const int *__restrict__ off, int *__restrict__ cand,
+                                                         int *__restrict__ is_centre)
 {
   const int lane = threadIdx.x & 63;
   const int s = lane % RP_L;
   const int glane0 = lane - s;
-  const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
-  const bool have = i64 < nall;
+  const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L + (MODE == 1 ? nlocal : 0);
+  const int ihi = MODE == 0 ? nlocal : nall;
+  bool have = i64 < ihi;
   const int i = have ? (int) i64 : 0;
+  if (MODE == 1 && have && !is_centre[i]) have = false; // ghosts far from every owned atom need no row
+  if (MODE == 2 && have && off[i + 1] == off[i]) have = false;
   const double4 xi = xq[i];
   const int ti = (int) xi.w;
-  const long long b = have ? nb_off[i] : 0, e = have ? nb_off[i + 1] : 0;
-  const int len = (int) (e - b);
-  const int lenw = wave_max_int(len);
-  const bool own = have && i < nlocal;
-  int nc = 0;
-  const int coff = have ? cand_off[i] : 0;
-  for (int base = 0; base < lenw; base += RP_L) {
-    const int k = base + s;
-    bool pc = false;
-    int j = 0;
-    if (k < len) {
-      j = nb[b + k];
-      const double4 xj = xq[j];
-      const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      pc = rsq <= P.cand_cutsq[ti * 2 + (int) xj.w];
-    }
-    const unsigned long long bc = (__ballot(pc) >> glane0) & ((1ull << RP_L) - 1ull);
-    const unsigned long long below = (1ull << s) - 1ull;
-    if (pc) {
-      cand[coff + nc + __popcll(bc & below)] = j;
-      if (own && j >= nlocal) is_centre[j] = 1; // ghost neighbours of owned atoms are centres too
-    }
-    nc += __popcll(bc);
+  int cx = (int) ((xi.x - g.lo[0]) * g.inv[0]), cy = (int) ((xi.y - g.lo[1]) * g.inv[1]),
+      cz = (int) ((xi.z - g.lo[2]) * g.inv[2]);
+  cx = cx < 0 ? 0 : (cx >= g.n[0] ? g.n[0] - 1 : cx);
+  cy = cy < 0 ? 0 : (cy >= g.n[1] ? g.n[1] - 1 : cy);
+  cz = cz < 0 ? 0 : (cz >= g.n[2] ? g.n[2] - 1 : cz);
+  int zlo = max(cz - R, 0), zhi = min(cz + R, g.n[2] - 1), ylo = max(cy - R, 0), yhi = min(cy + R, g.n[1] - 1);
+  const int xlo = max(cx - R, 0), xhi = min(cx + R, g.n[0] - 1);
+  if (!have) {
+    zlo = ylo = 1 << 30;
+    zhi = yhi = -1;
   }
-  if (own && s == 0) is_centre[i] = 1;
+  int wzlo = zlo, wzhi = zhi, wylo = ylo, wyhi = yhi;
+#pragma unroll
+  for (int o = 32; o >= RP_L; o >>= 1) {
+    wzlo = min(wzlo, __shfl_xor(wzlo, o, 64));
+    wzhi = max(wzhi, __shfl_xor(wzhi, o, 64));
+    wylo = min(wylo, __shfl_xor(wylo, o, 64));
+    wyhi = max(wyhi, __shfl_xor(wyhi, o, 64));
+  }
+  int n = 0;
+  int *row = (MODE == 2 && have) ? cand + off[i] : nullptr;
+  const unsigned long long below = (1ull << s) - 1ull;
+  for (int z = wzlo; z <= wzhi; z++)
+    for (int y = wylo; y <= wyhi; y++) {
+      const bool rowin = have && z >= zlo && z <= zhi && y >= ylo && y <= yhi;
+      int pb = 0, pe = 0;
+      if (rowin) {
+        pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
+        pe = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1];
+      }
+      const int lenw = wave_max_int(pe - pb);
+      for (int base = 0; base < lenw; base += RP_L) {
+        const int p = pb + base + s;
+        bool keep = false;
+        int j = 0;
+        if (p < pe) {
+          j = perm[p];
+          const double4 xj = xq[j];
+          const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+          keep = j != i && (dx * dx + dy * dy + dz * dz) <= P.cand_cutsq[ti * 2 + (int) xj.w];
+        }
+        const unsigned long long bk = (__ballot(keep) >> glane0) & 0xFFFFull;
+        if (keep) {
+          if (MODE == 2) row[n + __popcll(bk & below)] = j;
+          if (MODE == 0 && j >= nlocal) is_centre[j] = 1;
+        }
+        n += __popcll(bk);
+      }
+    }
+  if (MODE != 2 && have && s == 0) cnt[i] = n;
+}
+
+// positions at list-build time (all atoms, ghosts included) and the displacement trigger
+__global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, double *__restrict__ xhold)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nall) return;
+  const double4 x = xq[i];
+  xhold[3 * (size_t) i] = x.x;
+  xhold[3 * (size_t) i + 1] = x.y;
+  xhold[3 * (size_t) i + 2] = x.z;
+}
+
+__global__ __launch_bounds__(256) void moved_kernel(const int nall, const double trigsq,
+                                                    const double4 *__restrict__ xq,
+                                                    const double *__restrict__ xhold, int *__restrict__ flag)
+{
+  bool far = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nall; i += gridDim.x * 256) {
+    const double4 x = xq[i];
+    const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1],
+                 dz = x.z - xhold[3 * (size_t) i + 2];
+    far = far || (dx * dx + dy * dy + dz * dz > trigsq);
+  }
+  if (__any(far) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
@@ -989,29 +1050,38 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
   }
 }
 
-// current REBO coordination -> lane-group class, appended to the class lists
-__global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const int nall,
+// current REBO coordination -> lane-group class, appended to the class lists (one atomic per wave
+// and class: 4.8 M single-lane atomics on four counters took longer than the list build itself)
+__global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const int nall, const int nlocal,
                                                        const double4 *__restrict__ xq,
                                                        const int *__restrict__ cand_off, const int *__restrict__ cand,
                                                        const int *__restrict__ is_centre, int *__restrict__ class_list,
                                                        int *__restrict__ class_count)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nall || !is_centre[i]) return;
-  const double4 xi = xq[i];
-  const int ti = (int) xi.w;
-  int n = 0;
-  for (int k = cand_off[i]; k < cand_off[i + 1]; k++) {
-    const double4 xj = xq[cand[k]];
-    const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    n += (dx * dx + dy * dy + dz * dz) < P.rcmaxsq[ti * 2 + (int) xj.w];
+  const int lane = threadIdx.x & 63;
+  int k = -1;
+  if (i < nall && (i < nlocal || is_centre[i]) && cand_off[i + 1] > cand_off[i]) {
+    const double4 xi = xq[i];
+    const int ti = (int) xi.w;
+    int n = 0;
+    for (int q = cand_off[i]; q < cand_off[i + 1]; q++) {
+      const double4 xj = xq[cand[q]];
+      const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+      n += (dx * dx + dy * dy + dz * dz) < P.rcmaxsq[ti * 2 + (int) xj.w];
+    }
+    // smallest lane group that holds the current coordination (one lane per neighbour, some to spare)
+    k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 14) ? 2 : 3;
   }
-  const int ncand = cand_off[i + 1] - cand_off[i];
-  if (ncand == 0) return;
-  // smallest lane group that holds the current coordination with one slot to spare
-  const int k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 14) ? 2 : 3;
-  const int pos = atomicAdd(&class_count[k], 1);
-  class_list[(size_t) k * nall + pos] = i;
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const unsigned long long m = __ballot(k == kk);
+    if (m == 0ull) continue;
+    int base = 0;
+    if (lane == __ffsll((long long) m) - 1) base = atomicAdd(&class_count[kk], __popcll(m));
+    base = __shfl(base, __ffsll((long long) m) - 1, 64);
+    if (k == kk) class_list[(size_t) kk * nall + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
 }
 
 __global__ void zero_small_kernel(double *acc, int n)
@@ -1095,11 +1165,24 @@ void mdp_rebomos_fill_dev(mdp_ctx *c, double skin)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The style's own neighbor structures, built on the device from the positions at hand:
+//   * REBO candidate lists (r <= rcmax + s_in) for owned atoms and the ghosts next to them,
+//     reverse-slot table, lane-group classes
+//   * Lennard-Jones cluster pair lists (r <= rcLJmax + s_in)
+// s_in ("inner skin") <= the host's skin: the lists stay valid until some atom has moved s_in/2, which
+// the device checks itself every compute (moved_kernel); the host's list only defines the ghost shell.
 int mdp_rebomos_repack(mdp_ctx *c)
 {
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
-  if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
-  mdp_rebomos_fill_dev(c, c->skin);
+  if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  double s_in = c->skin > 0.0 ? c->skin : 2.0;
+  {
+    double want = 1.0; // default inner skin (A); MDP_INNER_SKIN overrides, never above the host's skin
+    if (const char *e = getenv("MDP_INNER_SKIN")) want = atof(e);
+    if (want > 0.0 && want < s_in) s_in = want;
+  }
+  c->skin_inner = s_in;
+  mdp_rebomos_fill_dev(c, s_in);
   const int nall = c->nall, nlocal = c->nlocal;
   hipStream_t st = c->stream;
   MDP_HIP(c, c->cand_cnt.reserve(nall + 1));
@@ -1118,22 +1201,36 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
   MDP_HIP(c, c->class_list.reserve((size_t) 4 * nall + 4));
   MDP_HIP(c, c->class_count.reserve(4));
+  MDP_HIP(c, c->xhold_all.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
+  MDP_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, sizeof(int) * (nall + 1), st));
   MDP_HIP(c, hipMemsetAsync(c->amask.p, 0, sizeof(unsigned long long) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, st));
   MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * 4, st));
+  // one bin grid serves both lists (cell width >= (rcLJmax + s_in)/2)
+  double ljcut = 0.0, candcut = 0.0;
+  for (int k = 0; k < 4; k++) {
+    ljcut = ljcut > c->rebomos.ljlist_cutsq[k] ? ljcut : c->rebomos.ljlist_cutsq[k];
+    candcut = candcut > c->rebomos.cand_cutsq[k] ? candcut : c->rebomos.cand_cutsq[k];
+  }
+  ljcut = sqrt(ljcut);
+  candcut = sqrt(candcut);
+  MDP_TRY(mdp_bin_atoms(c, ljcut, c->bbox_lo, c->bbox_hi));
+  const int Rc = candcut <= 0.5 * ljcut ? 1 : 2; // cells are >= ljcut/2 wide
   const int per_block = 256 / RP_L;
-  const int grid = (nall + per_block - 1) / per_block;
-  repack_count_kernel<<<grid, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_cnt.p);
+  const int nghost = nall - nlocal;
+  if (nlocal)
+    cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
+        c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
+        nullptr, c->is_center.p);
+  if (nghost)
+    cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
+        c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
+        nullptr, c->is_center.p);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
-  // Lennard-Jones cluster pair list from the bin grid (cutoff rcLJmax + skin)
-  double ljcut = 0.0;
-  for (int k = 0; k < 4; k++) ljcut = ljcut > c->rebomos.ljlist_cutsq[k] ? ljcut : c->rebomos.ljlist_cutsq[k];
-  ljcut = sqrt(ljcut);
-  MDP_TRY(mdp_bin_atoms(c, ljcut, c->bbox_lo, c->bbox_hi));
   if (nclus) {
-    const int gb = (nclus + 255) / 256;
+    const int gb = (nclus + 15) / 16;
 #define MDP_CB(CLV, FILLV, OFFP, OUTP)                                                                              \
   cluster_build_kernel<CLV, FILLV><<<gb, 256, 0, st>>>(c->grid, c->rebomos, nclus, nlocal, c->xq.p, c->cell_perm.p, \
                                                        c->cell_start.p, c->lj_cnt.p, c->lj_split.p, OFFP, OUTP)
@@ -1155,22 +1252,25 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->rev.reserve((size_t) cand_total + 1));
   MDP_HIP(c, c->fnbr.reserve((size_t) 3 * cand_total + 3));
   MDP_HIP(c, c->eslot.reserve((size_t) cand_total + 1));
-  repack_fill_kernel<<<grid, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_off.p,
-                                           c->cand.p, c->is_center.p);
+  if (nall)
+    cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
+        c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
+        c->cand.p, c->is_center.p);
   if (nclus) {
-    const int gb = (nclus + 255) / 256;
+    const int gb = (nclus + 15) / 16;
     if (cl == 1) MDP_CB(1, true, c->lj_off.p, c->lj.p);
     else if (cl == 2) MDP_CB(2, true, c->lj_off.p, c->lj.p);
     else MDP_CB(4, true, c->lj_off.p, c->lj.p);
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
-  classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, c->xq.p, c->cand_off.p, c->cand.p,
+  classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
                                                       c->is_center.p, c->class_list.p, c->class_count.p);
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
                                                                      c->flags.p);
+  if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
   MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -1179,6 +1279,27 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (hflags[1])
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
   c->rebo_packed = true;
+  c->style_builds++;
+  return MDP_OK;
+}
+
+// `neigh_modify check yes`, done by the style for its own lists: has any atom (ghosts included) moved
+// more than half the inner skin since they were built?
+static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
+{
+  hipStream_t st = c->stream;
+  const int nall = c->nall;
+  stale = false;
+  if (!nall) return MDP_OK;
+  MDP_HIP(c, hipMemsetAsync(c->flags.p + 2, 0, sizeof(int), st));
+  const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
+  const double trig = 0.5 * c->skin_inner;
+  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, c->xq.p, c->xhold_all.p, c->flags.p + 2);
+  MDP_HIP(c, hipGetLastError());
+  int *h = (int *) (c->h_pinned + 24);
+  MDP_HIP(c, hipMemcpyAsync(h, c->flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  stale = *h != 0;
   return MDP_OK;
 }
 
@@ -1197,8 +1318,13 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
 {
-  if (!c->rebo_packed) return mdp_fail(c, MDP_ESTATE, "rebomos: neighbor list not repacked");
   if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "rebomos: per-atom virial is not implemented on the device");
+  if (c->rebo_packed) {
+    bool stale = false;
+    MDP_TRY(rebomos_lists_stale(c, stale));
+    if (stale) c->rebo_packed = false;
+  }
+  if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
   hipStream_t st = c->stream;
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
   MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));

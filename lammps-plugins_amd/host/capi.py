@@ -35,7 +35,7 @@ class MdConfig(C.Structure):
     """mirror of mdp_md_config"""
     _fields_ = [("style", C.c_int), ("nlocal", C.c_int), ("nghost", C.c_int), ("ntypes", C.c_int),
                 ("skin", C.c_double), ("dt", C.c_double), ("ftm2v", C.c_double), ("mvv2e", C.c_double),
-                ("bbox_lo", C.c_double * 3), ("bbox_hi", C.c_double * 3)]
+                ("bbox_lo", C.c_double * 3), ("bbox_hi", C.c_double * 3), ("master_list", C.c_int)]
 
 
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
@@ -43,7 +43,7 @@ EXPORTS = [
     "mdp_abi_version", "mdp_device_count", "mdp_create", "mdp_destroy", "mdp_last_error", "mdp_set_stream",
     "mdp_sync", "mdp_rebomos_set_params", "mdp_rebomos_read_file", "mdp_rebomos_params_from_scalars",
     "mdp_aeam_set_tables", "mdp_aeam_file_read", "mdp_aeam_file_info", "mdp_aeam_file_build", "mdp_aeam_file_free", "mdp_set_atoms_host", "mdp_set_positions_host",
-    "mdp_set_neighbors_host", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
+    "mdp_set_neighbors_host", "mdp_set_skin", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
     "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
     "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
@@ -209,6 +209,9 @@ class Context:
         self._ck(self.L.mdp_set_neighbors_csr_host(self.h, C.c_int(len(numneigh)), _ip(numneigh),
                                                    offset.ctypes.data_as(C.POINTER(C.c_longlong)), _ip(neigh),
                                                    C.c_double(skin)))
+
+    def set_skin(self, skin):
+        self._ck(self.L.mdp_set_skin(self.h, C.c_double(skin)))
 
     def set_neighbors_paged_host(self, inum, gnum, ilist, numneigh, rows, skin):
         """rows: list of int32 arrays (one per atom index) -- exercises the LAMMPS int** path"""

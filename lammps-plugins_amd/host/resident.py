@@ -39,7 +39,7 @@ class Domain:
     """
 
     def __init__(self, ctx: capi.Context, style: int, box: S.Box, x, v, type_, tag, mass, map_, ghost_owner,
-                 ghost_shift, ghost_type, ghost_tag, skin: float, dt: float = 0.001):
+                 ghost_shift, ghost_type, ghost_tag, skin: float, dt: float = 0.001, master_list: bool = False):
         self.ctx, self.style, self.box = ctx, style, box
         self.nlocal, self.nghost = len(x), len(ghost_owner)
         self.mass = np.asarray(mass, dtype=np.float64)
@@ -51,6 +51,7 @@ class Domain:
         cfg = capi.MdConfig()
         cfg.style, cfg.nlocal, cfg.nghost, cfg.ntypes = style, self.nlocal, self.nghost, len(mass) - 1
         cfg.skin, cfg.dt, cfg.ftm2v, cfg.mvv2e = skin, dt, S.FTM2V, S.MVV2E
+        cfg.master_list = 1 if master_list else 0
         lo, hi = allx.min(axis=0) - pad, allx.max(axis=0) + pad
         for d in range(3):
             cfg.bbox_lo[d], cfg.bbox_hi[d] = lo[d], hi[d]
@@ -60,7 +61,8 @@ class Domain:
         self.builds = 0
 
     @classmethod
-    def single(cls, ctx, style, s: S.System, cutghost: float, skin: float, map_, v0=None, dt=0.001, sort=True):
+    def single(cls, ctx, style, s: S.System, cutghost: float, skin: float, map_, v0=None, dt=0.001, sort=True,
+               master_list=False):
         """whole periodic box on one GPU: ghosts are periodic self-images"""
         x = S.wrap(s.box, s.x)
         v = np.zeros_like(x) if v0 is None else np.asarray(v0, dtype=np.float64)
@@ -74,7 +76,8 @@ class Domain:
             go = morton_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0)
             owner, shift_cart = owner[go], shift_cart[go]
         d = cls(ctx, style, s.box, np.ascontiguousarray(x), np.ascontiguousarray(v), t, g, s.mass, map_,
-                owner.astype(np.int32), np.ascontiguousarray(shift_cart), t[owner], g[owner], skin, dt)
+                owner.astype(np.int32), np.ascontiguousarray(shift_cart), t[owner], g[owner], skin, dt,
+                master_list=master_list)
         d.order_tag = g
         return d
 

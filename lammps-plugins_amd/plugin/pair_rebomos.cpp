@@ -182,9 +182,11 @@ void PairREBOMoS::compute(int eflag, int vflag)
     rc = mdp_set_atoms_host(dev, nlocal, atom->nghost, nall ? atom->x[0] : nullptr, atom->type, atom->tag,
                             atom->ntypes, map);
     if (rc != MDP_OK) fail_one(rc, "atom upload");
-    rc = mdp_set_neighbors_host(dev, list->inum, list->gnum, list->ilist, list->numneigh, list->firstneigh,
-                                neighbor->skin);
-    if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
+    // the device builds its own trimmed lists from the positions; the host's list (requested in
+    // init_style for API parity and for the ghost shell it implies) only contributes its skin
+    if (list->inum != nlocal) error->one(FLERR, "Pair style rebomos (MI355X): neighbor list does not match nlocal");
+    rc = mdp_set_skin(dev, neighbor->skin);
+    if (rc != MDP_OK) fail_one(rc, "skin upload");
     nall_uploaded = nall;
   } else {
     rc = mdp_set_positions_host(dev, atom->x[0]);
