@@ -49,13 +49,60 @@ __device__ __forceinline__ const double *spline_row(const double *__restrict__ t
 __device__ __forceinline__ double sp_val(const double *c, double p) { return ((c[3] * p + c[4]) * p + c[5]) * p + c[6]; }
 __device__ __forceinline__ double sp_der(const double *c, double p) { return (c[0] * p + c[1]) * p + c[2]; }
 
+// The same coefficients re-laid for the streaming kernels: one 32-byte aligned record per row and use,
+//   val4[table][row] = {c3,c4,c5,c6}  (value),   der4[table][row] = {c0,c1,c2,0}  (derivative)
+// so a lookup is a single aligned 32-byte gather instead of 56 bytes straddling cache lines.
+__device__ __forceinline__ double v4_val(const double4 c, double p) { return ((c.x * p + c.y) * p + c.z) * p + c.w; }
+__device__ __forceinline__ double d4_der(const double4 c, double p) { return (c.x * p + c.y) * p + c.z; }
+
+__device__ __forceinline__ int spline_index(double r, double rdr, int nr, double &p)
+{
+  p = r * rdr + 1.0;
+  int m = (int) p;
+  m = m < nr - 1 ? m : nr - 1;
+  p -= m;
+  p = p < 1.0 ? p : 1.0;
+  return m;
+}
+
+// per-pair-type parameters of one centre type against every neighbour type, kept in registers
+// (selected with compares on the neighbour's type: no per-lane loads from the parameter block)
+template <int NT> struct PairPar {
+  double cut[NT], rdr[NT];
+  int nr[NT], trho[NT], tz2r[NT];
+};
+
+template <int NT> __device__ __forceinline__ PairPar<NT> load_pairpar(const AeamDev &A, const int ti, const bool transposed)
+{
+  PairPar<NT> q;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int pt = transposed ? t * A.ntypes + ti : ti * A.ntypes + t;
+    q.cut[t] = A.cut[pt];
+    q.rdr[t] = A.rdr[pt];
+    q.nr[t] = A.nr[pt];
+    q.trho[t] = A.t2rhor[pt];
+    q.tz2r[t] = A.t2z2r[pt];
+  }
+  return q;
+}
+
+template <int NT, typename T> __device__ __forceinline__ T pick(const T (&a)[NT], const int t)
+{
+  T v = a[0];
+#pragma unroll
+  for (int k = 1; k < NT; k++) v = (t == k) ? a[k] : v;
+  return v;
+}
+
 // ---- pass 1, metal centres (pair_aeam.cpp:174-205) ---------------------------------------------------
-template <int L>
+template <int L, int NT>
 __global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, const int nlocal,
                                                            const double4 *__restrict__ xq,
                                                            const long long *__restrict__ nb_off,
                                                            const int *__restrict__ nb, double *__restrict__ rho)
 {
+  constexpr int U = 2;
   const int s = threadIdx.x % L;
   const long long i64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
   const bool have = i64 < nlocal;
@@ -65,17 +112,30 @@ __global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, cons
   double acc = 0.0;
   const bool metal = ti < A.nnonangular;
   if (have && metal) {
+    const PairPar<NT> q = load_pairpar<NT>(A, ti, false);
+    const int nm1 = A.nrmax + 1;
     const long long b = nb_off[i], e = nb_off[i + 1];
-    for (long long k = b + s; k < e; k += L) {
-      const int j = nb[k];
-      const double4 xj = xq[j];
-      const double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-      const double r = sqrt(dx * dx + dy * dy + dz * dz);
-      const int pt = ti * A.ntypes + (int) xj.w;
-      if (r <= A.cut[pt]) { // CutDec applies only when BOTH are angular (pair_aeam.cpp:187-190)
-        double p;
-        const double *c = spline_row(A.rhor, A.t2rhor[pt], A.nrmax + 1, r, A.rdr[pt], A.nr[pt], p);
-        acc += sp_val(c, p);
+    for (long long k0 = b; k0 < e; k0 += U * L) {
+      int jj[U];
+      double4 xj[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long long k = k0 + u * L + s;
+        jj[u] = k < e ? nb[k] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) xj[u] = xq[jj[u] >= 0 ? jj[u] : i];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (jj[u] < 0) continue;
+        const double dx = xj[u].x - xi.x, dy = xj[u].y - xi.y, dz = xj[u].z - xi.z;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const int tj = (int) xj[u].w;
+        if (r <= pick<NT>(q.cut, tj)) { // CutDec applies only when BOTH are angular (pair_aeam.cpp:187-190)
+          double p;
+          const int m = spline_index(r, pick<NT>(q.rdr, tj), pick<NT>(q.nr, tj), p);
+          acc += v4_val(A.rhor_v4[(size_t) pick<NT>(q.trho, tj) * nm1 + m], p);
+        }
       }
     }
   }
@@ -227,7 +287,7 @@ __global__ __launch_bounds__(256) void aeam_embed_kernel(const AeamDev A, const 
 }
 
 // ---- pass 3, two-body part for every owned atom (pair_aeam.cpp:337-393) ----------------------------------
-template <int L>
+template <int L, int NT, bool EV>
 __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const int nlocal,
                                                          const double4 *__restrict__ xq,
                                                          const long long *__restrict__ nb_off,
@@ -235,6 +295,7 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
                                                          double *__restrict__ f, double *__restrict__ eatom,
                                                          double *__restrict__ acc, const int eflag, const int vflag)
 {
+  constexpr int U = 2;
   const int lane = threadIdx.x & 63;
   const int s = lane % L;
   const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
@@ -246,48 +307,69 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
   const double qa = a_metal ? fp[a] : 0.0; // (1 - deli) Fptmp fp
   double fx = 0, fy = 0, fz = 0, e = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
   if (have) {
+    const PairPar<NT> qA = load_pairpar<NT>(A, ta, false); // visit (i=a, j): tables of the pair (ta,tj)
+    const PairPar<NT> qJ = load_pairpar<NT>(A, ta, true);  // visit (i=j, a): tables of the pair (tj,ta)
     const long long b = nb_off[a], en = nb_off[a + 1];
     const int nm1 = A.nrmax + 1;
-    for (long long k = b + s; k < en; k += L) {
-      const int j = nb[k];
-      const double4 xj = xq[j];
-      const double dx = xj.x - xa.x, dy = xj.y - xa.y, dz = xj.z - xa.z;
-      const double r = sqrt(dx * dx + dy * dy + dz * dz);
-      const int tj = (int) xj.w;
-      const int pa = ta * A.ntypes + tj, pj = tj * A.ntypes + ta;
-      const bool in_a = r <= A.cut[pa], in_j = r <= A.cut[pj];
-      if (!(in_a || in_j)) continue;
-      const double recip = 1.0 / r;
-      double fpair_a = 0.0, fpair_j = 0.0;
-      if (in_a) { // the visit (i=a, j)
-        double p;
-        const double *c = spline_row(A.rhor, A.t2rhor[pa], nm1, r, A.rdr[pa], A.nr[pa], p);
-        const double dfij = sp_der(c, p);
-        const double *z = A.z2r + ((c - A.rhor) + (long long) (A.t2z2r[pa] - A.t2rhor[pa]) * nm1 * 7); // same row m1
-        const double phip = sp_der(z, p);
-        fpair_a = -qa * dfij * recip + 0.5 * (-phip * recip);
-        if (eflag) e += 0.5 * sp_val(z, p); // credited to i only (pair_aeam.cpp:386-390)
+    for (long long k0 = b; k0 < en; k0 += U * L) {
+      int jj[U];
+      double4 xj[U];
+      double fpj[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long long k = k0 + u * L + s;
+        jj[u] = k < en ? nb[k] : -1;
       }
-      if (in_j) { // the visit (i=j, neighbour a): only its action on a
-        double p;
-        const double *c = spline_row(A.rhor, A.t2rhor[pj], nm1, r, A.rdr[pj], A.nr[pj], p);
-        const double dfja = sp_der(c, p);
-        const double *z = A.z2r + ((c - A.rhor) + (long long) (A.t2z2r[pj] - A.t2rhor[pj]) * nm1 * 7);
-        const double phip = sp_der(z, p);
-        const double qj = (tj < A.nnonangular) ? fp[j] : 0.0;
-        fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xj[u] = xq[jj[u] >= 0 ? jj[u] : a];
+        fpj[u] = fp[jj[u] >= 0 ? jj[u] : a];
       }
-      const double ft = fpair_a + fpair_j;
-      fx -= dx * ft;
-      fy -= dy * ft;
-      fz -= dz * ft;
-      if (vflag) { // ev_tally(i=a, j, ..., fpair_a, d): this rank tallies its own visits
-        v0 += dx * dx * fpair_a;
-        v1 += dy * dy * fpair_a;
-        v2 += dz * dz * fpair_a;
-        v3 += dx * dy * fpair_a;
-        v4 += dx * dz * fpair_a;
-        v5 += dy * dz * fpair_a;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (jj[u] < 0) continue;
+        const double dx = xj[u].x - xa.x, dy = xj[u].y - xa.y, dz = xj[u].z - xa.z;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const int tj = (int) xj[u].w;
+        const bool in_a = r <= pick<NT>(qA.cut, tj), in_j = r <= pick<NT>(qJ.cut, tj);
+        if (!(in_a || in_j)) continue;
+        const double recip = 1.0 / r;
+        double fpair_a = 0.0, fpair_j = 0.0, dfa_shared = 0.0;
+        if (in_a) { // the visit (i=a, j)
+          double p;
+          const int m = spline_index(r, pick<NT>(qA.rdr, tj), pick<NT>(qA.nr, tj), p);
+          const double dfij = d4_der(A.rhor_d4[(size_t) pick<NT>(qA.trho, tj) * nm1 + m], p);
+          dfa_shared = dfij;
+          const size_t zrow = (size_t) pick<NT>(qA.tz2r, tj) * nm1 + m; // same row m1 (pair_aeam.cpp:367)
+          const double phip = d4_der(A.z2r_d4[zrow], p);
+          fpair_a = -qa * dfij * recip + 0.5 * (-phip * recip);
+          if (EV) e += 0.5 * v4_val(A.z2r_v4[zrow], p); // credited to i only (pair_aeam.cpp:386-390)
+        }
+        if (in_j) { // the visit (i=j, neighbour a): only its action on a
+          const double qj = (tj < A.nnonangular) ? fpj[u] : 0.0;
+          if (tj == ta && in_a) {
+            // same element: both visits read the same table rows (99 % of the pairs of an alloy matrix)
+            fpair_j = fpair_a + (qa - qj) * dfa_shared * recip;
+          } else {
+            double p;
+            const int m = spline_index(r, pick<NT>(qJ.rdr, tj), pick<NT>(qJ.nr, tj), p);
+            const double dfja = d4_der(A.rhor_d4[(size_t) pick<NT>(qJ.trho, tj) * nm1 + m], p);
+            const double phip = d4_der(A.z2r_d4[(size_t) pick<NT>(qJ.tz2r, tj) * nm1 + m], p);
+            fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
+          }
+        }
+        const double ft = fpair_a + fpair_j;
+        fx -= dx * ft;
+        fy -= dy * ft;
+        fz -= dz * ft;
+        if (EV && vflag) { // ev_tally(i=a, j, ..., fpair_a, d): this rank tallies its own visits
+          v0 += dx * dx * fpair_a;
+          v1 += dy * dy * fpair_a;
+          v2 += dz * dz * fpair_a;
+          v3 += dx * dy * fpair_a;
+          v4 += dx * dz * fpair_a;
+          v5 += dy * dz * fpair_a;
+        }
       }
     }
   }
@@ -302,29 +384,31 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
     fo[1] += fy;
     fo[2] += fz;
   }
-  if (eflag & MDP_EFLAG_ATOM) {
-    const double ea = lane_sum<L>(e);
-    if (have && s == 0) eatom[a] += ea;
-  }
-  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
-  if (eflag & MDP_EFLAG_GLOBAL) {
-    const double et = lane_sum<64>(e);
-    if (lane == 0) atomicAdd(&slot[0], et);
-  }
-  if (vflag & MDP_VFLAG_GLOBAL) {
-    v0 = lane_sum<64>(v0);
-    v1 = lane_sum<64>(v1);
-    v2 = lane_sum<64>(v2);
-    v3 = lane_sum<64>(v3);
-    v4 = lane_sum<64>(v4);
-    v5 = lane_sum<64>(v5);
-    if (lane == 0) {
-      atomicAdd(&slot[1], v0);
-      atomicAdd(&slot[2], v1);
-      atomicAdd(&slot[3], v2);
-      atomicAdd(&slot[4], v3);
-      atomicAdd(&slot[5], v4);
-      atomicAdd(&slot[6], v5);
+  if (EV) {
+    if (eflag & MDP_EFLAG_ATOM) {
+      const double ea = lane_sum<L>(e);
+      if (have && s == 0) eatom[a] += ea;
+    }
+    double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+    if (eflag & MDP_EFLAG_GLOBAL) {
+      const double et = lane_sum<64>(e);
+      if (lane == 0) atomicAdd(&slot[0], et);
+    }
+    if (vflag & MDP_VFLAG_GLOBAL) {
+      v0 = lane_sum<64>(v0);
+      v1 = lane_sum<64>(v1);
+      v2 = lane_sum<64>(v2);
+      v3 = lane_sum<64>(v3);
+      v4 = lane_sum<64>(v4);
+      v5 = lane_sum<64>(v5);
+      if (lane == 0) {
+        atomicAdd(&slot[1], v0);
+        atomicAdd(&slot[2], v1);
+        atomicAdd(&slot[3], v2);
+        atomicAdd(&slot[4], v3);
+        atomicAdd(&slot[5], v4);
+        atomicAdd(&slot[6], v5);
+      }
     }
   }
 }
@@ -432,6 +516,17 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
   }
 }
 
+// re-lay the 7-coefficient rows into the aligned records the streaming kernels gather
+__global__ void relay_kernel(const size_t nrows, const double *__restrict__ src, double4 *__restrict__ val4,
+                             double4 *__restrict__ der4)
+{
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= nrows) return;
+  const double *c = src + 7 * i;
+  val4[i] = make_double4(c[3], c[4], c[5], c[6]);
+  der4[i] = make_double4(c[0], c[1], c[2], 0.0);
+}
+
 __global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
                                 int *__restrict__ count)
 {
@@ -470,9 +565,15 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   const int nlocal = c->nlocal;
   MDP_TRY(mdp_acc_begin(c, true));
   mdp_time_mark(c, 0);
-  if (nlocal)
-    aeam_density_kernel<AE_L><<<nblk(nlocal, 256 / AE_L), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p,
-                                                                        c->rho.p);
+  if (nlocal) {
+    const int grid = nblk(nlocal, 256 / AE_L);
+    switch (c->aeam.ntypes) {
+      case 1: aeam_density_kernel<AE_L, 1><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      case 2: aeam_density_kernel<AE_L, 2><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      case 3: aeam_density_kernel<AE_L, 3><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      default: aeam_density_kernel<AE_L, 4><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+    }
+  }
   if (c->h_ang_count)
     aeam_density_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
                                                                      c->nb_off.p, c->nb.p, c->rho.p, c->flags.p);
@@ -494,10 +595,20 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
   MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, st));
-  if (nlocal)
-    aeam_force_kernel<AE_L><<<nblk(nlocal, 256 / AE_L), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p,
-                                                                      c->fp.p, c->f.p, c->eatom.p, c->acc.p, eflag,
-                                                                      vflag);
+  if (nlocal) {
+    const int grid = nblk(nlocal, 256 / AE_L);
+    const bool ev = eflag || vflag;
+#define MDP_AF(NTV, EVV)                                                                                              \
+  aeam_force_kernel<AE_L, NTV, EVV><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->fp.p,      \
+                                                          c->f.p, c->eatom.p, c->acc.p, eflag, vflag)
+    switch (c->aeam.ntypes) {
+      case 1: if (ev) MDP_AF(1, true); else MDP_AF(1, false); break;
+      case 2: if (ev) MDP_AF(2, true); else MDP_AF(2, false); break;
+      case 3: if (ev) MDP_AF(3, true); else MDP_AF(3, false); break;
+      default: if (ev) MDP_AF(4, true); else MDP_AF(4, false); break;
+    }
+#undef MDP_AF
+  }
   if (c->h_ang_count)
     aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
                                                                    c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->acc.p,
@@ -549,6 +660,21 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
   A.frho = c->aeam_frho.p;
   A.rhor = c->aeam_rhor.p;
   A.z2r = c->aeam_z2r.p;
+  {
+    const size_t rr = (size_t) t->nrhor * (t->nrmax + 1), zr = (size_t) t->nz2r * (t->nrmax + 1);
+    MDP_HIP(c, c->aeam_rhor_v4.reserve(rr));
+    MDP_HIP(c, c->aeam_rhor_d4.reserve(rr));
+    MDP_HIP(c, c->aeam_z2r_v4.reserve(zr));
+    MDP_HIP(c, c->aeam_z2r_d4.reserve(zr));
+    relay_kernel<<<(int) ((rr + 255) / 256), 256, 0, c->stream>>>(rr, c->aeam_rhor.p, c->aeam_rhor_v4.p, c->aeam_rhor_d4.p);
+    relay_kernel<<<(int) ((zr + 255) / 256), 256, 0, c->stream>>>(zr, c->aeam_z2r.p, c->aeam_z2r_v4.p, c->aeam_z2r_d4.p);
+    MDP_HIP(c, hipGetLastError());
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    A.rhor_v4 = c->aeam_rhor_v4.p;
+    A.rhor_d4 = c->aeam_rhor_d4.p;
+    A.z2r_v4 = c->aeam_z2r_v4.p;
+    A.z2r_d4 = c->aeam_z2r_d4.p;
+  }
   c->have_aeam = true;
   return MDP_OK;
 }

@@ -168,6 +168,10 @@ int mdp_destroy(mdp_ctx *c)
   c->aeam_frho.release();
   c->aeam_rhor.release();
   c->aeam_z2r.release();
+  c->aeam_rhor_v4.release();
+  c->aeam_rhor_d4.release();
+  c->aeam_z2r_v4.release();
+  c->aeam_z2r_d4.release();
   c->xq.release();
   c->xraw.release();
   c->tag.release();

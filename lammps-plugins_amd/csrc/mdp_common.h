@@ -81,6 +81,7 @@ struct AeamDev {
   double rdrho[4];
   int nrho[4], t2frho[4];
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
+  const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
 };
 
 struct mdp_ctx {
@@ -95,6 +96,7 @@ struct mdp_ctx {
   RebomosDev rebomos;
   AeamDev aeam;
   DevBuf<double> aeam_frho, aeam_rhor, aeam_z2r;
+  DevBuf<double4> aeam_rhor_v4, aeam_rhor_d4, aeam_z2r_v4, aeam_z2r_d4;
 
   // ---- atoms
   int nlocal = 0, nghost = 0, nall = 0, ntypes = 0;

@@ -639,7 +639,7 @@ __device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, con
   }
 }
 
-template <int CL, int L, bool EV>
+template <int CL, int L, bool EV, int U = 2>
 __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
     const RebomosDev P, const int nlocal, const int nclus, const double4 *__restrict__ xq,
     const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const int *__restrict__ lj,
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
     const double *__restrict__ fnbr, const double *__restrict__ eslot, double *__restrict__ f,
     double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag, const int accumulate)
 {
-  constexpr int U = 2; // list entries per lane in flight (x CL pair evaluations each)
+  // U = list entries per lane in flight (x CL pair evaluations each)
   static_assert(L % CL == 0, "lanes per cluster must be a multiple of the cluster size");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1345,19 +1345,30 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
   }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 1);
-  constexpr int L = 16;
-  const int per_block = 256 / L;
-  const int grid = (c->nclus + per_block - 1) / per_block;
-  if (grid > 0) {
-#define MDP_LJ(CLV, EVV)                                                                                            \
-  rebo_lj_gather_kernel<CLV, L, EVV><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->nclus, c->xq.p, c->lj_off.p,     \
-                                                           c->lj_split.p, c->lj.p, c->cand_off.p, c->amask.p,         \
-                                                           c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p,       \
-                                                           c->acc.p, eflag, vflag, zero_f ? 0 : 1)
+  {
+    int variant = 0; // tuning hook: MDP_LJ_VARIANT = 0..5 -> (L,U) = (16,2) (8,2) (32,2) (16,4) (8,4) (16,3)
+    if (const char *e = getenv("MDP_LJ_VARIANT")) variant = atoi(e);
     const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
-    if (c->cluster == 1) { if (ev) MDP_LJ(1, true); else MDP_LJ(1, false); }
-    else if (c->cluster == 2) { if (ev) MDP_LJ(2, true); else MDP_LJ(2, false); }
-    else { if (ev) MDP_LJ(4, true); else MDP_LJ(4, false); }
+#define MDP_LJ(CLV, LV, EVV, UV)                                                                                    \
+  rebo_lj_gather_kernel<CLV, LV, EVV, UV><<<(c->nclus + 256 / LV - 1) / (256 / LV), 256, 0, st>>>(                    \
+      c->rebomos, c->nlocal, c->nclus, c->xq.p, c->lj_off.p, c->lj_split.p, c->lj.p, c->cand_off.p, c->amask.p,      \
+      c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, zero_f ? 0 : 1)
+#define MDP_LJ2(CLV, LV, UV)                                                                                        \
+  do {                                                                                                              \
+    if (ev) MDP_LJ(CLV, LV, true, UV);                                                                              \
+    else MDP_LJ(CLV, LV, false, UV);                                                                                \
+  } while (0)
+    if (c->nclus > 0) {
+      if (c->cluster == 1) MDP_LJ2(1, 16, 2);
+      else if (c->cluster == 4) MDP_LJ2(4, 16, 2);
+      else if (variant == 1) MDP_LJ2(2, 8, 2);
+      else if (variant == 2) MDP_LJ2(2, 32, 2);
+      else if (variant == 3) MDP_LJ2(2, 16, 4);
+      else if (variant == 4) MDP_LJ2(2, 8, 4);
+      else if (variant == 5) MDP_LJ2(2, 16, 3);
+      else MDP_LJ2(2, 16, 2);
+    }
+#undef MDP_LJ2
 #undef MDP_LJ
   }
   MDP_HIP(c, hipGetLastError());
