@@ -320,6 +320,18 @@ int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi
   const int nall = c->nall;
   hipStream_t st = c->stream;
   Grid &g = c->grid;
+  if (nall <= 0) { // an empty sub-domain has nothing to bin
+    for (int d = 0; d < 3; d++) {
+      g.n[d] = 1;
+      g.lo[d] = 0.0;
+      g.inv[d] = 1.0;
+    }
+    g.range = 2;
+    MDP_HIP(c, c->cell_start.reserve(4));
+    MDP_HIP(c, c->cell_perm.reserve(4));
+    MDP_HIP(c, hipMemsetAsync(c->cell_start.p, 0, sizeof(int) * 2, st));
+    return MDP_OK;
+  }
   const double binsize = 0.5 * cutoff; // LAMMPS default: half the cutoff (log.rebomos-bulk.1:45)
   g.range = 2;
   long long ncell = 1;

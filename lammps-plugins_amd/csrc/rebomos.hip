@@ -1264,8 +1264,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
-  classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
-                                                      c->is_center.p, c->class_list.p, c->class_count.p);
+  if (nall)
+    classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
+                                                        c->is_center.p, c->class_list.p, c->class_count.p);
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
