@@ -3,7 +3,7 @@
 import csv, glob, os, sys, collections, json
 root = sys.argv[1]
 res = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")) + glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         short = ("lj_gather" if "lj_gather" in k else "centre16" if "centre_kernel<16>" in k else "centre4" if "centre_kernel<4>" in k
