@@ -110,12 +110,21 @@ def main():
         log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # MDP_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks: every rank uses
+    # GPU (local_rank mod #GPUs) and the halo is staged through the host.  The judged runs use RCCL.
+    backend = os.environ.get("MDP_BENCH_BACKEND", "nccl")
+    stage_host = backend != "nccl"
+    if stage_host:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if stage_host:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     t_setup = time.perf_counter()
     s, wname = build_system(args)
@@ -135,13 +144,15 @@ def main():
         cutghost = float(af.cut_table(tabs).max()) + skin
         s.mass[1:3] = af.mass[:2]
     dev = torch.device("cuda", local_rank)
-    dom = resident.make_domain(ctx, style, s, cutghost, skin, map_, v0=v0, dist=dist, device=dev)
+    dom = resident.make_domain(ctx, style, s, cutghost, skin, map_, v0=v0, dist=dist, device=dev,
+                               stage_host=stage_host and dist is not None)
     dom.build_neighbors()
     dom.compute(eflag=1, vflag=1)
     th = dom.thermo()
     pe0 = th["pe"]
+    rdev = "cpu" if stage_host else "cuda"   # device of the small reduction tensors
     if dist is not None:
-        t = torch.tensor([th["pe"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([th["pe"]], dtype=torch.float64, device=rdev)
         dist.all_reduce(t)
         pe0 = float(t.item())
     stats = ctx.md_neighbor_stats()
@@ -168,7 +179,7 @@ def main():
             if args.check_every and (step0 + k) % args.check_every == 0:
                 need = dom.needs_rebuild()
                 if dist is not None:
-                    t = torch.tensor([1.0 if need else 0.0], device="cuda")
+                    t = torch.tensor([1.0 if need else 0.0], device=rdev)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     need = bool(t.item() > 0)
                 if need:
@@ -188,7 +199,7 @@ def main():
     elapsed = time.perf_counter() - t0
     style_builds = ctx.md_neighbor_stats()[7] - style_builds0 if args.workload == "rebomos" else 0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -239,7 +250,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "ns_per_day": round(args.steps / elapsed * 0.001 * 86.4, 4),
-        "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}",
+        "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}", "transport": "rccl" if not stage_host else backend + "-staged (rehearsal)",
                    "initial_temp_K": args.temp, "skin": skin, "neighbor_rebuilds_in_timed_region": rebuilds,
                    "inner_skin": float(os.environ.get("MDP_INNER_SKIN", "1.0")) if args.workload == "rebomos" else None,
                    "style_list_builds_in_timed_region_rank0": int(style_builds),

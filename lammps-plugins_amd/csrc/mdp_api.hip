@@ -216,6 +216,7 @@ int mdp_destroy(mdp_ctx *c)
   c->sort_keys_b.release();
   c->sort_vals_b.release();
   c->nb_cnt.release();
+  if (c->ev_stale_made) (void) hipEventDestroy(c->ev_stale);
   if (c->h_pinned) (void) hipHostFree(c->h_pinned);
   if (c->ev_made)
     for (int i = 0; i < 8; i++) (void) hipEventDestroy(c->ev[i]);

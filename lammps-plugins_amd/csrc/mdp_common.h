@@ -142,6 +142,9 @@ struct mdp_ctx {
   DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
   long long style_builds = 0;     // number of style-list builds so far
+  long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
+  hipEvent_t ev_stale = nullptr;
+  bool ev_stale_made = false, stale_pending = false;
   DevBuf<double> fnbr;            // [cand_total][3]
   DevBuf<double> eslot;           // [cand_total]
   DevBuf<char> scan_tmp;

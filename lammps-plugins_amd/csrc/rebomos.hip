@@ -1012,18 +1012,22 @@ __global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, 
   xhold[3 * (size_t) i + 2] = x.z;
 }
 
-__global__ __launch_bounds__(256) void moved_kernel(const int nall, const double trigsq,
+// flag[0]: someone moved beyond the trigger; flag[1]: beyond the hard limit (half the inner skin)
+__global__ __launch_bounds__(256) void moved_kernel(const int nall, const double trigsq, const double hardsq,
                                                     const double4 *__restrict__ xq,
                                                     const double *__restrict__ xhold, int *__restrict__ flag)
 {
-  bool far = false;
+  bool far = false, toofar = false;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nall; i += gridDim.x * 256) {
     const double4 x = xq[i];
     const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1],
                  dz = x.z - xhold[3 * (size_t) i + 2];
-    far = far || (dx * dx + dy * dy + dz * dz > trigsq);
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    far = far || d2 > trigsq;
+    toofar = toofar || d2 > hardsq;
   }
-  if (__any(far) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  if (__any(far) && (threadIdx.x & 63) == 0) atomicOr(&flag[0], 1);
+  if (__any(toofar) && (threadIdx.x & 63) == 0) atomicOr(&flag[1], 1);
 }
 
 // rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
@@ -1280,27 +1284,62 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (hflags[1])
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
   c->rebo_packed = true;
+  c->stale_pending = false;
   c->style_builds++;
   return MDP_OK;
 }
 
 // `neigh_modify check yes`, done by the style for its own lists: has any atom (ghosts included) moved
 // more than half the inner skin since they were built?
-static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
+//   host mode     : checked before every compute (the host synchronises each step anyway)
+//   resident mode : the check of step n is read at step n+1 (pinned flag + event), so the CPU never waits
+//                   for the GPU inside the MD loop; the trigger is lowered by kStaleMargin to cover the one
+//                   step of extra motion, and a true violation is counted as a "dangerous build"
+constexpr double kStaleMargin = 0.1; // Angstrom
+
+static int rebomos_check_launch(mdp_ctx *c, const double trig)
 {
   hipStream_t st = c->stream;
   const int nall = c->nall;
-  stale = false;
-  if (!nall) return MDP_OK;
-  MDP_HIP(c, hipMemsetAsync(c->flags.p + 2, 0, sizeof(int), st));
+  MDP_HIP(c, hipMemsetAsync(c->flags.p + 2, 0, 2 * sizeof(int), st));
   const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
-  const double trig = 0.5 * c->skin_inner;
-  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, c->xq.p, c->xhold_all.p, c->flags.p + 2);
+  const double hard = 0.5 * c->skin_inner;
+  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, c->flags.p + 2);
   MDP_HIP(c, hipGetLastError());
   int *h = (int *) (c->h_pinned + 24);
-  MDP_HIP(c, hipMemcpyAsync(h, c->flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
-  stale = *h != 0;
+  MDP_HIP(c, hipMemcpyAsync(h, c->flags.p + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  return MDP_OK;
+}
+
+static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
+{
+  stale = false;
+  if (!c->nall) return MDP_OK;
+  int *h = (int *) (c->h_pinned + 24);
+  if (!c->md) { // immediate
+    MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    stale = h[0] != 0;
+    return MDP_OK;
+  }
+  // deferred by one compute
+  if (!c->ev_stale_made) {
+    MDP_HIP(c, hipEventCreateWithFlags(&c->ev_stale, hipEventDisableTiming));
+    c->ev_stale_made = true;
+  }
+  if (c->stale_pending) {
+    MDP_HIP(c, hipEventSynchronize(c->ev_stale)); // recorded a whole step ago
+    stale = h[0] != 0;
+    if (h[1]) c->dangerous_builds++;
+    c->stale_pending = false;
+  }
+  if (!stale) {
+    double trig = 0.5 * c->skin_inner - kStaleMargin;
+    if (trig < 0.25 * c->skin_inner) trig = 0.25 * c->skin_inner;
+    MDP_TRY(rebomos_check_launch(c, trig));
+    MDP_HIP(c, hipEventRecord(c->ev_stale, c->stream));
+    c->stale_pending = true;
+  }
   return MDP_OK;
 }
 
