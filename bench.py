@@ -166,16 +166,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def fwd(d):
-        if dist is not None:
-            d.forward_positions()
-
     def run(nsteps, step0):
+        """Verlet loop.  Every --check-every steps: `neigh_modify check yes` on the host's skin (max over
+        ranks); when it fires, atoms are re-wrapped / re-assigned and ghosts re-derived (Comm::exchange +
+        borders) before the step.  Multi-GPU REBO-MoS steps overlap the ghost exchange with the interior
+        Lennard-Jones work (RankDomain.step_overlapped)."""
         nonlocal dom
         rebuilds = 0
         for k in range(1, nsteps + 1):
-            ctx.md_initial_integrate()
-            fwd(dom)
             if args.check_every and (step0 + k) % args.check_every == 0:
                 need = dom.needs_rebuild()
                 if dist is not None:
@@ -183,11 +181,10 @@ def main():
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     need = bool(t.item() > 0)
                 if need:
-                    # Comm::exchange + borders + Neighbor::build: re-derive bricks/ghosts, rebuild on the device
                     dom = resident.reneighbor(dom, s, cutghost, map_, dist=dist, device=dev)
+                    dom.compute(0, 0)      # forces of the current positions for the next half kick
                     rebuilds += 1
-            dom.compute(0, 0)
-            ctx.md_final_integrate()
+            dom.step(0, 0)
         return rebuilds
 
     run(args.warmup, 0)
@@ -208,10 +205,7 @@ def main():
     kms = np.zeros(8)
     nmeas = 5
     for _ in range(nmeas):
-        ctx.md_initial_integrate()
-        fwd(dom)
-        dom.compute(0, 0)
-        ctx.md_final_integrate()
+        dom.step(0, 0)
         kms += np.array(ctx.get_timing())
     kms /= nmeas
     ctx.set_timing(False)

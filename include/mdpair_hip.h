@@ -159,6 +159,9 @@ typedef struct {
   double dt;
   double ftm2v, mvv2e;   /* unit constants (metal: SURVEY.md Appendix B)               */
   double bbox_lo[3], bbox_hi[3]; /* Cartesian bounds of owned+ghost atoms, for binning  */
+  int nghost_self;    /* ghosts [0,nghost_self) are periodic self-images (refreshed on the device), the rest are
+                         remote atoms filled by mdp_md_unpack_x; lists that reach none of the latter need not
+                         wait for the halo (mdp_md_compute_begin / _end)                                   */
   int master_list;    /* rebomos only: 1 = also build the LAMMPS-style full list at 3*rcmax+skin
                          (log.rebomos-bulk.1:43, for its statistics); the kernels never need it.
                          aeam always builds its (86-entry) list: the kernels stream it.          */
@@ -177,6 +180,11 @@ int mdp_md_build_neighbors(mdp_ctx *ctx);
 int mdp_md_initial_integrate(mdp_ctx *ctx); /* fix nve: v += dt/2 f/m; x += dt v; refresh self-image ghosts */
 int mdp_md_final_integrate(mdp_ctx *ctx);   /* v += dt/2 f/m */
 int mdp_md_compute(mdp_ctx *ctx, int eflag, int vflag); /* force_clear + Pair::compute on the device */
+/* the same in two halves for multi-GPU runs: _begin needs only owned atoms, self-image ghosts and LAST step's
+ * remote ghosts (it runs while this step's halo exchange is in flight: Lennard-Jones work of the clusters
+ * whose lists reach no remote ghost); _end needs the unpacked halo.  rebomos only; aeam: _begin is a no-op. */
+int mdp_md_compute_begin(mdp_ctx *ctx, int eflag, int vflag);
+int mdp_md_compute_end(mdp_ctx *ctx, int eflag, int vflag);
 /* halo plumbing for multi-GPU: pack x (or the AEAM fp) of owned atoms sendlist[n] (+shift) into buf;
  * unpack recv buffers into ghosts [first, first+n).  buf/sendlist/shift are DEVICE pointers. */
 int mdp_md_pack_x(mdp_ctx *ctx, int n, const int *d_sendlist, const double *d_shift, double *d_buf);

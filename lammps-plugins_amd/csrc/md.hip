@@ -458,6 +458,7 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
   MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->fp.p, 0, sizeof(double) * nall, st));
   MDP_HIP(c, hipStreamSynchronize(st));
+  c->remote_start = nlocal + (cfg->nghost_self >= 0 && cfg->nghost_self <= nghost ? cfg->nghost_self : nghost);
   c->md = true;
   return MDP_OK;
 }
@@ -542,6 +543,21 @@ int mdp_md_compute(mdp_ctx *c, int eflag, int vflag)
   MDP_TRY(mdp_md_aeam_density(c, eflag));
   MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
   return mdp_md_fold_self_ghost_f(c);
+}
+
+int mdp_md_compute_begin(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
+  if (c->cfg.style == 1) return mdp_rebomos_run_begin(c, eflag, vflag);
+  return MDP_OK;
+}
+
+int mdp_md_compute_end(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c || !c->md) return MDP_EINVAL;
+  if (c->cfg.style == 1) return mdp_rebomos_run_end(c, eflag, vflag);
+  return mdp_md_compute(c, eflag, vflag);
 }
 
 int mdp_md_thermo(mdp_ctx *c, double out[9])

@@ -188,6 +188,9 @@ int mdp_destroy(mdp_ctx *c)
   c->lj_off.release();
   c->lj_cnt.release();
   c->lj_split.release();
+  c->cl_flag.release();
+  c->cl_pos.release();
+  c->cl_order.release();
   c->lj.release();
   c->is_center.release();
   c->class_list.release();

@@ -131,6 +131,10 @@ struct mdp_ctx {
   DevBuf<int> lj;                 // union neighbours (r <= rcLJmax+skin of ANY atom of the cluster)
   long long lj_total = 0;
   int nclus = 0, cluster = MDP_CLUSTER;
+  // halo overlap (multi-GPU): clusters whose lists reach no remote ghost come first in cl_order
+  int remote_start = 1 << 30, nclus_interior = 0;
+  bool split_halo = false;
+  DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
   DevBuf<int> is_center;          // [nall]
   DevBuf<int> class_list;         // [4][nall]
@@ -204,6 +208,8 @@ int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // 
 int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n);
 int mdp_rebomos_repack(mdp_ctx *c);
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
+int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag);
+int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag);
 int mdp_aeam_prepare(mdp_ctx *c);
 int mdp_aeam_run_density(mdp_ctx *c, int eflag);
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);

@@ -24,6 +24,9 @@
 
 namespace {
 
+#ifndef MDP_LJ_WAVES
+#define MDP_LJ_WAVES 4
+#endif
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTol = 1.0e-9; // pair_rebomos.cpp:52
 
@@ -608,40 +611,45 @@ __device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, con
 {
   const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
   const double rsq = dx * dx + dy * dy + dz * dz;
-  if (rsq >= q.lo && rsq <= q.hi) { // FLJ windows
-    double fpair, V = 0.0;
-    if (rsq >= q.sw) {
-      const double r2inv = fast_rcp(rsq);
-      const double r6inv = r2inv * r2inv * r2inv;
-      if (EV) V = r6inv * (q.c3 * r6inv - q.c4);
-      fpair = r6inv * (q.c1 * r6inv - q.c2) * r2inv;
-    } else { // cubic inner spline, rare: parameters fetched here
+  // FLJ windows (pair_rebomos.cpp:518-543).  The 12-6 branch is evaluated without divergence and
+  // selected by the window predicate, so the independent evaluations of a lane interleave; the cubic
+  // inner spline (rcLJmin <= r < 0.95 sigma, empty in the equilibrium crystal) sits behind a wave-uniform test.
+  const bool inwin = rsq >= q.lo && rsq <= q.hi;
+  const double r2inv = fast_rcp(inwin ? rsq : 1.0);
+  const double r6inv = r2inv * r2inv * r2inv;
+  double fpair = inwin ? r6inv * (q.c1 * r6inv - q.c2) * r2inv : 0.0;
+  double V = 0.0;
+  if (EV) V = inwin ? r6inv * (q.c3 * r6inv - q.c4) : 0.0;
+  const bool cubic = inwin && rsq < q.sw;
+  if (__any(cubic)) {
+    if (cubic) {
       const double rij = sqrt(rsq);
       const double drp = rij - P.rcLJmin[pt];
       if (EV) V = drp * drp * (drp * P.ljc3[pt] + P.ljc2[pt]);
       fpair = -drp * (3.0 * drp * P.ljc3[pt] + 2.0 * P.ljc2[pt]) / rij;
     }
-    fx += dx * fpair;
-    fy += dy * fpair;
-    fz += dz * fpair;
-    if (EV) {
-      e += 0.5 * V; // both directions of every pair are visited: half the energy each
-      if (vflag) {
-        const double h = 0.5 * fpair;
-        v0 += dx * dx * h;
-        v1 += dy * dy * h;
-        v2 += dz * dz * h;
-        v3 += dx * dy * h;
-        v4 += dx * dz * h;
-        v5 += dy * dz * h;
-      }
+  }
+  fx += dx * fpair;
+  fy += dy * fpair;
+  fz += dz * fpair;
+  if (EV) {
+    e += 0.5 * V; // both directions of every pair are visited: half the energy each
+    if (vflag) {
+      const double h = 0.5 * fpair;
+      v0 += dx * dx * h;
+      v1 += dy * dy * h;
+      v2 += dz * dz * h;
+      v3 += dx * dy * h;
+      v4 += dx * dz * h;
+      v5 += dy * dz * h;
     }
   }
 }
 
-template <int CL, int L, bool EV, int U = 2>
-__global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
-    const RebomosDev P, const int nlocal, const int nclus, const double4 *__restrict__ xq,
+template <int CL, int L, bool EV, bool GATHER, int U = 2>
+__global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
+    const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
+    const double4 *__restrict__ xq,
     const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const int *__restrict__ lj,
     const int *__restrict__ cand_off, const unsigned long long *__restrict__ amask, const int *__restrict__ rev,
     const double *__restrict__ fnbr, const double *__restrict__ eslot, double *__restrict__ f,
@@ -654,7 +662,8 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
   const int s = lane % L;
   const long long k64 = (long long) blockIdx.x * (256 / L) + tid / L;
   const bool have = k64 < nclus;
-  const int kc = have ? (int) k64 : 0;
+  // clusters are taken in the order of the interior/boundary partition (or as they come when order == null)
+  const int kc = have ? (order ? order[first + (int) k64] : first + (int) k64) : 0;
 
   double4 xa[CL];
   int ta[CL];
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
     real[c] = have && ia < nlocal;
     xa[c] = xq[ia < nlocal ? ia : nlocal - 1];
     ta[c] = (int) xa[c].w;
+    if (!real[c]) xa[c].x = -1.0e30; // padding atom of the last cluster: outside every window
     fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
   }
 
@@ -691,8 +701,12 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
         const int k = kb + u * L + s;
         j0[u] = k < ke ? row[k] : -1;
       }
+      // padding entries (j < 0) are moved far away: they fall outside every window without a branch
 #pragma unroll
-      for (int u = 0; u < U; u++) x0[u] = xq[j0[u] >= 0 ? j0[u] : self];
+      for (int u = 0; u < U; u++) {
+        x0[u] = xq[j0[u] >= 0 ? j0[u] : self];
+        x0[u].x = j0[u] >= 0 ? x0[u].x : 1.0e30;
+      }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int k = kb + U * L + u * L + s;
@@ -702,7 +716,10 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
         double4 x1[U];
         int j2[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) x1[u] = xq[j1[u] >= 0 ? j1[u] : self];
+        for (int u = 0; u < U; u++) {
+          x1[u] = xq[j1[u] >= 0 ? j1[u] : self];
+          x1[u].x = j1[u] >= 0 ? x1[u].x : 1.0e30;
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int k = k0 + 2 * U * L + u * L + s;
@@ -710,12 +727,10 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          if (j0[u] < 0) continue;
 #pragma unroll
           for (int c = 0; c < CL; c++)
-            if (real[c])
-              lj_pair<EV>(P, q[c], ta[c] * 2 + seg, xa[c], x0[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3,
-                          v4, v5);
+            lj_pair<EV>(P, q[c], ta[c] * 2 + seg, xa[c], x0[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4,
+                        v5);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -728,13 +743,13 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
   }
   double e_lj = 0.0;
 #pragma unroll
-  for (int c = 0; c < CL; c++) e_lj += ee[c];
+  for (int c = 0; c < CL; c++) e_lj += real[c] ? ee[c] : 0.0;
 
   // ---- gather the REBO cluster forces: own centre (-sum of slot forces) + neighbour centres.
   // Slot (a,t) is active iff bit t of amask[a]; the REBO relation is symmetric, so the reverse slot
   // rev[a][t] (static between list builds) is active too and holds what centre j pushes onto a.
   // L/CL lanes work on each atom of the cluster.
-  {
+  if (GATHER) {
     const int mine = s % CL;
     const int ia = kc * CL + mine;
     if (have && ia < nlocal) {
@@ -819,6 +834,85 @@ __global__ __launch_bounds__(256) void rebo_lj_gather_kernel(
       atomicAdd(&slot[6], v5);
     }
   }
+}
+
+// REBO slot-force gather alone: f[a] += -sum_t fnbr[a][t] + sum_t fnbr[rev[a][t]] (and the per-atom REBO
+// energy).  Used when the Lennard-Jones kernel runs in two parts around the halo exchange.
+template <int L>
+__global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, const int *__restrict__ cand_off,
+                                                          const unsigned long long *__restrict__ amask,
+                                                          const int *__restrict__ rev,
+                                                          const double *__restrict__ fnbr,
+                                                          const double *__restrict__ eslot, double *__restrict__ f,
+                                                          double *__restrict__ eatom, const int eflag)
+{
+  const int s = threadIdx.x % L;
+  const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = a64 < nlocal;
+  const int ia = have ? (int) a64 : 0;
+  double gx = 0, gy = 0, gz = 0, ge = 0;
+  if (have) {
+    const int off = cand_off[ia];
+    const int nc = cand_off[ia + 1] - off;
+    const unsigned long long act = amask[ia];
+    for (int t = s; t < nc; t += L) {
+      if (!((act >> t) & 1ull)) continue;
+      const int ra = rev[off + t];
+      const double *o = fnbr + 3 * (size_t) (off + t);
+      gx -= o[0];
+      gy -= o[1];
+      gz -= o[2];
+      if (ra >= 0) {
+        const double *oj = fnbr + 3 * (size_t) ra;
+        gx += oj[0];
+        gy += oj[1];
+        gz += oj[2];
+        if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+      }
+    }
+  }
+  gx = group_sum<L>(gx);
+  gy = group_sum<L>(gy);
+  gz = group_sum<L>(gz);
+  if (eflag & MDP_EFLAG_ATOM) ge = group_sum<L>(ge);
+  if (have && s == 0) {
+    double *fo = f + 3 * (size_t) ia;
+    fo[0] += gx;
+    fo[1] += gy;
+    fo[2] += gz;
+    if (eflag & MDP_EFLAG_ATOM) eatom[ia] += ge;
+  }
+}
+
+// does the cluster's list reach a remote ghost (index >= remote_start)?  Such clusters wait for the halo.
+__global__ __launch_bounds__(256) void cluster_boundary_kernel(const int nclus, const int remote_start,
+                                                               const long long *__restrict__ lj_off,
+                                                               const int *__restrict__ lj, int *__restrict__ is_int,
+                                                               int *__restrict__ is_bnd)
+{
+  constexpr int L = 16;
+  const int s = threadIdx.x % L;
+  const long long k64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = k64 < nclus;
+  const int k = have ? (int) k64 : 0;
+  int hit = 0;
+  if (have)
+    for (long long q = lj_off[k] + s; q < lj_off[k + 1]; q += L) hit |= lj[q] >= remote_start;
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) hit |= __shfl_xor(hit, o, 64);
+  if (have && s == 0) {
+    is_int[k] = !hit;
+    is_bnd[k] = hit;
+  }
+}
+
+__global__ void cluster_order_kernel(const int nclus, const int nint, const int *__restrict__ is_int,
+                                     const int *__restrict__ pos_int, const int *__restrict__ pos_bnd,
+                                     int *__restrict__ order)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nclus) return;
+  order[is_int[k] ? pos_int[k] : nint + pos_bnd[k]] = k; // stable: Morton locality survives inside each part
 }
 
 // cluster pair list straight from the bin grid: every atom j within rcLJmax+skin of ANY atom of the
@@ -1268,6 +1362,28 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
+  // interior / boundary partition of the clusters (only meaningful with remote ghosts)
+  c->nclus_interior = nclus;
+  c->split_halo = false;
+  if (c->md && c->remote_start < nall && nclus > 0) {
+    MDP_HIP(c, c->cl_flag.reserve((size_t) 2 * (nclus + 1)));
+    MDP_HIP(c, c->cl_pos.reserve((size_t) 2 * (nclus + 2)));
+    MDP_HIP(c, c->cl_order.reserve(nclus + 1));
+    int *is_int = c->cl_flag.p, *is_bnd = c->cl_flag.p + (nclus + 1);
+    int *pos_int = c->cl_pos.p, *pos_bnd = c->cl_pos.p + (nclus + 2);
+    cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p, is_int,
+                                                               is_bnd);
+    MDP_HIP(c, hipGetLastError());
+    MDP_TRY(mdp_scan_exclusive_int(c, is_int, pos_int, nclus));
+    MDP_TRY(mdp_scan_exclusive_int(c, is_bnd, pos_bnd, nclus));
+    int nint = 0;
+    MDP_HIP(c, hipMemcpyAsync(&nint, pos_int + nclus, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipStreamSynchronize(st));
+    cluster_order_kernel<<<(nclus + 255) / 256, 256, 0, st>>>(nclus, nint, is_int, pos_int, pos_bnd, c->cl_order.p);
+    MDP_HIP(c, hipGetLastError());
+    c->nclus_interior = nint;
+    c->split_halo = true;
+  }
   if (nall)
     classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
                                                         c->is_center.p, c->class_list.p, c->class_count.p);
@@ -1356,7 +1472,55 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
-int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
+static void launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, int vflag, bool accumulate)
+{
+  if (count <= 0) return;
+  hipStream_t st = c->stream;
+  constexpr int L = 16;
+  const int grid = (count + 256 / L - 1) / (256 / L);
+  const int *order = c->split_halo ? c->cl_order.p : nullptr;
+  const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
+#define MDP_LJ(CLV, EVV, GV)                                                                                        \
+  rebo_lj_gather_kernel<CLV, L, EVV, GV><<<grid, 256, 0, st>>>(                                                      \
+      c->rebomos, c->nlocal, order, first, count, c->xq.p, c->lj_off.p, c->lj_split.p, c->lj.p, c->cand_off.p,       \
+      c->amask.p, c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0)
+#define MDP_LJ2(CLV)                                                                                                \
+  do {                                                                                                              \
+    if (ev && gather) MDP_LJ(CLV, true, true);                                                                      \
+    else if (ev) MDP_LJ(CLV, true, false);                                                                          \
+    else if (gather) MDP_LJ(CLV, false, true);                                                                      \
+    else MDP_LJ(CLV, false, false);                                                                                 \
+  } while (0)
+  if (c->cluster == 1) MDP_LJ2(1);
+  else if (c->cluster == 4) MDP_LJ2(4);
+  else MDP_LJ2(2);
+#undef MDP_LJ2
+#undef MDP_LJ
+}
+
+static int launch_centres(mdp_ctx *c, int eflag, int vflag)
+{
+  hipStream_t st = c->stream;
+  MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));
+  launch_centre<4>(c, 0, eflag, vflag);
+  launch_centre<8>(c, 1, eflag, vflag);
+  launch_centre<16>(c, 2, eflag, vflag);
+  launch_centre<32>(c, 3, eflag, vflag);
+  // centres that outgrew their lane group since the last build (normally none: the kernel reads the
+  // count from the device and exits)
+  const int total = c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
+  const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
+  if (grid)
+    rebo_centre_general_kernel<<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, c->nlocal, c->xq.p, c->cand_off.p,
+                                                     c->cand.p, c->amask.p, c->fnbr.p, c->eslot.p, c->acc.p,
+                                                     c->flags.p, eflag, vflag);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// First half of compute(): everything that does not need this step's REMOTE ghost positions -- the list
+// upkeep and the Lennard-Jones work of the interior clusters.  Runs while the halo exchange is in flight.
+int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 {
   if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "rebomos: per-atom virial is not implemented on the device");
   if (c->rebo_packed) {
@@ -1365,53 +1529,37 @@ int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
     if (stale) c->rebo_packed = false;
   }
   if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
-  hipStream_t st = c->stream;
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
-  MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));
   mdp_time_mark(c, 0);
-  launch_centre<4>(c, 0, eflag, vflag);
-  launch_centre<8>(c, 1, eflag, vflag);
-  launch_centre<16>(c, 2, eflag, vflag);
-  launch_centre<32>(c, 3, eflag, vflag);
-  {
-    // centres that outgrew their lane group since the last build (normally none: the kernel reads the
-    // count from the device and exits)
-    const int total = c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
-    const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
-    if (grid)
-      rebo_centre_general_kernel<<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, c->nlocal, c->xq.p, c->cand_off.p,
-                                                       c->cand.p, c->amask.p, c->fnbr.p, c->eslot.p, c->acc.p,
-                                                       c->flags.p, eflag, vflag);
-  }
+  if (c->split_halo) launch_lj(c, 0, c->nclus_interior, /*gather=*/false, eflag, vflag, /*accumulate=*/false);
   MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// Second half: REBO centre kernels, boundary clusters, slot-force gather (or, without remote ghosts, the
+// fused Lennard-Jones + gather kernel over all clusters).
+int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
+{
+  hipStream_t st = c->stream;
+  MDP_TRY(launch_centres(c, eflag, vflag));
   mdp_time_mark(c, 1);
-  {
-    int variant = 0; // tuning hook: MDP_LJ_VARIANT = 0..5 -> (L,U) = (16,2) (8,2) (32,2) (16,4) (8,4) (16,3)
-    if (const char *e = getenv("MDP_LJ_VARIANT")) variant = atoi(e);
-    const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
-#define MDP_LJ(CLV, LV, EVV, UV)                                                                                    \
-  rebo_lj_gather_kernel<CLV, LV, EVV, UV><<<(c->nclus + 256 / LV - 1) / (256 / LV), 256, 0, st>>>(                    \
-      c->rebomos, c->nlocal, c->nclus, c->xq.p, c->lj_off.p, c->lj_split.p, c->lj.p, c->cand_off.p, c->amask.p,      \
-      c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, zero_f ? 0 : 1)
-#define MDP_LJ2(CLV, LV, UV)                                                                                        \
-  do {                                                                                                              \
-    if (ev) MDP_LJ(CLV, LV, true, UV);                                                                              \
-    else MDP_LJ(CLV, LV, false, UV);                                                                                \
-  } while (0)
-    if (c->nclus > 0) {
-      if (c->cluster == 1) MDP_LJ2(1, 16, 2);
-      else if (c->cluster == 4) MDP_LJ2(4, 16, 2);
-      else if (variant == 1) MDP_LJ2(2, 8, 2);
-      else if (variant == 2) MDP_LJ2(2, 32, 2);
-      else if (variant == 3) MDP_LJ2(2, 16, 4);
-      else if (variant == 4) MDP_LJ2(2, 8, 4);
-      else if (variant == 5) MDP_LJ2(2, 16, 3);
-      else MDP_LJ2(2, 16, 2);
-    }
-#undef MDP_LJ2
-#undef MDP_LJ
+  if (c->split_halo) {
+    launch_lj(c, c->nclus_interior, c->nclus - c->nclus_interior, false, eflag, vflag, false);
+    if (c->nlocal)
+      rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
+                                                                   c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, eflag);
+  } else {
+    launch_lj(c, 0, c->nclus, /*gather=*/true, eflag, vflag, false);
   }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 2);
   return mdp_acc_end(c, eflag || vflag);
+}
+
+// force_clear + compute on the device; results stay on the device (f, eatom, acc)
+int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f)
+{
+  (void) zero_f; // owned forces are always overwritten; the host-mode caller adds them on the host
+  MDP_TRY(mdp_rebomos_run_begin(c, eflag, vflag));
+  return mdp_rebomos_run_end(c, eflag, vflag);
 }

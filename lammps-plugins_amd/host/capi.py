@@ -35,7 +35,8 @@ class MdConfig(C.Structure):
     """mirror of mdp_md_config"""
     _fields_ = [("style", C.c_int), ("nlocal", C.c_int), ("nghost", C.c_int), ("ntypes", C.c_int),
                 ("skin", C.c_double), ("dt", C.c_double), ("ftm2v", C.c_double), ("mvv2e", C.c_double),
-                ("bbox_lo", C.c_double * 3), ("bbox_hi", C.c_double * 3), ("master_list", C.c_int)]
+                ("bbox_lo", C.c_double * 3), ("bbox_hi", C.c_double * 3), ("nghost_self", C.c_int),
+                ("master_list", C.c_int)]
 
 
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
@@ -45,7 +46,7 @@ EXPORTS = [
     "mdp_aeam_set_tables", "mdp_aeam_file_read", "mdp_aeam_file_info", "mdp_aeam_file_build", "mdp_aeam_file_free", "mdp_set_atoms_host", "mdp_set_positions_host",
     "mdp_set_neighbors_host", "mdp_set_skin", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
     "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
-    "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
+    "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
     "mdp_md_neighbor_stats", "mdp_set_timing", "mdp_get_timing",
@@ -271,6 +272,12 @@ class Context:
 
     def md_compute(self, eflag=0, vflag=0):
         self._ck(self.L.mdp_md_compute(self.h, C.c_int(eflag), C.c_int(vflag)))
+
+    def md_compute_begin(self, eflag=0, vflag=0):
+        self._ck(self.L.mdp_md_compute_begin(self.h, C.c_int(eflag), C.c_int(vflag)))
+
+    def md_compute_end(self, eflag=0, vflag=0):
+        self._ck(self.L.mdp_md_compute_end(self.h, C.c_int(eflag), C.c_int(vflag)))
 
     def md_aeam_density(self, eflag=0):
         self._ck(self.L.mdp_md_aeam_density(self.h, C.c_int(eflag)))

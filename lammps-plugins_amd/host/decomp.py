@@ -119,19 +119,18 @@ class Halo:
         self.in1 = [int(c) for c in plan.send_counts]
         self.out1 = [int(c) for c in plan.recv_counts]
 
-    def _a2a(self, out, inp, out_splits, in_splits):
+    def _a2a(self, out, inp, out_splits, in_splits, async_op=False):
         if not self.stage_host:
-            self.dist.all_to_all_single(out, inp, out_splits, in_splits)
-            return
+            return self.dist.all_to_all_single(out, inp, out_splits, in_splits, async_op=async_op)
         self.torch.cuda.synchronize()
         o, i = out.cpu(), inp.cpu()
         self.dist.all_to_all_single(o, i, out_splits, in_splits)
         out.copy_(o)
         self.torch.cuda.synchronize()
 
-    def forward3(self):
-        """send3 (packed owned positions+shift) -> recv3 (remote ghosts)"""
-        self._a2a(self.recv3[:self.nrecv * 3], self.send3[:self.nsend * 3], self.out3, self.in3)
+    def forward3(self, async_op=False):
+        """send3 (packed owned positions+shift) -> recv3 (remote ghosts); async_op returns the work handle"""
+        return self._a2a(self.recv3[:self.nrecv * 3], self.send3[:self.nsend * 3], self.out3, self.in3, async_op)
 
     def forward1(self):
         self._a2a(self.recv1[:self.nrecv], self.send1[:self.nsend], self.out1, self.in1)

@@ -52,6 +52,7 @@ class Domain:
         cfg.style, cfg.nlocal, cfg.nghost, cfg.ntypes = style, self.nlocal, self.nghost, len(mass) - 1
         cfg.skin, cfg.dt, cfg.ftm2v, cfg.mvv2e = skin, dt, S.FTM2V, S.MVV2E
         cfg.master_list = 1 if master_list else 0
+        cfg.nghost_self = int((np.asarray(ghost_owner) >= 0).sum()) if self.nghost else 0
         lo, hi = allx.min(axis=0) - pad, allx.max(axis=0) + pad
         for d in range(3):
             cfg.bbox_lo[d], cfg.bbox_hi[d] = lo[d], hi[d]
@@ -140,6 +141,24 @@ class RankDomain(Domain):
         h.forward3()
         self.ctx.md_unpack_x(self.plan.nself, h.nrecv, h.recv3.data_ptr())
 
+    def step_overlapped(self, eflag=0, vflag=0):
+        """one step with the ghost-position exchange hidden behind the interior Lennard-Jones work
+        (REBO-MoS): pack -> all_to_all (async) || compute_begin -> wait -> unpack -> compute_end"""
+        h = self.halo
+        self.ctx.md_initial_integrate()
+        active = h is not None and (h.nsend or h.nrecv)
+        work = None
+        if active:
+            self.ctx.md_pack_x(h.nsend, h.sendlist.data_ptr(), h.sendshift.data_ptr(), h.send3.data_ptr())
+            work = h.forward3(async_op=True)
+        self.ctx.md_compute_begin(eflag, vflag)
+        if active:
+            if work is not None:
+                work.wait()
+            self.ctx.md_unpack_x(self.plan.nself, h.nrecv, h.recv3.data_ptr())
+        self.ctx.md_compute_end(eflag, vflag)
+        self.ctx.md_final_integrate()
+
     def forward_fp(self):
         h = self.halo
         if h is None or (h.nsend == 0 and h.nrecv == 0):
@@ -167,6 +186,8 @@ class RankDomain(Domain):
             self.reverse_forces()
 
     def step(self, eflag=0, vflag=0):
+        if self.style == capi.STYLE_REBOMOS:
+            return self.step_overlapped(eflag, vflag)
         self.ctx.md_initial_integrate()
         self.forward_positions()
         self.compute(eflag, vflag)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # 8 pair tables + b,bg (7x2) + a (4x2) + 8 pair tables, all doubles
     assert ctypes.sizeof(capi.RebomosParams) == 8 * (4 * 8 + 14 + 14 + 8 + 4 * 8)
-    assert ctypes.sizeof(capi.MdConfig) == 4 * 4 + 8 * 4 + 8 * 6 + 8   # + master_list (int, padded)
+    assert ctypes.sizeof(capi.MdConfig) == 4 * 4 + 8 * 4 + 8 * 6 + 8   # + nghost_self, master_list
 
 
 def test_no_cpu_fallback_without_gpu():
