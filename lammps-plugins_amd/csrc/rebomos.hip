@@ -676,7 +676,11 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
     real[c] = have && ia < nlocal;
     xa[c] = xq[ia < nlocal ? ia : nlocal - 1];
     ta[c] = (int) xa[c].w;
-    if (!real[c]) xa[c].x = -1.0e30; // padding atom of the last cluster: outside every window
+    if (ta[c] < 0) { // type mapped to NULL: takes part in nothing
+      real[c] = false;
+      ta[c] = 0;
+    }
+    if (!real[c]) xa[c].x = -1.0e30; // padding / NULL atom: outside every window
     fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
   }
 
@@ -995,8 +999,9 @@ __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, con
 #pragma unroll
           for (int c = 0; c < CL; c++) {
             const double dx = xa[c].x - xj.x, dy = xa[c].y - xj.y, dz = xa[c].z - xj.z;
-            keep = keep || (dx * dx + dy * dy + dz * dz <= P.ljlist_cutsq[ta[c] * 2 + tj]);
+            keep = keep || (ta[c] >= 0 && dx * dx + dy * dy + dz * dz <= P.ljlist_cutsq[ta[c] * 2 + tj]);
           }
+          keep = keep && tj >= 0; // NULL-mapped neighbours are invisible to this style
           k0 = keep && tj == 0;
           k1 = keep && tj != 0;
         }
@@ -1043,6 +1048,7 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
   if (MODE == 2 && have && off[i + 1] == off[i]) have = false;
   const double4 xi = xq[i];
   const int ti = (int) xi.w;
+  if (ti < 0) have = false; // type mapped to NULL (pair_rebomos.cpp:169-171): not part of this style
   int cx = (int) ((xi.x - g.lo[0]) * g.inv[0]), cy = (int) ((xi.y - g.lo[1]) * g.inv[1]),
       cz = (int) ((xi.z - g.lo[2]) * g.inv[2]);
   cx = cx < 0 ? 0 : (cx >= g.n[0] ? g.n[0] - 1 : cx);
@@ -1082,7 +1088,8 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
           j = perm[p];
           const double4 xj = xq[j];
           const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-          keep = j != i && (dx * dx + dy * dy + dz * dz) <= P.cand_cutsq[ti * 2 + (int) xj.w];
+          const int tj = (int) xj.w;
+          keep = j != i && tj >= 0 && (dx * dx + dy * dy + dz * dz) <= P.cand_cutsq[ti * 2 + tj];
         }
         const unsigned long long bk = (__ballot(keep) >> glane0) & 0xFFFFull;
         if (keep) {

@@ -148,8 +148,7 @@ void PairREBOMoS::init_style()
 {
   if (atom->tag_enable == 0) error->all(FLERR, "Pair style REBOMoS requires atom IDs");
   if (force->newton_pair == 0) error->all(FLERR, "Pair style REBOMoS requires newton pair on");
-  for (int i = 1; i <= atom->ntypes; i++)
-    if (map[i] < 0) error->all(FLERR, "Pair style rebomos (MI355X) does not support NULL-mapped atom types yet");
+  // atom types mapped to NULL (pair hybrid) are invisible to the device lists: map[] = -1 goes down as is
 
   // full neighbor list including neighbors of ghosts (pair_rebomos.cpp:218)
   neighbor->add_request(this, NeighConst::REQ_FULL | NeighConst::REQ_GHOST);

@@ -155,3 +155,24 @@ def test_centres_that_outgrow_their_lane_group_between_list_builds(ctx, oracle, 
     assert np.abs(g_hi["f"] - o_hi["f_owned"]).max() < 1e-8
     assert g_hi["eng"] == pytest.approx(o_hi["eng"], rel=1e-10)
     assert np.abs(g_hi["eatom"] - o_hi["eatom_owned"]).max() < 1e-8
+
+
+def test_null_mapped_types_are_invisible(ctx, oracle, P):
+    """`pair_coeff * * file Mo S NULL` (pair hybrid): atoms of the NULL type take no part
+    (pair_rebomos.cpp:169-171).  The device builds its own lists, so it must filter them itself:
+    compare with the oracle run on the system without those atoms."""
+    s = S.jitter(S.rebomos_bulk_cell(), 0.05, seed=41)
+    rng = np.random.default_rng(42)
+    extra = S.wrap(s.box, s.box.lamda2x(rng.random((40, 3))))          # 40 inert atoms anywhere in the cell
+    x3 = np.concatenate([s.x, extra])
+    t3 = np.concatenate([s.type, np.full(40, 3, dtype=np.int32)])
+    s3 = S.System(s.box, x3, t3, np.arange(1, len(x3) + 1, dtype=np.int32), np.array([0.0, 95.95, 32.065, 1.0]))
+    x_all, type_all, tag_all, owner, shift, nlocal, nghost = S.with_ghosts(s3, P.cut3rebo + 2.0)
+    ctx.set_atoms_host(nlocal, x_all, type_all, tag_all, 3, map_=[0, 0, 1, -1])
+    ctx.set_skin(2.0)
+    g = ctx.rebomos_compute_host(nlocal)
+    o = mdref.RebomosCPU(oracle, P, s).compute(s.x)
+    assert np.abs(g["f"][:s.n] - o["f_owned"]).max() < F_TOL
+    assert not g["f"][s.n:].any() and not g["eatom"][s.n:].any()
+    assert g["eng"] == pytest.approx(o["eng"], rel=1e-10)
+    assert np.abs(g["eatom"][:s.n] - o["eatom_owned"]).max() < E_TOL
