@@ -36,7 +36,7 @@ enum {
   MDP_EHIP = -2,      /* HIP runtime error (text in mdp_last_error)                  */
   MDP_ENOMEM = -3,
   MDP_EOVERFLOW = -4, /* "Neighbor list overflow, boost neigh_modify one" (pair_rebomos.cpp:350) */
-  MDP_ENOTIMPL = -5,  /* e.g. per-atom virial (vflag&4) is not built yet             */
+  MDP_ENOTIMPL = -5,  /* feature not available                                       */
   MDP_ESTATE = -6     /* potential / atoms / neighbors not set                       */
 };
 
@@ -134,9 +134,11 @@ int mdp_set_neighbors_csr_host(mdp_ctx *ctx, int nall, const int *numneigh, cons
  * f[nlocal][3] and eatom[nlocal] are ACCUMULATED into (LAMMPS zeroes them); forces are complete
  * for owned atoms (owner-computes: nothing is written to ghosts, so the host's reverse_comm adds
  * zeros).  virial[6] is the explicit pair virial (xx,yy,zz,xy,xz,yz) of this rank's owned atoms,
- * to be used with no_virial_fdotr = 1.  Any of eng/virial/eatom may be NULL. */
+ * to be used with no_virial_fdotr = 1.  vatom[nlocal][6] (vflag & 4) is the per-atom virial in the
+ * reference's split (ev_tally halves, v_tally3 thirds, v_tally2 halves: pair_rebomos.cpp:444,554,707-725),
+ * complete for owned atoms.  Any of eng/virial/eatom/vatom may be NULL. */
 int mdp_rebomos_compute_host(mdp_ctx *ctx, int eflag, int vflag, double *f, double *eng_vdwl, double *virial,
-                             double *eatom);
+                             double *eatom, double *vatom);
 
 /* replaces PairAEAM::compute (pair_aeam.cpp:110-479) in two halves around the style's own
  * forward_comm (pair_aeam.cpp:307):
@@ -144,10 +146,11 @@ int mdp_rebomos_compute_host(mdp_ctx *ctx, int eflag, int vflag, double *f, doub
  *             neighbors need, adds the embedding energy to *eng_vdwl / eatom.
  *   force:    pass 3; fp_all[nall] must hold the owners' values on ghosts (after forward_comm).
  *             f[nall][3] is accumulated into: owned atoms fully, ghosts only with the angular
- *             three-body terms (folded by the host's reverse_comm). */
+ *             three-body terms (folded by the host's reverse_comm).  vatom[nall][6] (vflag & 4, may be
+ *             NULL) follows ev_tally / ev_tally3 (pair_aeam.cpp:393,472): halves / thirds, ghosts as for f. */
 int mdp_aeam_density_host(mdp_ctx *ctx, int eflag, double *fp, double *rho, double *eng_vdwl, double *eatom);
 int mdp_aeam_force_host(mdp_ctx *ctx, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
-                        double *virial, double *eatom);
+                        double *virial, double *eatom, double *vatom);
 
 /* ---- resident mode: device-side MD around the hot path -------------------------------------
  * (neighbor build, integrator, thermo.)  One sub-domain per context. */

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
                                                          const long long *__restrict__ nb_off,
                                                          const int *__restrict__ nb, const double *__restrict__ fp,
                                                          double *__restrict__ f, double *__restrict__ eatom,
-                                                         double *__restrict__ acc, const int eflag, const int vflag)
+                                                         double *__restrict__ vatom, double *__restrict__ acc,
+                                                         const int eflag, const int vflag)
 {
   constexpr int U = 2;
   const int lane = threadIdx.x & 63;
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
   const bool a_metal = ta < A.nnonangular;
   const double qa = a_metal ? fp[a] : 0.0; // (1 - deli) Fptmp fp
   double fx = 0, fy = 0, fz = 0, e = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0; // per-atom virial of atom a (vflag_atom)
   if (have) {
     const PairPar<NT> qA = load_pairpar<NT>(A, ta, false); // visit (i=a, j): tables of the pair (ta,tj)
     const PairPar<NT> qJ = load_pairpar<NT>(A, ta, true);  // visit (i=j, a): tables of the pair (tj,ta)
@@ -369,6 +371,15 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
           v3 += dx * dy * fpair_a;
           v4 += dx * dz * fpair_a;
           v5 += dy * dz * fpair_a;
+          if (vflag & MDP_VFLAG_ATOM) { // each visit gives half its virial to either end: a collects both
+            const double h = 0.5 * ft;
+            a0 += dx * dx * h;
+            a1 += dy * dy * h;
+            a2 += dz * dz * h;
+            a3 += dx * dy * h;
+            a4 += dx * dz * h;
+            a5 += dy * dz * h;
+          }
         }
       }
     }
@@ -388,6 +399,23 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
     if (eflag & MDP_EFLAG_ATOM) {
       const double ea = lane_sum<L>(e);
       if (have && s == 0) eatom[a] += ea;
+    }
+    if (vflag & MDP_VFLAG_ATOM) {
+      a0 = lane_sum<L>(a0);
+      a1 = lane_sum<L>(a1);
+      a2 = lane_sum<L>(a2);
+      a3 = lane_sum<L>(a3);
+      a4 = lane_sum<L>(a4);
+      a5 = lane_sum<L>(a5);
+      if (have && s == 0) { // plain stores: the angular kernel (atomics) runs after this one
+        double *va = vatom + 6 * (size_t) a;
+        va[0] += a0;
+        va[1] += a1;
+        va[2] += a2;
+        va[3] += a3;
+        va[4] += a4;
+        va[5] += a5;
+      }
     }
     double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
     if (eflag & MDP_EFLAG_GLOBAL) {
@@ -419,8 +447,9 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
                                                              const double4 *__restrict__ xq,
                                                              const long long *__restrict__ nb_off,
                                                              const int *__restrict__ nb, const double *__restrict__ fp,
-                                                             double *__restrict__ f, double *__restrict__ acc,
-                                                             int *__restrict__ flags, const int vflag)
+                                                             double *__restrict__ f, double *__restrict__ vatom,
+                                                             double *__restrict__ acc, int *__restrict__ flags,
+                                                             const int vflag)
 {
   __shared__ double s_rec[4][ANG_CAP * AREC];
   __shared__ int s_j[4][ANG_CAP];
@@ -471,12 +500,24 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
       fiy -= gjy + gky;
       fiz -= gjz + gkz;
       if (vflag) { // ev_tally3(i,j,k,0,0,fj,fk,drji,drki)
-        v0 += qa[0] * gjx + qb[0] * gkx;
-        v1 += qa[1] * gjy + qb[1] * gky;
-        v2 += qa[2] * gjz + qb[2] * gkz;
-        v3 += qa[0] * gjy + qb[0] * gky;
-        v4 += qa[0] * gjz + qb[0] * gkz;
-        v5 += qa[1] * gjz + qb[1] * gkz;
+        const double t0 = qa[0] * gjx + qb[0] * gkx, t1 = qa[1] * gjy + qb[1] * gky, t2 = qa[2] * gjz + qb[2] * gkz;
+        const double t3 = qa[0] * gjy + qb[0] * gky, t4 = qa[0] * gjz + qb[0] * gkz, t5 = qa[1] * gjz + qb[1] * gkz;
+        v0 += t0;
+        v1 += t1;
+        v2 += t2;
+        v3 += t3;
+        v4 += t4;
+        v5 += t5;
+        if (vflag & MDP_VFLAG_ATOM) { // a third each to i, j, k (angular centres are rare: atomics)
+          const double tt[6] = {t0 * third, t1 * third, t2 * third, t3 * third, t4 * third, t5 * third};
+          const int jj = jdx[a] & MDP_NEIGHMASK;
+#pragma unroll
+          for (int q6 = 0; q6 < 6; q6++) {
+            atomicAdd(&vatom[6 * (size_t) i + q6], tt[q6]);
+            atomicAdd(&vatom[6 * (size_t) jj + q6], tt[q6]);
+            atomicAdd(&vatom[6 * (size_t) kk + q6], tt[q6]);
+          }
+        }
       }
     }
     fjx = lane_sum<64>(fjx);
@@ -591,16 +632,19 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
 // centres put on our atoms; ghost forces hold our angular centres' contributions.
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
 {
-  if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "aeam: per-atom virial is not implemented on the device");
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
   MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, st));
+  if (vflag & MDP_VFLAG_ATOM) {
+    MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
+    MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, st));
+  }
   if (nlocal) {
     const int grid = nblk(nlocal, 256 / AE_L);
     const bool ev = eflag || vflag;
 #define MDP_AF(NTV, EVV)                                                                                              \
   aeam_force_kernel<AE_L, NTV, EVV><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->fp.p,      \
-                                                          c->f.p, c->eatom.p, c->acc.p, eflag, vflag)
+                                                          c->f.p, c->eatom.p, c->vatom.p, c->acc.p, eflag, vflag)
     switch (c->aeam.ntypes) {
       case 1: if (ev) MDP_AF(1, true); else MDP_AF(1, false); break;
       case 2: if (ev) MDP_AF(2, true); else MDP_AF(2, false); break;
@@ -611,8 +655,8 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
   }
   if (c->h_ang_count)
     aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
-                                                                   c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->acc.p,
-                                                                   c->flags.p, vflag);
+                                                                   c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->vatom.p,
+                                                                   c->acc.p, c->flags.p, vflag);
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 3);
   return mdp_acc_end(c, true);
@@ -722,13 +766,14 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
 }
 
 int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
-                        double *virial, double *eatom)
+                        double *virial, double *eatom, double *vatom)
 {
   if (!c || !fp_all || !f) return MDP_EINVAL;
   if (!c->have_aeam || !c->atoms_set || !c->neigh_set || !c->rebo_packed)
     return mdp_fail(c, MDP_ESTATE, "aeam: call mdp_aeam_density_host first");
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
+  if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;
   hipStream_t st = c->stream;
   const int n = c->nlocal, nall = c->nall;
   // ghosts' fp come from the host's forward comm; owned values are already on the device
@@ -743,7 +788,14 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
     he.resize(n);
     MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   }
+  std::vector<double> hv;
+  if (vflag & MDP_VFLAG_ATOM) {
+    hv.resize((size_t) 6 * nall);
+    MDP_HIP(c, hipMemcpyAsync(hv.data(), c->vatom.p, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
+  }
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  if (vflag & MDP_VFLAG_ATOM)
+    for (size_t k = 0; k < (size_t) 6 * nall; k++) vatom[k] += hv[k];
   for (size_t k = 0; k < (size_t) 3 * nall; k++) f[k] += hf[k];
   if (eflag & MDP_EFLAG_ATOM)
     for (int i = 0; i < n; i++) eatom[i] += he[i];

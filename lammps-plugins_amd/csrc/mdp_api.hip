@@ -178,6 +178,7 @@ int mdp_destroy(mdp_ctx *c)
   c->type.release();
   c->f.release();
   c->eatom.release();
+  c->vatom.release();
   c->acc.release();
   c->flags.release();
   c->nb_off.release();
@@ -201,6 +202,7 @@ int mdp_destroy(mdp_ctx *c)
   c->rev.release();
   c->fnbr.release();
   c->eslot.release();
+  c->vslot.release();
   c->scan_tmp.release();
   c->rho.release();
   c->fp.release();
@@ -442,13 +444,14 @@ static int fetch_acc(mdp_ctx *c, double *eng, double *virial)
 }
 
 int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double *eng_vdwl, double *virial,
-                             double *eatom)
+                             double *eatom, double *vatom)
 {
   if (!c || !f) return MDP_EINVAL;
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
+  if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;
   MDP_TRY(mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true));
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
@@ -459,7 +462,14 @@ int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double
     he.resize(nlocal);
     MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * nlocal, hipMemcpyDeviceToHost, st));
   }
+  std::vector<double> hv;
+  if (vflag & MDP_VFLAG_ATOM) {
+    hv.resize((size_t) 6 * nlocal);
+    MDP_HIP(c, hipMemcpyAsync(hv.data(), c->vatom.p, sizeof(double) * 6 * nlocal, hipMemcpyDeviceToHost, st));
+  }
   MDP_TRY(fetch_acc(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  if (vflag & MDP_VFLAG_ATOM)
+    for (size_t k = 0; k < (size_t) 6 * nlocal; k++) vatom[k] += hv[k];
   for (size_t k = 0; k < (size_t) 3 * nlocal; k++) f[k] += hf[k];
   if (eflag & MDP_EFLAG_ATOM)
     for (int i = 0; i < nlocal; i++) eatom[i] += he[i];

@@ -107,6 +107,7 @@ struct mdp_ctx {
   DevBuf<int> tag, type;
   DevBuf<double> f;     // [nall][3]
   DevBuf<double> eatom; // [nall]
+  DevBuf<double> vatom; // [nall][6] per-atom virial (allocated on first use)
   DevBuf<double> acc;   // [16] eng, virial[6], flags...
   DevBuf<int> flags;    // [4] overflow etc.
   double *h_pinned = nullptr; // pinned staging for small results (32 doubles)
@@ -151,6 +152,7 @@ struct mdp_ctx {
   bool ev_stale_made = false, stale_pending = false;
   DevBuf<double> fnbr;            // [cand_total][3]
   DevBuf<double> eslot;           // [cand_total]
+  DevBuf<double> vslot;           // [cand_total][6] per-atom virial shares (allocated on first use)
   DevBuf<char> scan_tmp;
 
   // ---- AEAM work arrays

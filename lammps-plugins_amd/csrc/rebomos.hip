@@ -425,16 +425,23 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
 
 // ---- general centre kernel: 32 lanes per centre, up to 64 neighbours, no pair matrix ------------------
 // Works through the overflow list of the fast kernels (normally empty).
+// VATOM: also the per-atom virial in the reference's split (v_tally3 thirds, v_tally2 / ev_tally halves,
+// pair_rebomos.cpp:444,707-711,725): the centre's share goes to vatom[c], every neighbour's share to
+// vslot[c][slot] for the gather.  All centres take this kernel on the (rare) steps that ask for it.
+template <bool VATOM>
 __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
-    const RebomosDev P, const int *__restrict__ ovf, const int nlocal, const double4 *__restrict__ xq,
-    const int *__restrict__ cand_off, const int *__restrict__ cand, unsigned long long *__restrict__ amask,
-    double *__restrict__ fnbr, double *__restrict__ eslot, double *__restrict__ acc, int *__restrict__ flags,
+    const RebomosDev P, const int *__restrict__ list, const int list_count, const int nlocal,
+    const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
+    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ eslot,
+    double *__restrict__ vslot, double *__restrict__ vatom, double *__restrict__ acc, int *__restrict__ flags,
     const int eflag, const int vflag)
 {
   constexpr int G = 32, CAP = 64, STRIDE = CAP * kRec + 2;
   __shared__ double s_rec[8 * STRIDE];
   __shared__ int s_je[8 * CAP];
-  const int ncent = ovf[0];
+  // list_count < 0: overflow list of the fast kernels, {count, ids...}; else an explicit list of centres
+  const int ncent = list_count < 0 ? list[0] : list_count;
+  const int *ovf = list_count < 0 ? list : list - 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int s = lane % G;
@@ -542,6 +549,7 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
       }
       const double ux = mx * mri, uy = my * mri, uz = mz * mri;
       double fx = 0, fy = 0, fz = 0, acc1 = 0;
+      double vs[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0}; // slot share / centre share (VATOM)
       for (int qi = 0; qi < nw; qi++) {
         if (act && qi < n && qi != m) {
           const double *q = rec + qi * kRec;
@@ -552,15 +560,76 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
           double dg;
           const double g = gspline(cb, cg, cs, dg);
           const double coef = (mC * q[4] + q[6] * mw) * dg * mri;
-          fx += coef * (q[0] * qrinv - cs * ux);
-          fy += coef * (q[1] * qrinv - cs * uy);
-          fz += coef * (q[2] * qrinv - cs * uz);
+          const double qx = q[0] * qrinv, qy = q[1] * qrinv, qz = q[2] * qrinv;
+          fx += coef * (qx - cs * ux);
+          fy += coef * (qy - cs * uy);
+          fz += coef * (qz - cs * uz);
           acc1 += q[6] * g;
+          if (VATOM) {
+            // triplet (bond m, third body q) and its mirror (bond q, third body m): v_tally3(i,j,k,fj,fk,rji,rki)
+            const double third = 1.0 / 3.0;
+            const double am[3] = {ux - cs * qx, uy - cs * qy, uz - cs * qz}; // (u_m - cos u_q)
+            const double aq[3] = {qx - cs * ux, qy - cs * uy, qz - cs * uz}; // (u_q - cos u_m)
+            const double um[3] = {ux, uy, uz}, uq[3] = {qx, qy, qz};
+            const double dm[3] = {mx, my, mz}, dq[3] = {q[0], q[1], q[2]};
+            const double T1 = mC * q[4] * dg, R1 = mC * q[5] * (g + dp);   // bond m: on m / on q
+            const double T2 = q[6] * mw * dg, R2 = q[6] * mdw * (g + dp);  // bond q: on q / on m
+            double fj[3], fk[3], gj[3], gk[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+              fj[d] = T1 * aq[d] * mri;                    // on m from bond m
+              fk[d] = T1 * am[d] * qrinv + R1 * uq[d];     // on q from bond m
+              gj[d] = T2 * am[d] * qrinv;                  // on q from bond q
+              gk[d] = T2 * aq[d] * mri + R2 * um[d];       // on m from bond q
+            }
+            const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+            for (int k6 = 0; k6 < 6; k6++) {
+              const double v1 = -dm[ia[k6]] * fj[ib[k6]] - dq[ia[k6]] * fk[ib[k6]]; // bond m, third q
+              const double v2 = -dq[ia[k6]] * gj[ib[k6]] - dm[ia[k6]] * gk[ib[k6]]; // bond q, third m
+              vs[k6] += third * (v1 + v2);
+              vc[k6] += third * v1;
+            }
+          }
         }
       }
-      if (act)
+      if (act) {
         finish_slot(P, tc, je[m], off, dp, owned, eflag, mx, my, mz, mr, mw, mdw, mp, mri, mVA, fx, fy, fz, acc1,
                     Csum, fnbr, eslot, o);
+        if (VATOM) {
+          // v_tally2(i,j,tmp2,rij) with tmp2 = -C_m P' dw_m / r_m and ev_tally's pair part with this
+          // centre's half of fpair: both give half to either end
+          const int pt = tc * 2 + (((unsigned) je[m]) >> 30);
+          double fh = -mC * dp * mdw * mri;
+          if (mw > kTol) {
+            const double ex = exp(-P.alpha[pt] * mr);
+            const double pre = mw * P.A[pt] * ex;
+            const double VR = pre * (1.0 + P.Q[pt] * mri);
+            double dVR = pre * (-P.alpha[pt] - P.Q[pt] * mri * mri - P.Q[pt] * P.alpha[pt] * mri);
+            dVR += VR / mw * mdw;
+            double dVA = -P.beta[pt] * mVA;
+            dVA += mVA / mw * mdw;
+            fh += -0.5 * (dVR + mp * dVA) * mri;
+          }
+          const double dm[3] = {mx, my, mz};
+          const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
+          const int tslot = je[m] & 0x3FFFFFFF;
+#pragma unroll
+          for (int k6 = 0; k6 < 6; k6++) {
+            const double vh = 0.5 * dm[ia[k6]] * dm[ib[k6]] * fh;
+            vs[k6] += vh;
+            vc[k6] += vh;
+            vslot[6 * (size_t) (off + tslot) + k6] = vs[k6];
+          }
+        }
+      }
+      if (VATOM) { // the centre's own share: sum over the slots of this group
+#pragma unroll
+        for (int k6 = 0; k6 < 6; k6++) {
+          const double t = group_sum<G>(act ? vc[k6] : 0.0);
+          if (owned && s == 0) vatom[6 * (size_t) c + k6] += t;
+        }
+      }
     }
     wave_lds_fence();
   }
@@ -848,13 +917,16 @@ __global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, cons
                                                           const int *__restrict__ rev,
                                                           const double *__restrict__ fnbr,
                                                           const double *__restrict__ eslot, double *__restrict__ f,
-                                                          double *__restrict__ eatom, const int eflag)
+                                                          double *__restrict__ eatom, const int eflag,
+                                                          const double *__restrict__ vslot,
+                                                          double *__restrict__ vatom)
 {
   const int s = threadIdx.x % L;
   const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
   const bool have = a64 < nlocal;
   const int ia = have ? (int) a64 : 0;
   double gx = 0, gy = 0, gz = 0, ge = 0;
+  double gv[6] = {0, 0, 0, 0, 0, 0};
   if (have) {
     const int off = cand_off[ia];
     const int nc = cand_off[ia + 1] - off;
@@ -872,6 +944,9 @@ __global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, cons
         gy += oj[1];
         gz += oj[2];
         if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+        if (vslot) // what the neighbour centre's cluster energy contributes to this atom's virial
+#pragma unroll
+          for (int k6 = 0; k6 < 6; k6++) gv[k6] += vslot[6 * (size_t) ra + k6];
       }
     }
   }
@@ -879,12 +954,59 @@ __global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, cons
   gy = group_sum<L>(gy);
   gz = group_sum<L>(gz);
   if (eflag & MDP_EFLAG_ATOM) ge = group_sum<L>(ge);
+  if (vslot)
+#pragma unroll
+    for (int k6 = 0; k6 < 6; k6++) gv[k6] = group_sum<L>(gv[k6]);
   if (have && s == 0) {
     double *fo = f + 3 * (size_t) ia;
     fo[0] += gx;
     fo[1] += gy;
     fo[2] += gz;
     if (eflag & MDP_EFLAG_ATOM) eatom[ia] += ge;
+    if (vslot)
+#pragma unroll
+      for (int k6 = 0; k6 < 6; k6++) vatom[6 * (size_t) ia + k6] += gv[k6];
+  }
+}
+
+// Lennard-Jones part of the per-atom virial (ev_tally, pair_rebomos.cpp:554): half of every pair's virial
+// to either end; with both directions visited each atom simply keeps half of what it sees.  Separate small
+// kernel (8 lanes per atom over the atom's cluster list) so that the hot kernel carries no extra registers.
+template <int CL>
+__global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, const int nlocal,
+                                                            const double4 *__restrict__ xq,
+                                                            const long long *__restrict__ lj_off,
+                                                            const int *__restrict__ lj,
+                                                            double *__restrict__ vatom)
+{
+  constexpr int L = 8;
+  const int s = threadIdx.x % L;
+  const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool have = a64 < nlocal;
+  const int a = have ? (int) a64 : 0;
+  const double4 xa = xq[a];
+  const int ta = (int) xa.w;
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  if (have && ta >= 0) {
+    const int kc = a / CL;
+    for (long long k = lj_off[kc] + s; k < lj_off[kc + 1]; k += L) {
+      const double4 xj = xq[lj[k]];
+      const int pt = ta * 2 + (int) xj.w;
+      const LJPar q = lj_load(P, pt);
+      double fx = 0, fy = 0, fz = 0, e = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
+      lj_pair<true>(P, q, pt, xa, xj, fx, fy, fz, e, 1, d0, d1, d2, d3, d4, d5); // d* = dx dx fpair / 2 ...
+      v[0] += d0;
+      v[1] += d1;
+      v[2] += d2;
+      v[3] += d3;
+      v[4] += d4;
+      v[5] += d5;
+    }
+  }
+#pragma unroll
+  for (int k6 = 0; k6 < 6; k6++) {
+    v[k6] = group_sum<L>(v[k6]);
+    if (have && s == 0) vatom[6 * (size_t) a + k6] += v[k6];
   }
 }
 
@@ -1518,9 +1640,27 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
   const int total = c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
   const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
   if (grid)
-    rebo_centre_general_kernel<<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, c->nlocal, c->xq.p, c->cand_off.p,
-                                                     c->cand.p, c->amask.p, c->fnbr.p, c->eslot.p, c->acc.p,
-                                                     c->flags.p, eflag, vflag);
+    rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
+                                                            c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
+                                                            c->eslot.p, nullptr, nullptr, c->acc.p, c->flags.p,
+                                                            eflag, vflag);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// per-atom virial steps: every centre goes through the general kernel's VATOM variant
+static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
+{
+  hipStream_t st = c->stream;
+  for (int k = 0; k < 4; k++) {
+    const int n = c->h_class_count[k];
+    if (n <= 0) continue;
+    const int grid = n / 8 + 1 < 2048 ? n / 8 + 1 : 2048;
+    rebo_centre_general_kernel<true><<<grid, 256, 0, st>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
+                                                           c->nlocal, c->xq.p, c->cand_off.p, c->cand.p, c->amask.p,
+                                                           c->fnbr.p, c->eslot.p, c->vslot.p, c->vatom.p, c->acc.p,
+                                                           c->flags.p, eflag, vflag);
+  }
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -1529,7 +1669,6 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
 // upkeep and the Lennard-Jones work of the interior clusters.  Runs while the halo exchange is in flight.
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 {
-  if (vflag & MDP_VFLAG_ATOM) return mdp_fail(c, MDP_ENOTIMPL, "rebomos: per-atom virial is not implemented on the device");
   if (c->rebo_packed) {
     bool stale = false;
     MDP_TRY(rebomos_lists_stale(c, stale));
@@ -1538,6 +1677,11 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
   if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
   mdp_time_mark(c, 0);
+  if (vflag & MDP_VFLAG_ATOM) {
+    MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
+    MDP_HIP(c, c->vslot.reserve((size_t) 6 * c->cand_total + 6));
+    MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, c->stream));
+  }
   if (c->split_halo) launch_lj(c, 0, c->nclus_interior, /*gather=*/false, eflag, vflag, /*accumulate=*/false);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
@@ -1548,13 +1692,28 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
-  MDP_TRY(launch_centres(c, eflag, vflag));
+  const bool va = (vflag & MDP_VFLAG_ATOM) != 0;
+  if (va)
+    MDP_TRY(launch_centres_vatom(c, eflag, vflag));
+  else
+    MDP_TRY(launch_centres(c, eflag, vflag));
   mdp_time_mark(c, 1);
-  if (c->split_halo) {
-    launch_lj(c, c->nclus_interior, c->nclus - c->nclus_interior, false, eflag, vflag, false);
-    if (c->nlocal)
+  if (c->split_halo || va) {
+    if (c->split_halo)
+      launch_lj(c, c->nclus_interior, c->nclus - c->nclus_interior, false, eflag, vflag, false);
+    else
+      launch_lj(c, 0, c->nclus, false, eflag, vflag, false);
+    if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
-                                                                   c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, eflag);
+                                                                   c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, eflag,
+                                                                   va ? c->vslot.p : nullptr, c->vatom.p);
+      if (va) {
+        const int grid = (c->nlocal + 31) / 32;
+        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
+        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
+        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
+      }
+    }
   } else {
     launch_lj(c, 0, c->nclus, /*gather=*/true, eflag, vflag, false);
   }

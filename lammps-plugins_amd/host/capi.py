@@ -229,9 +229,10 @@ class Context:
         eng = C.c_double(0.0)
         vir = np.zeros(6)
         eatom = np.zeros(nlocal)
+        vatom = np.zeros((nlocal, 6)) if vflag & 4 else None
         self._ck(self.L.mdp_rebomos_compute_host(self.h, C.c_int(eflag), C.c_int(vflag), _dp(f), C.byref(eng),
-                                                 _dp(vir), _dp(eatom)))
-        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom)
+                                                 _dp(vir), _dp(eatom), _dp(vatom)))
+        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom, vatom=vatom)
 
     def aeam_density_host(self, nlocal, eflag=3):
         fp = np.zeros(nlocal)
@@ -247,9 +248,10 @@ class Context:
         eng = C.c_double(0.0)
         vir = np.zeros(6)
         eatom = np.zeros(nlocal)
+        vatom = np.zeros((nall, 6)) if vflag & 4 else None
         self._ck(self.L.mdp_aeam_force_host(self.h, C.c_int(eflag), C.c_int(vflag), _dp(fp_all), _dp(f), C.byref(eng),
-                                            _dp(vir), _dp(eatom)))
-        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom)
+                                            _dp(vir), _dp(eatom), _dp(vatom)))
+        return dict(f=f, eng=eng.value, virial=vir, eatom=eatom, vatom=vatom)
 
     # ---------------- resident mode
     def md_setup(self, cfg: MdConfig, x, v, type_, tag, mass, map_, ghost_owner, ghost_shift, ghost_type, ghost_tag):

@@ -192,7 +192,6 @@ double PairAEAM::init_one(int i, int j)
 void PairAEAM::compute(int eflag, int vflag)
 {
   ev_init(eflag, vflag);
-  if (vflag_atom) error->all(FLERR, "Pair style aeam (MI355X) does not provide per-atom virial yet");
 
   if (atom->nmax > nmax) {
     memory->destroy(rho);
@@ -217,7 +216,7 @@ void PairAEAM::compute(int eflag, int vflag)
   }
 
   const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
-  const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0);
+  const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0) | (vflag_atom ? MDP_VFLAG_ATOM : 0);
 
   // passes 1+2 on the device; fp (owned) comes back for the halo
   rc = mdp_aeam_density_host(dev, ef, fp, rho, &eng_vdwl, eatom);
@@ -226,7 +225,8 @@ void PairAEAM::compute(int eflag, int vflag)
   // communicate the derivative of the embedding function (pair_aeam.cpp:307)
   comm->forward_comm(this);
 
-  rc = mdp_aeam_force_host(dev, ef, vf, fp, nall ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom);
+  rc = mdp_aeam_force_host(dev, ef, vf, fp, nall ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
+                           (vflag_atom && vatom) ? vatom[0] : nullptr);
   if (rc != MDP_OK) fail_one(rc, "force pass");
 }
 

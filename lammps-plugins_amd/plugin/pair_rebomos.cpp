@@ -12,7 +12,7 @@
        host's reverse_comm of f carries zeros for this style;
      * the global virial is tallied explicitly on the device (no_virial_fdotr = 1), because
        x.f over ghosts is only valid for the scatter formulation;
-     * per-atom virial (compute stress/atom) is not available yet: error->all.
+     * per-atom virial (compute stress/atom) is complete on owned atoms, nothing on ghosts.
 -------------------------------------------------------------------------------------------------- */
 #include "pair_rebomos.h"
 
@@ -171,8 +171,6 @@ double PairREBOMoS::init_one(int i, int j)
 void PairREBOMoS::compute(int eflag, int vflag)
 {
   ev_init(eflag, vflag);
-  if (vflag_atom)
-    error->all(FLERR, "Pair style rebomos (MI355X) does not provide per-atom virial yet");
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   int rc;
@@ -193,8 +191,9 @@ void PairREBOMoS::compute(int eflag, int vflag)
   }
 
   const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
-  const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0);
-  rc = mdp_rebomos_compute_host(dev, ef, vf, nlocal ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom);
+  const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0) | (vflag_atom ? MDP_VFLAG_ATOM : 0);
+  rc = mdp_rebomos_compute_host(dev, ef, vf, nlocal ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
+                                (vflag_atom && vatom) ? vatom[0] : nullptr);
   if (rc != MDP_OK) fail_one(rc, "compute");
 }
 

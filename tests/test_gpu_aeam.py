@@ -43,9 +43,11 @@ def _host_mode(ctx, eng, x):
     ctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, 1.0)
     d = ctx.aeam_density_host(nloc, eflag=3)
     fp_all = np.concatenate([d["fp"], d["fp"][eng.owner]])          # forward_comm on one periodic rank
-    r = ctx.aeam_force_host(nall, nloc, fp_all, eflag=3, vflag=1)
+    r = ctx.aeam_force_host(nall, nloc, fp_all, eflag=3, vflag=5)
+    va = r["vatom"][:nloc].copy()
+    np.add.at(va, eng.owner, r["vatom"][nloc:])                      # reverse comm of vatom on one periodic rank
     return dict(f=ob.fold_ghost_forces(r["f"], eng.owner, nloc), eng=d["eng"] + r["eng"], virial=r["virial"],
-                eatom=d["eatom"] + r["eatom"], rho=d["rho"])
+                eatom=d["eatom"] + r["eatom"], rho=d["rho"], vatom=va)
 
 
 @pytest.mark.parametrize("ncell,frac,amp", [(5, 0.08, 0.075), (6, 0.0075, 0.05), (4, 0.5, 0.1), (4, 0.0, 0.1)])
@@ -62,6 +64,10 @@ def test_host_mode_matches_oracle(oracle, T, pot, ncell, frac, amp):
     assert g["eng"] == pytest.approx(o["eng"], rel=1e-11)
     assert np.abs(g["eatom"] - o["eatom"][:s.n]).max() < 1e-9
     assert np.allclose(g["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    # per-atom virial: ev_tally halves + ev_tally3 thirds (pair_aeam.cpp:393,472), folded onto owners
+    vo = o["vatom"][:s.n].copy()
+    np.add.at(vo, eng.owner, o["vatom"][s.n:])
+    assert np.abs(g["vatom"] - vo).max() < 1e-9 * max(1.0, np.abs(vo).max())
     ctx.close()
 
 

@@ -176,3 +176,22 @@ def test_null_mapped_types_are_invisible(ctx, oracle, P):
     assert not g["f"][s.n:].any() and not g["eatom"][s.n:].any()
     assert g["eng"] == pytest.approx(o["eng"], rel=1e-10)
     assert np.abs(g["eatom"][:s.n] - o["eatom_owned"]).max() < E_TOL
+
+
+@pytest.mark.parametrize("fac,amp,seed", [(1.0, 0.0, 0), (1.12, 0.15, 1234), (0.93, 0.10, 77)])
+def test_per_atom_virial_matches_oracle(ctx, oracle, P, fac, amp, seed):
+    """vflag_atom (compute stress/atom): ev_tally halves, v_tally3 thirds, v_tally2 halves
+    (pair_rebomos.cpp:444,554,707-711,725,826-829,843).  The oracle's scatter result is folded onto the
+    owners; the device's owner-computes result must equal it atom by atom.  (Unpinned by any reference log.)"""
+    s = S.rebomos_bulk_cell()
+    if amp:
+        s = S.jitter(S.scale(s, fac), amp, seed=seed)
+    eng = mdref.RebomosCPU(oracle, P, s)
+    g = _gpu_compute(ctx, eng, s.x, eflag=3, vflag=5)
+    o = eng.compute(s.x)
+    va = o["vatom"][:eng.nlocal].copy()
+    np.add.at(va, eng.owner, o["vatom"][eng.nlocal:])
+    scale = max(1.0, np.abs(va).max())
+    assert np.abs(g["vatom"] - va).max() < 1e-9 * scale
+    assert np.allclose(g["vatom"].sum(axis=0), g["virial"], rtol=1e-9, atol=1e-8)
+    _compare(g, o)
