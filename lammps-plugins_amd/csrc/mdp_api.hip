@@ -193,6 +193,11 @@ int mdp_destroy(mdp_ctx *c)
   c->cl_pos.release();
   c->cl_order.release();
   c->lj.release();
+  c->tu.release();
+  c->tmask.release();
+  c->tile_nu.release();
+  c->tile_flag.release();
+  c->lj16.release();
   c->is_center.release();
   c->class_list.release();
   c->class_count.release();

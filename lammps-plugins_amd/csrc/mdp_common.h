@@ -137,6 +137,17 @@ struct mdp_ctx {
   bool split_halo = false;
   DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
+  // Lennard-Jones tile lists (default): the MDP_TILE consecutive clusters one workgroup handles share
+  // the UNION of their neighbours; its coordinates are staged in LDS once per step and the cluster rows
+  // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
+  bool lj_tiled = false;
+  int ntile = 0, tile_cap = 0, tile_maxu = 0;
+  int lj_units = 0, lj_units_interior = 0; // launch units of the LJ kernel: tiles (tiled) or clusters
+  DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
+  DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
+  DevBuf<int> tile_nu;            // [ntile] members of each union
+  DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union
+  DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
   DevBuf<int> class_list;         // [4][nall]
   DevBuf<int> class_count;        // [4]

@@ -22,6 +22,8 @@
 // Nothing is written to ghost atoms; the explicit virial replaces virial_fdotr_compute.
 #include "mdp_common.h"
 
+#include <type_traits>
+
 namespace {
 
 #ifndef MDP_LJ_WAVES
@@ -672,7 +674,22 @@ __device__ __forceinline__ LJPar lj_load(const RebomosDev &P, const int pt)
   return q;
 }
 
-template <bool EV>
+// the same parameters picked from the two uniform (scalar-register) candidates by the atom's element: no
+// vector memory instruction, so nothing but the index prefetch ever counts on vmcnt inside the tile loop
+__device__ __forceinline__ LJPar lj_select(const RebomosDev &P, const int ta, const int seg)
+{
+  LJPar q;
+  q.lo = ta ? P.lj_rsq_lo[2 + seg] : P.lj_rsq_lo[seg];
+  q.hi = ta ? P.lj_rsq_hi[2 + seg] : P.lj_rsq_hi[seg];
+  q.sw = ta ? P.lj_rsq_sw[2 + seg] : P.lj_rsq_sw[seg];
+  q.c1 = ta ? P.lj1[2 + seg] : P.lj1[seg];
+  q.c2 = ta ? P.lj2[2 + seg] : P.lj2[seg];
+  q.c3 = ta ? P.lj3[2 + seg] : P.lj3[seg];
+  q.c4 = ta ? P.lj4[2 + seg] : P.lj4[seg];
+  return q;
+}
+
+template <bool EV, int SEG = -1>
 __device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, const int pt, const double4 &xa,
                                         const double4 &xj, double &fx, double &fy, double &fz, double &e,
                                         const int vflag, double &v0, double &v1, double &v2, double &v3, double &v4,
@@ -683,19 +700,35 @@ __device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, con
   // FLJ windows (pair_rebomos.cpp:518-543).  The 12-6 branch is evaluated without divergence and
   // selected by the window predicate, so the independent evaluations of a lane interleave; the cubic
   // inner spline (rcLJmin <= r < 0.95 sigma, empty in the equilibrium crystal) sits behind a wave-uniform test.
+  // (both sides of every select are plain values: `c ? expression : 0` would compile to a branch)
   const bool inwin = rsq >= q.lo && rsq <= q.hi;
-  const double r2inv = fast_rcp(inwin ? rsq : 1.0);
+  const double rs = inwin ? rsq : 1.0;
+  const double r2inv = fast_rcp(rs);
   const double r6inv = r2inv * r2inv * r2inv;
-  double fpair = inwin ? r6inv * (q.c1 * r6inv - q.c2) * r2inv : 0.0;
+  const double f12 = r6inv * (q.c1 * r6inv - q.c2) * r2inv;
+  double fpair = inwin ? f12 : 0.0;
   double V = 0.0;
-  if (EV) V = inwin ? r6inv * (q.c3 * r6inv - q.c4) : 0.0;
+  if (EV) {
+    const double v12 = r6inv * (q.c3 * r6inv - q.c4);
+    V = inwin ? v12 : 0.0;
+  }
   const bool cubic = inwin && rsq < q.sw;
   if (__any(cubic)) {
     if (cubic) {
       const double rij = sqrt(rsq);
-      const double drp = rij - P.rcLJmin[pt];
-      if (EV) V = drp * drp * (drp * P.ljc3[pt] + P.ljc2[pt]);
-      fpair = -drp * (3.0 * drp * P.ljc3[pt] + 2.0 * P.ljc2[pt]) / rij;
+      double rmin, k2, k3;
+      if (SEG < 0) {
+        rmin = P.rcLJmin[pt];
+        k2 = P.ljc2[pt];
+        k3 = P.ljc3[pt];
+      } else { // neighbour element known at compile time, pt = the atom's element: scalar candidates (lj_select)
+        rmin = pt ? P.rcLJmin[2 + SEG] : P.rcLJmin[SEG];
+        k2 = pt ? P.ljc2[2 + SEG] : P.ljc2[SEG];
+        k3 = pt ? P.ljc3[2 + SEG] : P.ljc3[SEG];
+      }
+      const double drp = rij - rmin;
+      if (EV) V = drp * drp * (drp * k3 + k2);
+      fpair = -drp * (3.0 * drp * k3 + 2.0 * k2) / rij;
     }
   }
   fx += dx * fpair;
@@ -713,6 +746,187 @@ __device__ __forceinline__ void lj_pair(const RebomosDev &P, const LJPar &q, con
       v5 += dy * dz * h;
     }
   }
+}
+
+// group reductions, stores and global tallies shared by the Lennard-Jones kernels
+template <int CL, int L>
+__device__ __forceinline__ void lj_store(const bool have, const int kc, const int s, const int lane, const int nlocal,
+                                         const double e_lj, double (&fx)[CL], double (&fy)[CL], double (&fz)[CL],
+                                         double (&ee)[CL], double v0, double v1, double v2, double v3, double v4,
+                                         double v5, double *__restrict__ f, double *__restrict__ eatom,
+                                         double *__restrict__ acc, const int eflag, const int vflag,
+                                         const int accumulate)
+{
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    fx[c] = group_sum<L>(fx[c]);
+    fy[c] = group_sum<L>(fy[c]);
+    fz[c] = group_sum<L>(fz[c]);
+    if (eflag & MDP_EFLAG_ATOM) ee[c] = group_sum<L>(ee[c]);
+  }
+  if (have && s < CL) {
+#pragma unroll
+    for (int c = 0; c < CL; c++)
+      if (c == s && kc * CL + c < nlocal) {
+        const int ia = kc * CL + c;
+        double *fo = f + 3 * (size_t) ia;
+        if (accumulate) {
+          fo[0] += fx[c];
+          fo[1] += fy[c];
+          fo[2] += fz[c];
+        } else {
+          fo[0] = fx[c];
+          fo[1] = fy[c];
+          fo[2] = fz[c];
+        }
+        if (eflag & MDP_EFLAG_ATOM) {
+          if (accumulate)
+            eatom[ia] += ee[c];
+          else
+            eatom[ia] = ee[c];
+        }
+      }
+  }
+  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+  if (eflag & MDP_EFLAG_GLOBAL) {
+    const double et = group_sum<64>(e_lj);
+    if (lane == 0) atomicAdd(&slot[0], et);
+  }
+  if (vflag & MDP_VFLAG_GLOBAL) {
+    v0 = group_sum<64>(v0);
+    v1 = group_sum<64>(v1);
+    v2 = group_sum<64>(v2);
+    v3 = group_sum<64>(v3);
+    v4 = group_sum<64>(v4);
+    v5 = group_sum<64>(v5);
+    if (lane == 0) {
+      atomicAdd(&slot[1], v0);
+      atomicAdd(&slot[2], v1);
+      atomicAdd(&slot[3], v2);
+      atomicAdd(&slot[4], v3);
+      atomicAdd(&slot[5], v4);
+      atomicAdd(&slot[6], v5);
+    }
+  }
+}
+
+// 12-6 branch only, straight-line: pairs inside the cubic inner spline (rcLJmin <= r < 0.95 sigma; none in
+// an equilibrium crystal) are evaluated as 12-6 here and flagged; lj_cubic_fix() then replaces them.
+template <bool EV>
+__device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, const double4 &xj, double &fx,
+                                             double &fy, double &fz, double &e, const int vflag, double &v0,
+                                             double &v1, double &v2, double &v3, double &v4, double &v5, bool &cub)
+{
+  const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
+  const double rsq = dx * dx + dy * dy + dz * dz;
+  const bool inwin = rsq >= q.lo && rsq <= q.hi;
+  cub = cub || (inwin && rsq < q.sw);
+  const double rs = inwin ? rsq : 1.0;
+  const double r2inv = fast_rcp(rs);
+  const double r6inv = r2inv * r2inv * r2inv;
+  const double f12 = r6inv * (q.c1 * r6inv - q.c2) * r2inv;
+  const double fpair = inwin ? f12 : 0.0;
+  fx += dx * fpair;
+  fy += dy * fpair;
+  fz += dz * fpair;
+  if (EV) {
+    const double v12 = r6inv * (q.c3 * r6inv - q.c4);
+    e += inwin ? 0.5 * v12 : 0.0;
+    if (vflag) {
+      const double h = 0.5 * fpair;
+      v0 += dx * dx * h;
+      v1 += dy * dy * h;
+      v2 += dz * dz * h;
+      v3 += dx * dy * h;
+      v4 += dx * dz * h;
+      v5 += dy * dz * h;
+    }
+  }
+}
+
+// the correction for one pair flagged by lj_pair_fast: cubic spline minus the 12-6 value already added
+// (parameters by value: taking the address of the kernel-argument struct would move all of it to scratch)
+__device__ __noinline__ void lj_cubic_fix(const double c1, const double c2, const double c3, const double c4,
+                                          const double rmin, const double k2, const double k3, const double dx,
+                                          const double dy, const double dz, const double rsq,
+                                          double *out /* fx fy fz e v0..v5 */)
+{
+  const double r2inv = 1.0 / rsq, r6inv = r2inv * r2inv * r2inv;
+  const double f12 = r6inv * (c1 * r6inv - c2) * r2inv;
+  const double v12 = r6inv * (c3 * r6inv - c4);
+  const double rij = sqrt(rsq);
+  const double drp = rij - rmin;
+  const double V = drp * drp * (drp * k3 + k2);
+  const double fc = -drp * (3.0 * drp * k3 + 2.0 * k2) / rij;
+  const double df = fc - f12, h = 0.5 * df;
+  out[0] += dx * df;
+  out[1] += dy * df;
+  out[2] += dz * df;
+  out[3] += 0.5 * (V - v12);
+  out[4] += dx * dx * h;
+  out[5] += dy * dy * h;
+  out[6] += dz * dz * h;
+  out[7] += dx * dy * h;
+  out[8] += dx * dz * h;
+  out[9] += dy * dz * h;
+}
+
+// tail of both Lennard-Jones kernels: REBO slot-force gather, group reductions, stores, global tallies
+template <int CL, int L, bool GATHER>
+__device__ __forceinline__ void lj_finish(const bool have, const int kc, const int s, const int lane, const int nlocal,
+                                          const bool (&real)[CL], double (&fx)[CL], double (&fy)[CL],
+                                          double (&fz)[CL], double (&ee)[CL], double v0, double v1, double v2,
+                                          double v3, double v4, double v5, const int *__restrict__ cand_off,
+                                          const unsigned long long *__restrict__ amask,
+                                          const int *__restrict__ rev, const double *__restrict__ fnbr,
+                                          const double *__restrict__ eslot, double *__restrict__ f,
+                                          double *__restrict__ eatom, double *__restrict__ acc, const int eflag,
+                                          const int vflag, const int accumulate)
+{
+  double e_lj = 0.0;
+#pragma unroll
+  for (int c = 0; c < CL; c++) e_lj += real[c] ? ee[c] : 0.0;
+
+  // ---- gather the REBO cluster forces: own centre (-sum of slot forces) + neighbour centres.
+  // Slot (a,t) is active iff bit t of amask[a]; the REBO relation is symmetric, so the reverse slot
+  // rev[a][t] (static between list builds) is active too and holds what centre j pushes onto a.
+  // L/CL lanes work on each atom of the cluster.
+  if (GATHER) {
+    const int mine = s % CL;
+    const int ia = kc * CL + mine;
+    if (have && ia < nlocal) {
+      const int off = cand_off[ia];
+      const int nc = cand_off[ia + 1] - off;
+      const unsigned long long act = amask[ia];
+      double gx = 0, gy = 0, gz = 0, ge = 0;
+      for (int t = s / CL; t < nc; t += L / CL) {
+        if (!((act >> t) & 1ull)) continue;
+        const int ra = rev[off + t];
+        const double *o = fnbr + 3 * (size_t) (off + t);
+        gx -= o[0];
+        gy -= o[1];
+        gz -= o[2];
+        if (ra >= 0) {
+          const double *oj = fnbr + 3 * (size_t) ra;
+          gx += oj[0];
+          gy += oj[1];
+          gz += oj[2];
+          if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CL; c++)
+        if (c == mine) {
+          fx[c] += gx;
+          fy[c] += gy;
+          fz[c] += gz;
+          ee[c] += ge; // per-atom energy only (the centre kernel tallies the global REBO energy)
+        }
+    }
+  }
+
+  lj_store<CL, L>(have, kc, s, lane, nlocal, e_lj, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
+                  accumulate);
 }
 
 template <int CL, int L, bool EV, bool GATHER, int U = 2>
@@ -814,26 +1028,237 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
       }
     }
   }
+  lj_finish<CL, L, GATHER>(have, kc, s, lane, nlocal, real, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, cand_off, amask, rev,
+                           fnbr, eslot, f, eatom, acc, eflag, vflag, accumulate);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lennard-Jones over TILE lists.  One workgroup = one tile = MDP_TILE consecutive clusters (32 atoms, a
+// compact Morton blob).  The union of their neighbourhoods (~1300 atoms) is gathered from global memory
+// ONCE into LDS (structure of arrays, 24 bytes per atom); the cluster rows then carry 16-bit indices into
+// that union.  The old kernel's bound was the L1 tag rate of its per-lane gathers (each gathered atom
+// was used by 2 pair evaluations); here a gathered atom serves ~13, and the inner loop reads LDS.
+// ------------------------------------------------------------------------------------------------
+#define MDP_TILE 16 // clusters per tile = 256 threads / 16 lanes per cluster
+
+template <bool EV, bool GATHER, int U, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
+    const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
+    const double4 *__restrict__ xq, const int cap, const int capL, const int *__restrict__ tu,
+    const int *__restrict__ tile_nu, const long long *__restrict__ lj_off, const int *__restrict__ lj_split,
+    const unsigned short *__restrict__ lj16, const int *__restrict__ cand_off,
+    const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const double *__restrict__ fnbr,
+    const double *__restrict__ eslot, double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc,
+    const int eflag, const int vflag, const int accumulate)
+{
+  constexpr int CL = 2, L = 16;
+  constexpr int SK = 3; // union members per thread whose index loads are issued unconditionally (cap >= 2048)
+  extern __shared__ double s_pos[]; // x[capL] | y[capL] | z[capL]
+  double *__restrict__ s_x = s_pos;
+  double *__restrict__ s_y = s_pos + capL;
+  double *__restrict__ s_z = s_pos + 2 * capL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int s = lane % L;
+  const int t = order ? order[first + blockIdx.x] : first + blockIdx.x;
+  const int kc0 = t * MDP_TILE + tid / L;
+  const bool have = kc0 < nclus;
+  const int kc = have ? kc0 : 0;
+
+  // A workgroup lives for ~10 us, so a chain of dependent global round trips (~1 us each) at its head or
+  // tail is what would bound the kernel.  Everything that depends on the tile number alone is therefore
+  // requested at once: union size and member indices, row bounds, the cluster's own atoms ...
+  const int nU = tile_nu[t];
+  const int *__restrict__ mem = tu + (size_t) t * cap;
+  int sidx[SK];
+#pragma unroll
+  for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // rows are cap >= 2048 long: always in bounds
+  const long long b = lj_off[kc];
+  const int cnt = have ? (int) (lj_off[kc + 1] - b) : 0;
+  const int split = have ? lj_split[kc] : 0;
+  const unsigned short *__restrict__ row = lj16 + b;
+  double4 xa[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) xa[c] = xq[kc * CL + c < nlocal ? kc * CL + c : nlocal - 1];
+  // ... (second round) the coordinates of the union, the head of both row segments ...
+  {
+    double4 sv[SK]; // all gathers in flight together (index clamped instead of a branch around each load)
+#pragma unroll
+    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int u = tid + 256 * k;
+      if (u < nU) {
+        s_x[u] = sv[k].x;
+        s_y[u] = sv[k].y;
+        s_z[u] = sv[k].z;
+      }
+    }
+  }
+  for (int u = tid + 256 * SK; u < nU; u += 256) {
+    const double4 v = xq[mem[u]];
+    s_x[u] = v.x;
+    s_y[u] = v.y;
+    s_z[u] = v.z;
+  }
+  if (tid == 0) { // slot nU: what the ragged row ends point at -- outside every window
+    s_x[nU] = 1.0e30;
+    s_y[nU] = 0.0;
+    s_z[nU] = 0.0;
+  }
+  int jh[2][3 * U]; // first 3U entries per lane of the Mo segment and of the S segment
+#pragma unroll
+  for (int seg = 0; seg < 2; seg++) {
+    const int kb = seg ? split : 0, ke = seg ? cnt : split;
+#pragma unroll
+    for (int u = 0; u < 3 * U; u++) {
+      const int k = kb + u * L + s;
+      jh[seg][u] = k < ke ? (int) row[k] : nU;
+    }
+  }
+  // ... and the slot-gather bookkeeping of the tail
+  const int mine = s % CL;
+  const int ia_g = kc * CL + mine;
+  const bool g_on = GATHER && have && ia_g < nlocal;
+  int g_off = 0, g_nc = 0, g_ra[2] = {-1, -1};
+  unsigned long long g_act = 0;
+  if (g_on) {
+    g_off = cand_off[ia_g];
+    g_nc = cand_off[ia_g + 1] - g_off;
+    g_act = amask[ia_g];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int tt = s / CL + h * (L / CL);
+      if (tt < g_nc) g_ra[h] = rev[g_off + tt];
+    }
+  }
+
+  int ta[CL];
+  bool real[CL];
+  double fx[CL], fy[CL], fz[CL], ee[CL];
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    real[c] = have && kc * CL + c < nlocal;
+    ta[c] = (int) xa[c].w;
+    if (ta[c] < 0) {
+      real[c] = false;
+      ta[c] = 0;
+    }
+    if (!real[c]) xa[c].x = -1.0e30;
+    fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
+  }
+  __syncthreads();
+
+  // One row segment (neighbour element SEG, a compile-time constant so that every parameter is a select
+  // between two scalar registers).  Two iterations per trip with two index sets (je: even, jo: odd
+  // iterations) and two coordinate sets: an index set is re-requested from global memory the moment its
+  // LDS reads are issued and is needed again two iterations later.  No register is copied and the loads
+  // are unconditional (address clamped, validity re-derived at use), so the only wait inside the loop is
+  // for the load issued a full trip earlier.
+  bool cub = false;
+  auto segment = [&](auto segc) {
+    constexpr int SEG = decltype(segc)::value;
+    const int kb = SEG ? split : 0, ke = SEG ? cnt : split;
+    LJPar q[CL];
+#pragma unroll
+    for (int c = 0; c < CL; c++) q[c] = lj_select(P, ta[c], SEG);
+    int je[U], jo[U];
+    double4 xe[U], xo[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      xe[u] = make_double4(s_x[jh[SEG][u]], s_y[jh[SEG][u]], s_z[jh[SEG][u]], 0.0); // iteration 0
+      jo[u] = jh[SEG][U + u];                                                        // iteration 1
+      je[u] = jh[SEG][2 * U + u];                                                    // iteration 2
+    }
+#pragma unroll 1
+    for (int k0 = kb; k0 < ke; k0 += 2 * U * L) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int li = k0 + U * L + u * L + s < ke ? jo[u] : nU;
+        xo[u] = make_double4(s_x[li], s_y[li], s_z[li], 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = k0 + 3 * U * L + u * L + s;
+        jo[u] = (int) row[k < ke ? k : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int c = 0; c < CL; c++)
+          lj_pair_fast<EV>(q[c], xa[c], xe[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int li = k0 + 2 * U * L + u * L + s < ke ? je[u] : nU;
+        xe[u] = make_double4(s_x[li], s_y[li], s_z[li], 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = k0 + 4 * U * L + u * L + s;
+        je[u] = (int) row[k < ke ? k : 0];
+      }
+      if (k0 + U * L < ke) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+          for (int c = 0; c < CL; c++)
+            lj_pair_fast<EV>(q[c], xa[c], xo[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+        }
+      }
+    }
+  };
+  segment(std::integral_constant<int, 0>{});
+  segment(std::integral_constant<int, 1>{});
+
+  // rare: some pair sat on the cubic inner spline -- walk the row again and replace those pairs
+  if (__any(cub)) {
+    for (int k = s; k < cnt; k += L) {
+      const int li = row[k], seg = k < split ? 0 : 1;
+      const double xjx = s_x[li], xjy = s_y[li], xjz = s_z[li];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        if (!real[c]) continue;
+        const int pt = ta[c] * 2 + seg;
+        const double dx = xa[c].x - xjx, dy = xa[c].y - xjy, dz = xa[c].z - xjz;
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        if (rsq >= P.lj_rsq_lo[pt] && rsq <= P.lj_rsq_hi[pt] && rsq < P.lj_rsq_sw[pt]) {
+          double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          lj_cubic_fix(P.lj1[pt], P.lj2[pt], P.lj3[pt], P.lj4[pt], P.rcLJmin[pt], P.ljc2[pt], P.ljc3[pt], dx, dy, dz,
+                       rsq, o);
+          fx[c] += o[0];
+          fy[c] += o[1];
+          fz[c] += o[2];
+          if (EV) {
+            ee[c] += o[3];
+            if (vflag) {
+              v0 += o[4];
+              v1 += o[5];
+              v2 += o[6];
+              v3 += o[7];
+              v4 += o[8];
+              v5 += o[9];
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // REBO slot forces: own centre (-sum of slot forces) + what the neighbour centres push onto this atom
+  // (reverse slots requested at the top; candidates beyond the first two per lane are rare)
   double e_lj = 0.0;
 #pragma unroll
   for (int c = 0; c < CL; c++) e_lj += real[c] ? ee[c] : 0.0;
-
-  // ---- gather the REBO cluster forces: own centre (-sum of slot forces) + neighbour centres.
-  // Slot (a,t) is active iff bit t of amask[a]; the REBO relation is symmetric, so the reverse slot
-  // rev[a][t] (static between list builds) is active too and holds what centre j pushes onto a.
-  // L/CL lanes work on each atom of the cluster.
   if (GATHER) {
-    const int mine = s % CL;
-    const int ia = kc * CL + mine;
-    if (have && ia < nlocal) {
-      const int off = cand_off[ia];
-      const int nc = cand_off[ia + 1] - off;
-      const unsigned long long act = amask[ia];
-      double gx = 0, gy = 0, gz = 0, ge = 0;
-      for (int t = s / CL; t < nc; t += L / CL) {
-        if (!((act >> t) & 1ull)) continue;
-        const int ra = rev[off + t];
-        const double *o = fnbr + 3 * (size_t) (off + t);
+    double gx = 0, gy = 0, gz = 0, ge = 0;
+    if (g_on) {
+      int h = 0;
+      for (int tt = s / CL; tt < g_nc; tt += L / CL, h++) {
+        if (!((g_act >> tt) & 1ull)) continue;
+        const int ra = h < 2 ? (h ? g_ra[1] : g_ra[0]) : rev[g_off + tt];
+        const double *o = fnbr + 3 * (size_t) (g_off + tt);
         gx -= o[0];
         gy -= o[1];
         gz -= o[2];
@@ -842,71 +1267,21 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
           gx += oj[0];
           gy += oj[1];
           gz += oj[2];
-          if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+          if (eflag & MDP_EFLAG_ATOM) ge += eslot[g_off + tt] + eslot[ra];
         }
       }
-#pragma unroll
-      for (int c = 0; c < CL; c++)
-        if (c == mine) {
-          fx[c] += gx;
-          fy[c] += gy;
-          fz[c] += gz;
-          ee[c] += ge; // per-atom energy only (the centre kernel tallies the global REBO energy)
-        }
     }
-  }
-
-#pragma unroll
-  for (int c = 0; c < CL; c++) {
-    fx[c] = group_sum<L>(fx[c]);
-    fy[c] = group_sum<L>(fy[c]);
-    fz[c] = group_sum<L>(fz[c]);
-    if (eflag & MDP_EFLAG_ATOM) ee[c] = group_sum<L>(ee[c]);
-  }
-  if (have && s < CL) {
 #pragma unroll
     for (int c = 0; c < CL; c++)
-      if (c == s && kc * CL + c < nlocal) {
-        const int ia = kc * CL + c;
-        double *fo = f + 3 * (size_t) ia;
-        if (accumulate) {
-          fo[0] += fx[c];
-          fo[1] += fy[c];
-          fo[2] += fz[c];
-        } else {
-          fo[0] = fx[c];
-          fo[1] = fy[c];
-          fo[2] = fz[c];
-        }
-        if (eflag & MDP_EFLAG_ATOM) {
-          if (accumulate)
-            eatom[ia] += ee[c];
-          else
-            eatom[ia] = ee[c];
-        }
+      if (c == mine) {
+        fx[c] += gx;
+        fy[c] += gy;
+        fz[c] += gz;
+        ee[c] += ge;
       }
   }
-  double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
-  if (eflag & MDP_EFLAG_GLOBAL) {
-    const double et = group_sum<64>(e_lj);
-    if (lane == 0) atomicAdd(&slot[0], et);
-  }
-  if (vflag & MDP_VFLAG_GLOBAL) {
-    v0 = group_sum<64>(v0);
-    v1 = group_sum<64>(v1);
-    v2 = group_sum<64>(v2);
-    v3 = group_sum<64>(v3);
-    v4 = group_sum<64>(v4);
-    v5 = group_sum<64>(v5);
-    if (lane == 0) {
-      atomicAdd(&slot[1], v0);
-      atomicAdd(&slot[2], v1);
-      atomicAdd(&slot[3], v2);
-      atomicAdd(&slot[4], v3);
-      atomicAdd(&slot[5], v4);
-      atomicAdd(&slot[6], v5);
-    }
-  }
+  lj_store<CL, L>(have, kc, s, lane, nlocal, e_lj, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
+                  accumulate);
 }
 
 // REBO slot-force gather alone: f[a] += -sum_t fnbr[a][t] + sum_t fnbr[rev[a][t]] (and the per-atom REBO
@@ -977,6 +1352,8 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
                                                             const double4 *__restrict__ xq,
                                                             const long long *__restrict__ lj_off,
                                                             const int *__restrict__ lj,
+                                                            const unsigned short *__restrict__ lj16,
+                                                            const int *__restrict__ tu, const int cap,
                                                             double *__restrict__ vatom)
 {
   constexpr int L = 8;
@@ -989,8 +1366,9 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
   double v[6] = {0, 0, 0, 0, 0, 0};
   if (have && ta >= 0) {
     const int kc = a / CL;
+    const int *mem = lj16 ? tu + (size_t) (kc / MDP_TILE) * cap : nullptr; // tile lists: rows index the union
     for (long long k = lj_off[kc] + s; k < lj_off[kc + 1]; k += L) {
-      const double4 xj = xq[lj[k]];
+      const double4 xj = xq[lj16 ? mem[lj16[k]] : lj[k]];
       const int pt = ta * 2 + (int) xj.w;
       const LJPar q = lj_load(P, pt);
       double fx = 0, fy = 0, fz = 0, e = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
@@ -1140,6 +1518,221 @@ __global__ __launch_bounds__(256) void cluster_build_kernel(const MdpGrid g, con
   if (!FILL && have && s == 0) {
     cnt[k] = n0 + n1;
     split[k] = n0;
+  }
+}
+
+// ---- tile lists -------------------------------------------------------------------------------
+// Pass 1, one workgroup per tile: sweep the stencil of the tile's bounding cells; every candidate is
+// tested against all atoms of the tile (broadcast LDS reads) giving a 16-bit mask of the clusters that
+// list it.  Each wave takes every fourth (y,z) row and compacts its members with ballots into its own
+// LDS segment (Mo from the front, S from the back); the segments are then concatenated Mo-first, so the
+// result is deterministic.  Outputs: the union (tu), the masks, and the row lengths of the 16 clusters.
+template <int CL>
+__global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const RebomosDev P, const int nclus,
+                                                        const int nlocal, const double4 *__restrict__ xq,
+                                                        const int *__restrict__ perm,
+                                                        const int *__restrict__ cell_start, const int cap,
+                                                        int *__restrict__ tu, unsigned short *__restrict__ tmask,
+                                                        int *__restrict__ tile_nu, int *__restrict__ cnt,
+                                                        int *__restrict__ split, int *__restrict__ tile_flag)
+{
+  constexpr int NA = MDP_TILE * CL;
+  extern __shared__ int s_dyn[];
+  const int wcap = cap / 2; // per-wave segment (a wave sees about a quarter of the union)
+  int *s_idx = s_dyn;                                                    // [4][wcap]
+  unsigned short *s_m = (unsigned short *) (s_dyn + 4 * wcap);           // [4][wcap]
+  unsigned short *s_fm = s_m + 4 * wcap;                                 // [cap] masks in final order
+  __shared__ double4 s_xa[NA];
+  __shared__ double s_cut[NA][2];
+  __shared__ int s_lo[3], s_hi[3], s_n0[4], s_n1[4], s_over;
+  const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 3) {
+    s_lo[tid] = 1 << 30;
+    s_hi[tid] = -1;
+  }
+  if (tid == 0) s_over = 0;
+  __syncthreads();
+  if (tid < NA) {
+    const int ia = t * NA + tid;
+    bool valid = ia < nlocal;
+    const double4 xa = xq[valid ? ia : (nlocal > 0 ? nlocal - 1 : 0)];
+    const int ta = (int) xa.w;
+    if (ta < 0) valid = false; // NULL-mapped atom: lists nothing
+    s_xa[tid] = xa;
+    s_cut[tid][0] = valid ? P.ljlist_cutsq[ta * 2 + 0] : -1.0;
+    s_cut[tid][1] = valid ? P.ljlist_cutsq[ta * 2 + 1] : -1.0;
+    if (valid) {
+      int cc[3];
+      cc[0] = (int) ((xa.x - g.lo[0]) * g.inv[0]);
+      cc[1] = (int) ((xa.y - g.lo[1]) * g.inv[1]);
+      cc[2] = (int) ((xa.z - g.lo[2]) * g.inv[2]);
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        cc[d] = cc[d] < 0 ? 0 : (cc[d] >= g.n[d] ? g.n[d] - 1 : cc[d]);
+        atomicMin(&s_lo[d], cc[d]);
+        atomicMax(&s_hi[d], cc[d]);
+      }
+    }
+  }
+  __syncthreads();
+  const int R = g.range;
+  const bool any = s_hi[0] >= 0;
+  const int xlo = max(s_lo[0] - R, 0), xhi = min(s_hi[0] + R, g.n[0] - 1);
+  const int ylo = max(s_lo[1] - R, 0), yhi = min(s_hi[1] + R, g.n[1] - 1);
+  const int zlo = max(s_lo[2] - R, 0), zhi = min(s_hi[2] + R, g.n[2] - 1);
+  const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+  const int nrows = any ? ny * nz : 0;
+  int *seg_i = s_idx + wave * wcap;
+  unsigned short *seg_m = s_m + wave * wcap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int n0 = 0, n1 = 0;
+  bool over = false;
+  for (int r = wave; r < nrows && !over; r += 4) {
+    const int y = ylo + r % ny, z = zlo + r / ny;
+    const int pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
+    const int pe = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1];
+    for (int p0 = pb; p0 < pe; p0 += 64) {
+      const int p = p0 + lane;
+      unsigned m = 0;
+      int j = 0, tj = 0;
+      if (p < pe) {
+        j = perm[p];
+        const double4 xj = xq[j];
+        tj = (int) xj.w;
+        if (tj >= 0) {
+#pragma unroll 8
+          for (int a = 0; a < NA; a++) {
+            const double4 xa = s_xa[a];
+            const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
+            if (dx * dx + dy * dy + dz * dz <= s_cut[a][tj]) m |= 1u << (a / CL);
+          }
+        }
+      }
+      const bool k0 = m != 0 && tj == 0, k1 = m != 0 && tj != 0;
+      const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+      const int c0 = __popcll(b0), c1 = __popcll(b1);
+      if (n0 + n1 + c0 + c1 > wcap) {
+        over = true;
+        break;
+      }
+      if (k0) {
+        const int pos = n0 + __popcll(b0 & below);
+        seg_i[pos] = j;
+        seg_m[pos] = (unsigned short) m;
+      }
+      if (k1) {
+        const int pos = wcap - 1 - (n1 + __popcll(b1 & below));
+        seg_i[pos] = j;
+        seg_m[pos] = (unsigned short) m;
+      }
+      n0 += c0;
+      n1 += c1;
+    }
+  }
+  if (lane == 0) {
+    s_n0[wave] = n0;
+    s_n1[wave] = n1;
+    if (over) s_over = 1;
+  }
+  __syncthreads();
+  const int N0 = s_n0[0] + s_n0[1] + s_n0[2] + s_n0[3];
+  const int N1 = s_n1[0] + s_n1[1] + s_n1[2] + s_n1[3];
+  int nU = N0 + N1;
+  if (s_over || nU > cap - 1) { // (slot nU is the kernel's dummy entry, so nU <= cap-1)
+    if (tid == 0) {
+      atomicOr(&tile_flag[0], 1);
+      tile_nu[t] = 0;
+    }
+    if (tid < MDP_TILE && t * MDP_TILE + tid < nclus) cnt[t * MDP_TILE + tid] = split[t * MDP_TILE + tid] = 0;
+    return;
+  }
+  int base0 = 0, base1 = N0;
+  for (int w = 0; w < wave; w++) {
+    base0 += s_n0[w];
+    base1 += s_n1[w];
+  }
+  int *mem = tu + (size_t) t * cap;
+  unsigned short *mm = tmask + (size_t) t * cap;
+  for (int i = lane; i < n0; i += 64) {
+    const int u = base0 + i;
+    const unsigned short m = seg_m[i];
+    mem[u] = seg_i[i];
+    mm[u] = m;
+    s_fm[u] = m;
+  }
+  for (int i = lane; i < n1; i += 64) {
+    const int u = base1 + i, src = wcap - 1 - i;
+    const unsigned short m = seg_m[src];
+    mem[u] = seg_i[src];
+    mm[u] = m;
+    s_fm[u] = m;
+  }
+  __syncthreads();
+  const int gq = tid / 16, sq = tid % 16;
+  int c0 = 0, c1 = 0;
+  for (int u = sq; u < nU; u += 16) {
+    const int bit = (s_fm[u] >> gq) & 1;
+    c0 += u < N0 ? bit : 0;
+    c1 += u < N0 ? 0 : bit;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    c0 += __shfl_xor(c0, o, 64);
+    c1 += __shfl_xor(c1, o, 64);
+  }
+  const int kc = t * MDP_TILE + gq;
+  if (sq == 0 && kc < nclus) {
+    cnt[kc] = c0 + c1;
+    split[kc] = c0;
+  }
+  if (tid == 0) {
+    tile_nu[t] = nU;
+    atomicMax(&tile_flag[1], nU);
+  }
+}
+
+// Pass 2: each cluster (16 lanes) walks its tile's masks in union order and keeps the entries with its bit
+__global__ __launch_bounds__(256) void tile_fill_kernel(const int nclus, const int cap,
+                                                        const int *__restrict__ tile_nu,
+                                                        const unsigned short *__restrict__ tmask,
+                                                        const long long *__restrict__ off,
+                                                        unsigned short *__restrict__ lj16)
+{
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int gq = tid / 16, sq = tid % 16, glane0 = lane - sq;
+  const int kc = t * MDP_TILE + gq;
+  const bool have = kc < nclus;
+  const int nU = tile_nu[t];
+  const unsigned short *mm = tmask + (size_t) t * cap;
+  unsigned short *row = have ? lj16 + off[kc] : nullptr;
+  const unsigned long long below = (1ull << sq) - 1ull;
+  int n = 0;
+  for (int base = 0; base < nU; base += 16) {
+    const int u = base + sq;
+    const bool k = have && u < nU && ((mm[u] >> gq) & 1);
+    const unsigned long long b = (__ballot(k) >> glane0) & 0xFFFFull;
+    if (k) row[n + __popcll(b & below)] = (unsigned short) u;
+    n += __popcll(b);
+  }
+}
+
+// does the tile's union reach a remote ghost?  Such tiles wait for the halo.
+__global__ __launch_bounds__(256) void tile_boundary_kernel(const int ntile, const int cap, const int remote_start,
+                                                            const int *__restrict__ tile_nu,
+                                                            const int *__restrict__ tu, int *__restrict__ is_int,
+                                                            int *__restrict__ is_bnd)
+{
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntile) return;
+  const int *mem = tu + (size_t) t * cap;
+  const int nU = tile_nu[t];
+  int hit = 0;
+  for (int u = lane; u < nU; u += 64) hit |= mem[u] >= remote_start;
+  hit = __any(hit);
+  if (lane == 0) {
+    is_int[t] = !hit;
+    is_bnd[t] = hit;
   }
 }
 
@@ -1456,7 +2049,52 @@ int mdp_rebomos_repack(mdp_ctx *c)
         nullptr, c->is_center.p);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
-  if (nclus) {
+  // Lennard-Jones lists: tile lists for the default cluster size, unless switched off or a union outgrows LDS
+  bool tiled = cl == 2 && nclus > 0;
+  if (const char *e = getenv("MDP_LJ_TILE")) tiled = tiled && atoi(e) != 0;
+  const int ntile = (nclus + MDP_TILE - 1) / MDP_TILE;
+  if (tiled) {
+    int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
+    MDP_HIP(c, c->tile_flag.reserve(4));
+    MDP_HIP(c, c->tile_nu.reserve(ntile + 1));
+    for (;;) {
+      MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
+      MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
+      MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 2, st));
+      const size_t lds = (size_t) 14 * cap; // 4 wave segments of cap/2 (int + ushort) + cap ushort
+      if (lds > 48 * 1024)
+        MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) lds));
+      tile_scan_kernel<2><<<ntile, 256, lds, st>>>(c->grid, c->rebomos, nclus, nlocal, c->xq.p, c->cell_perm.p,
+                                                   c->cell_start.p, cap, c->tu.p, c->tmask.p, c->tile_nu.p,
+                                                   c->lj_cnt.p, c->lj_split.p, c->tile_flag.p);
+      MDP_HIP(c, hipGetLastError());
+      int tf[2] = {0, 0};
+      MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+      MDP_HIP(c, hipStreamSynchronize(st));
+      if (!tf[0]) {
+        c->tile_cap = cap;
+        c->tile_maxu = tf[1];
+        break;
+      }
+      cap *= 2; // a union outgrew the segment: retry larger, give up beyond what LDS can stage
+      if (cap > 4096) {
+        tiled = false;
+        break;
+      }
+    }
+  }
+  c->lj_tiled = tiled;
+  c->ntile = tiled ? ntile : 0;
+  if (tiled && getenv("MDP_DEBUG")) {
+    std::vector<int> h(ntile);
+    MDP_HIP(c, hipMemcpy(h.data(), c->tile_nu.p, sizeof(int) * ntile, hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (int v : h) sum += v;
+    fprintf(stderr, "[mdp] tile lists: %d tiles, cap %d, union mean %.1f max %d\n", ntile, c->tile_cap, sum / ntile,
+            c->tile_maxu);
+  }
+  if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
 #define MDP_CB(CLV, FILLV, OFFP, OUTP)                                                                              \
   cluster_build_kernel<CLV, FILLV><<<gb, 256, 0, st>>>(c->grid, c->rebomos, nclus, nlocal, c->xq.p, c->cell_perm.p, \
@@ -1475,7 +2113,10 @@ int mdp_rebomos_repack(mdp_ctx *c)
   c->cand_total = cand_total;
   c->lj_total = lj_total;
   MDP_HIP(c, c->cand.reserve((size_t) cand_total + 1));
-  MDP_HIP(c, c->lj.reserve((size_t) lj_total + 1));
+  if (tiled)
+    MDP_HIP(c, c->lj16.reserve((size_t) lj_total + 1));
+  else
+    MDP_HIP(c, c->lj.reserve((size_t) lj_total + 1));
   MDP_HIP(c, c->rev.reserve((size_t) cand_total + 1));
   MDP_HIP(c, c->fnbr.reserve((size_t) 3 * cand_total + 3));
   MDP_HIP(c, c->eslot.reserve((size_t) cand_total + 1));
@@ -1483,7 +2124,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p);
-  if (nclus) {
+  if (tiled)
+    tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj16.p);
+  if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
     if (cl == 1) MDP_CB(1, true, c->lj_off.p, c->lj.p);
     else if (cl == 2) MDP_CB(2, true, c->lj_off.p, c->lj.p);
@@ -1491,26 +2134,34 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
-  // interior / boundary partition of the clusters (only meaningful with remote ghosts)
+  // interior / boundary partition of the launch units -- tiles, or clusters without tile lists -- (only
+  // meaningful with remote ghosts)
+  const int nunit = tiled ? ntile : nclus;
+  c->lj_units = nunit;
+  c->lj_units_interior = nunit;
   c->nclus_interior = nclus;
   c->split_halo = false;
-  if (c->md && c->remote_start < nall && nclus > 0) {
-    MDP_HIP(c, c->cl_flag.reserve((size_t) 2 * (nclus + 1)));
-    MDP_HIP(c, c->cl_pos.reserve((size_t) 2 * (nclus + 2)));
-    MDP_HIP(c, c->cl_order.reserve(nclus + 1));
-    int *is_int = c->cl_flag.p, *is_bnd = c->cl_flag.p + (nclus + 1);
-    int *pos_int = c->cl_pos.p, *pos_bnd = c->cl_pos.p + (nclus + 2);
-    cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p, is_int,
-                                                               is_bnd);
+  if (c->md && c->remote_start < nall && nunit > 0) {
+    MDP_HIP(c, c->cl_flag.reserve((size_t) 2 * (nunit + 1)));
+    MDP_HIP(c, c->cl_pos.reserve((size_t) 2 * (nunit + 2)));
+    MDP_HIP(c, c->cl_order.reserve(nunit + 1));
+    int *is_int = c->cl_flag.p, *is_bnd = c->cl_flag.p + (nunit + 1);
+    int *pos_int = c->cl_pos.p, *pos_bnd = c->cl_pos.p + (nunit + 2);
+    if (tiled)
+      tile_boundary_kernel<<<(ntile + 3) / 4, 256, 0, st>>>(ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
+                                                            c->tu.p, is_int, is_bnd);
+    else
+      cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p,
+                                                                 is_int, is_bnd);
     MDP_HIP(c, hipGetLastError());
-    MDP_TRY(mdp_scan_exclusive_int(c, is_int, pos_int, nclus));
-    MDP_TRY(mdp_scan_exclusive_int(c, is_bnd, pos_bnd, nclus));
+    MDP_TRY(mdp_scan_exclusive_int(c, is_int, pos_int, nunit));
+    MDP_TRY(mdp_scan_exclusive_int(c, is_bnd, pos_bnd, nunit));
     int nint = 0;
-    MDP_HIP(c, hipMemcpyAsync(&nint, pos_int + nclus, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipMemcpyAsync(&nint, pos_int + nunit, sizeof(int), hipMemcpyDeviceToHost, st));
     MDP_HIP(c, hipStreamSynchronize(st));
-    cluster_order_kernel<<<(nclus + 255) / 256, 256, 0, st>>>(nclus, nint, is_int, pos_int, pos_bnd, c->cl_order.p);
+    cluster_order_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, nint, is_int, pos_int, pos_bnd, c->cl_order.p);
     MDP_HIP(c, hipGetLastError());
-    c->nclus_interior = nint;
+    c->lj_units_interior = nint;
     c->split_halo = true;
   }
   if (nall)
@@ -1601,14 +2252,43 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
-static void launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, int vflag, bool accumulate)
+static int launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, int vflag, bool accumulate)
 {
-  if (count <= 0) return;
+  if (count <= 0) return MDP_OK;
   hipStream_t st = c->stream;
-  constexpr int L = 16;
-  const int grid = (count + 256 / L - 1) / (256 / L);
   const int *order = c->split_halo ? c->cl_order.p : nullptr;
   const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
+  if (c->lj_tiled) { // first/count in tiles
+    const int capL = (c->tile_maxu + 1 + 7) & ~7;
+    const size_t lds = (size_t) capL * 3 * sizeof(double);
+#define MDP_LJT3(EVV, GV, UV, WV)                                                                                   \
+  do {                                                                                                              \
+    if (lds > 48 * 1024)                                                                                            \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile_kernel<EVV, GV, UV, WV>,                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                       \
+    rebo_lj_tile_kernel<EVV, GV, UV, WV><<<count, 256, lds, st>>>(                                                  \
+        c->rebomos, c->nlocal, order, first, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p,           \
+        c->lj_off.p, c->lj_split.p, c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->fnbr.p, c->eslot.p, c->f.p,  \
+        c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                                    \
+  } while (0)
+#define MDP_LJT(EVV, GV)                                                                                            \
+  do {                                                                                                              \
+    static const int variant = getenv("MDP_LJ_VARIANT") ? atoi(getenv("MDP_LJ_VARIANT")) : 0;                       \
+    if (variant == 1) MDP_LJT3(EVV, GV, 2, 3);                                                                      \
+    else if (variant == 2) MDP_LJT3(EVV, GV, 2, 4);                                                                 \
+    else if (variant == 3) MDP_LJT3(EVV, GV, 1, 3);                                                                 \
+    else MDP_LJT3(EVV, GV, 1, 4);                                                                                   \
+  } while (0)
+    if (ev && gather) MDP_LJT(true, true);
+    else if (ev) MDP_LJT(true, false);
+    else if (gather) MDP_LJT(false, true);
+    else MDP_LJT(false, false);
+#undef MDP_LJT3
+#undef MDP_LJT
+    return MDP_OK;
+  }
+  constexpr int L = 16;
+  const int grid = (count + 256 / L - 1) / (256 / L);
 #define MDP_LJ(CLV, EVV, GV)                                                                                        \
   rebo_lj_gather_kernel<CLV, L, EVV, GV><<<grid, 256, 0, st>>>(                                                      \
       c->rebomos, c->nlocal, order, first, count, c->xq.p, c->lj_off.p, c->lj_split.p, c->lj.p, c->cand_off.p,       \
@@ -1625,6 +2305,7 @@ static void launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, 
   else MDP_LJ2(2);
 #undef MDP_LJ2
 #undef MDP_LJ
+  return MDP_OK;
 }
 
 static int launch_centres(mdp_ctx *c, int eflag, int vflag)
@@ -1682,7 +2363,7 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vslot.reserve((size_t) 6 * c->cand_total + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, c->stream));
   }
-  if (c->split_halo) launch_lj(c, 0, c->nclus_interior, /*gather=*/false, eflag, vflag, /*accumulate=*/false);
+  if (c->split_halo) MDP_TRY(launch_lj(c, 0, c->lj_units_interior, /*gather=*/false, eflag, vflag, /*accumulate=*/false));
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -1700,22 +2381,23 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
   mdp_time_mark(c, 1);
   if (c->split_halo || va) {
     if (c->split_halo)
-      launch_lj(c, c->nclus_interior, c->nclus - c->nclus_interior, false, eflag, vflag, false);
+      MDP_TRY(launch_lj(c, c->lj_units_interior, c->lj_units - c->lj_units_interior, false, eflag, vflag, false));
     else
-      launch_lj(c, 0, c->nclus, false, eflag, vflag, false);
+      MDP_TRY(launch_lj(c, 0, c->lj_units, false, eflag, vflag, false));
     if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
                                                                    c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, eflag,
                                                                    va ? c->vslot.p : nullptr, c->vatom.p);
       if (va) {
         const int grid = (c->nlocal + 31) / 32;
-        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
-        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
-        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, c->vatom.p);
+        const unsigned short *lj16 = c->lj_tiled ? c->lj16.p : nullptr;
+        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
+        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
+        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
       }
     }
   } else {
-    launch_lj(c, 0, c->nclus, /*gather=*/true, eflag, vflag, false);
+    MDP_TRY(launch_lj(c, 0, c->lj_units, /*gather=*/true, eflag, vflag, false));
   }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 2);

@@ -31,6 +31,53 @@ def morton_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
+def hilbert_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
+    """argsort of atoms along a 3-D Hilbert curve on a `cell`-sized grid.  Unlike the Z-order curve a
+    Hilbert curve has no jumps: ANY run of consecutive atoms is a compact blob, which is what bounds the
+    neighbour union of the Lennard-Jones tiles (csrc/rebomos.hip) and with it their LDS footprint.
+    (Skilling's axes-to-transpose algorithm, vectorised.)"""
+    if len(x) == 0:
+        return np.zeros(0, dtype=np.int64)
+    # exactly 2^bits cells per dimension over the atoms' extent (cells need not be cubic): the curve is
+    # continuous only on its full cube, a partly occupied cube would bring the jumps back
+    xmin = x.min(axis=0)
+    ext = np.maximum(x.max(axis=0) - xmin, 1e-9)
+    bits = max(1, int(np.ceil(np.log2(max(ext.max() / cell, 1.0)))))
+    ncell = 1 << bits
+    g = np.minimum(np.floor((x - xmin) / ext * ncell).astype(np.int64), ncell - 1)
+    X = [g[:, 0].astype(np.uint64), g[:, 1].astype(np.uint64), g[:, 2].astype(np.uint64)]
+    zero = np.uint64(0)
+    q = 1 << (bits - 1)
+    while q > 1:
+        Q, P = np.uint64(q), np.uint64(q - 1)
+        for i in range(3):
+            hit = (X[i] & Q) != zero
+            X[0] = np.where(hit, X[0] ^ P, X[0])
+            t = np.where(hit, zero, (X[0] ^ X[i]) & P)
+            X[0] = X[0] ^ t
+            X[i] = X[i] ^ t
+        q >>= 1
+    X[1] ^= X[0]
+    X[2] ^= X[1]
+    t = np.zeros_like(X[0])
+    q = 1 << (bits - 1)
+    while q > 1:
+        t = np.where((X[2] & np.uint64(q)) != zero, t ^ np.uint64(q - 1), t)
+        q >>= 1
+    X = [v ^ t for v in X]
+    key = np.zeros_like(X[0])
+    for b in range(bits - 1, -1, -1):
+        for i in range(3):
+            key = (key << np.uint64(1)) | ((X[i] >> np.uint64(b)) & np.uint64(1))
+    return np.argsort(key, kind="stable")
+
+
+def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
+    """the order atoms are stored in on the device (MDP_ORDER=morton selects the Z-order curve)"""
+    import os
+    return morton_order(x, lo, cell) if os.environ.get("MDP_ORDER", "hilbert") == "morton" else hilbert_order(x, lo, cell)
+
+
 class Domain:
     """One GPU sub-domain in resident mode.
 
@@ -69,12 +116,12 @@ class Domain:
         v = np.zeros_like(x) if v0 is None else np.asarray(v0, dtype=np.float64)
         t, g = s.type, s.tag
         if sort:
-            order = morton_order(x, s.box.lo, 3.0)
+            order = spatial_order(x, s.box.lo, 3.0)
             x, v, t, g = x[order], v[order], t[order], g[order]
         owner, shift = S.make_ghosts(s.box, x, cutghost)
         shift_cart = shift @ s.box.h.T
         if sort and len(owner):
-            go = morton_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0)
+            go = spatial_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0)
             owner, shift_cart = owner[go], shift_cart[go]
         d = cls(ctx, style, s.box, np.ascontiguousarray(x), np.ascontiguousarray(v), t, g, s.mass, map_,
                 owner.astype(np.int32), np.ascontiguousarray(shift_cart), t[owner], g[owner], skin, dt,
