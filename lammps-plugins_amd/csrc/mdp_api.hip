@@ -205,8 +205,9 @@ int mdp_destroy(mdp_ctx *c)
   c->xhold_all.release();
   c->ovf.release();
   c->rev.release();
+  c->rev16.release();
   c->fnbr.release();
-  c->eslot.release();
+  c->fown.release();
   c->vslot.release();
   c->scan_tmp.release();
   c->rho.release();

@@ -142,7 +142,10 @@ struct mdp_ctx {
   // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
   bool lj_tiled = false;
   int ntile = 0, tile_cap = 0, tile_maxu = 0;
-  int lj_units = 0, lj_units_interior = 0; // launch units of the LJ kernel: tiles (tiled) or clusters
+  int lj_units = 0;               // launch units of the LJ kernel: tiles (tiled) or clusters
+  int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: interior small/large, boundary small/large
+  bool lj_ordered = false;        // cl_order in use (otherwise natural order, everything in class 0)
+  int tile_small = 0;             // largest union of the "small" launch classes
   DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
   DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
   DevBuf<int> tile_nu;            // [ntile] members of each union
@@ -154,6 +157,7 @@ struct mdp_ctx {
   int h_class_count[4] = {0, 0, 0, 0};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
+  DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride
   DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
   DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
@@ -161,8 +165,8 @@ struct mdp_ctx {
   long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
   hipEvent_t ev_stale = nullptr;
   bool ev_stale_made = false, stale_pending = false;
-  DevBuf<double> fnbr;            // [cand_total][3]
-  DevBuf<double> eslot;           // [cand_total]
+  DevBuf<double> fnbr;            // [cand_total][4] force on the slot's neighbour + its share of the pair energy
+  DevBuf<double> fown;            // [nall][4] the centre's own share: -(sum of its slot forces), energy
   DevBuf<double> vslot;           // [cand_total][6] per-atom virial shares (allocated on first use)
   DevBuf<char> scan_tmp;
 

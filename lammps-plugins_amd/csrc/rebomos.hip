@@ -14,11 +14,14 @@
 // depends only on x_c and the <= ~12 REBO neighbours of c, so
 //   1. rebo_centre_kernel<G>: G lanes per centre (owned atoms AND the ghost atoms that neighbour
 //      them).  Neighbour geometry is staged in LDS, the O(n^2) angular sums run out of LDS, and the
-//      force of E_c on each neighbour slot m is written to fnbr[c][m] -- one plain store per slot.
-//   2. rebo_lj_gather_kernel<L>: L lanes per owned atom stream the trimmed, repacked Lennard-Jones
-//      list (full list, both directions, no parity rule needed), then gather the REBO forces
-//      F_a = -sum_m fnbr[a][m] + sum_{c in N(a)} fnbr[c][slot of a], reduce across the L lanes with
-//      wave shuffles and store f[a] once.
+//      force of E_c on each neighbour slot m is written as one aligned record fnbr[c][m] = {F, e/2};
+//      the centre's own share -sum_m F goes to fown[c].
+//   2. rebo_lj_tile_kernel: Lennard-Jones over the full list in both directions (no parity rule needed).
+//      One workgroup = one tile of 16 two-atom clusters; the union of their neighbourhoods is gathered
+//      ONCE into LDS and the cluster rows are 16-bit indices into it (rebo_lj_gather_kernel is the
+//      older per-cluster-list form, kept as the fallback when a union does not fit LDS).  The same kernel
+//      gathers the REBO forces  F_a = fown[a] + sum_{c in N(a)} fnbr[c][slot of a]  through the
+//      reverse-slot table, reduces across lanes with wave shuffles and stores f[a] once.
 // Nothing is written to ghost atoms; the explicit virial replaces virial_fdotr_compute.
 #include "mdp_common.h"
 
@@ -39,6 +42,15 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Work items that are neighbours
+// in space (consecutive along the Hilbert curve) share most of what they gather, so every XCD is given one
+// contiguous stretch of the items instead of every eighth one.
+__device__ __forceinline__ int xcd_contiguous(const int b, const int n)
+{
+  const int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
 template <int W> __device__ __forceinline__ double group_sum(double v)
@@ -150,8 +162,8 @@ __device__ __forceinline__ void finish_slot(const RebomosDev &P, const int tc, c
                                             const double dp, const bool owned, const int eflag, const double mx,
                                             const double my, const double mz, const double mr, const double mw,
                                             const double mdw, const double mp, const double mrinv, const double mVA,
-                                            double fx, double fy, double fz, const double acc1, const double Csum,
-                                            double *__restrict__ fnbr, double *__restrict__ eslot, CentreOut &o)
+                                            double &fx, double &fy, double &fz, const double acc1, const double Csum,
+                                            double *__restrict__ fnbr, double &eh, CentreOut &o)
 {
   const int tm = ((unsigned) je_m) >> 30;
   const int pt = tc * 2 + tm;
@@ -174,12 +186,10 @@ __device__ __forceinline__ void finish_slot(const RebomosDev &P, const int tc, c
   fz += radial * uz;
   // slot forces are filed under the neighbour's (static) candidate slot: the gather finds the
   // reverse slot through a table built once per list build
+  // one aligned 32-byte record per slot: force on the neighbour and its share of the pair energy
   const int tslot = je_m & 0x3FFFFFFF;
-  double *out = fnbr + 3 * (size_t) (off + tslot);
-  out[0] = fx;
-  out[1] = fy;
-  out[2] = fz;
-  if (eflag & MDP_EFLAG_ATOM) eslot[off + tslot] = 0.5 * ehalf;
+  eh = 0.5 * ehalf;
+  reinterpret_cast<double4 *>(fnbr)[off + tslot] = make_double4(fx, fy, fz, eh);
   if (owned) {
     o.e_acc += ehalf;
     // virial of the cluster: sum_m (x_m - x_c) (x) F_m = -sum_m d_m (x) F_m
@@ -277,7 +287,7 @@ template <int G>
 __global__ __launch_bounds__(256) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
-    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ eslot,
+    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ fown,
     double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag)
 {
   using C = CentreCfg<G>;
@@ -330,7 +340,8 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     }
   }
   if (have && s == 0) amask[c] = active;
-  if (n > C::CAP) { // outgrown: the general kernel takes this centre
+  const bool outgrown = n > C::CAP; // the general kernel takes this centre
+  if (outgrown) {
     if (s == 0) ovf[1 + atomicAdd(&ovf[0], 1)] = c;
     n = 0;
   }
@@ -419,9 +430,15 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
       acc1 += q[6] * g;
     }
   }
+  double eh = 0.0;
   if (act)
     finish_slot(P, tc, je[m], off, dp, owned, eflag, mx, my, mz, mr, mw, mdw, mp, mri, mVA, fx, fy, fz, acc1, Csum,
-                fnbr, eslot, o);
+                fnbr, eh, o);
+  // the centre's own share: minus the sum of its slot forces, plus the centre halves of the pair energies.
+  // Written once here so that the gather only has to follow the reverse slots.
+  const double ox = group_sum<G>(act ? fx : 0.0), oy = group_sum<G>(act ? fy : 0.0), oz = group_sum<G>(act ? fz : 0.0);
+  const double oe = (eflag & MDP_EFLAG_ATOM) ? group_sum<G>(eh) : 0.0;
+  if (owned && s == 0 && !outgrown) reinterpret_cast<double4 *>(fown)[c] = make_double4(-ox, -oy, -oz, oe);
   centre_tally(o, acc, eflag, vflag);
 }
 
@@ -434,7 +451,7 @@ template <bool VATOM>
 __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
     const RebomosDev P, const int *__restrict__ list, const int list_count, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
-    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ eslot,
+    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ fown,
     double *__restrict__ vslot, double *__restrict__ vatom, double *__restrict__ acc, int *__restrict__ flags,
     const int eflag, const int vflag)
 {
@@ -532,6 +549,7 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
     }
     const double Csum = group_sum<G>(csum_part);
     wave_lds_fence();
+    double ox = 0, oy = 0, oz = 0, oe = 0; // this lane's part of the centre's own share
     for (int mb = 0; mb < nw; mb += G) {
       const int m = mb + s;
       const bool act = m < n;
@@ -596,8 +614,13 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
         }
       }
       if (act) {
+        double eh = 0.0;
         finish_slot(P, tc, je[m], off, dp, owned, eflag, mx, my, mz, mr, mw, mdw, mp, mri, mVA, fx, fy, fz, acc1,
-                    Csum, fnbr, eslot, o);
+                    Csum, fnbr, eh, o);
+        ox += fx;
+        oy += fy;
+        oz += fz;
+        oe += eh;
         if (VATOM) {
           // v_tally2(i,j,tmp2,rij) with tmp2 = -C_m P' dw_m / r_m and ev_tally's pair part with this
           // centre's half of fpair: both give half to either end
@@ -633,6 +656,11 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
         }
       }
     }
+    ox = group_sum<G>(ox);
+    oy = group_sum<G>(oy);
+    oz = group_sum<G>(oz);
+    oe = group_sum<G>(oe);
+    if (owned && s == 0) reinterpret_cast<double4 *>(fown)[c] = make_double4(-ox, -oy, -oz, oe);
     wave_lds_fence();
   }
   centre_tally(o, acc, eflag, vflag);
@@ -815,14 +843,19 @@ __device__ __forceinline__ void lj_store(const bool have, const int kc, const in
 template <bool EV>
 __device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, const double4 &xj, double &fx,
                                              double &fy, double &fz, double &e, const int vflag, double &v0,
-                                             double &v1, double &v2, double &v3, double &v4, double &v5, bool &cub)
+                                             double &v1, double &v2, double &v3, double &v4, double &v5,
+                                             unsigned long long &cub)
 {
   const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
   const double rsq = dx * dx + dy * dy + dz * dz;
   const bool inwin = rsq >= q.lo && rsq <= q.hi;
-  cub = cub || (inwin && rsq < q.sw);
-  const double rs = inwin ? rsq : 1.0;
-  const double r2inv = fast_rcp(rs);
+  // wave-uniform flag kept in scalar registers: the compare masks are ANDed/ORed by the scalar unit
+  cub |= __builtin_amdgcn_fcmp(rsq, q.lo, 3 /*oge*/) & __builtin_amdgcn_fcmp(rsq, q.sw, 4 /*olt*/);
+  // 1/rsq: hardware seed (24 bits, measured) + ONE Newton step = 2e-15 relative.  Evaluated for every
+  // entry: rsq = 0 (the atom itself) gives inf/NaN, rsq = 1e60 (dummy entry) gives 0 -- both are discarded
+  // by the select below, which never propagates its unselected operand.
+  double r2inv = __builtin_amdgcn_rcp(rsq);
+  r2inv = fma(r2inv, fma(-rsq, r2inv, 1.0), r2inv);
   const double r6inv = r2inv * r2inv * r2inv;
   const double f12 = r6inv * (q.c1 * r6inv - q.c2) * r2inv;
   const double fpair = inwin ? f12 : 0.0;
@@ -879,7 +912,7 @@ __device__ __forceinline__ void lj_finish(const bool have, const int kc, const i
                                           double v3, double v4, double v5, const int *__restrict__ cand_off,
                                           const unsigned long long *__restrict__ amask,
                                           const int *__restrict__ rev, const double *__restrict__ fnbr,
-                                          const double *__restrict__ eslot, double *__restrict__ f,
+                                          const double *__restrict__ fown, double *__restrict__ f,
                                           double *__restrict__ eatom, double *__restrict__ acc, const int eflag,
                                           const int vflag, const int accumulate)
 {
@@ -899,19 +932,22 @@ __device__ __forceinline__ void lj_finish(const bool have, const int kc, const i
       const int nc = cand_off[ia + 1] - off;
       const unsigned long long act = amask[ia];
       double gx = 0, gy = 0, gz = 0, ge = 0;
+      if (s / CL == 0) { // the centre's own share (written by the centre kernel)
+        const double4 own = reinterpret_cast<const double4 *>(fown)[ia];
+        gx = own.x;
+        gy = own.y;
+        gz = own.z;
+        ge = own.w;
+      }
       for (int t = s / CL; t < nc; t += L / CL) {
         if (!((act >> t) & 1ull)) continue;
         const int ra = rev[off + t];
-        const double *o = fnbr + 3 * (size_t) (off + t);
-        gx -= o[0];
-        gy -= o[1];
-        gz -= o[2];
         if (ra >= 0) {
-          const double *oj = fnbr + 3 * (size_t) ra;
-          gx += oj[0];
-          gy += oj[1];
-          gz += oj[2];
-          if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+          const double4 oj = reinterpret_cast<const double4 *>(fnbr)[ra];
+          gx += oj.x;
+          gy += oj.y;
+          gz += oj.z;
+          ge += oj.w;
         }
       }
 #pragma unroll
@@ -935,7 +971,7 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
     const double4 *__restrict__ xq,
     const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const int *__restrict__ lj,
     const int *__restrict__ cand_off, const unsigned long long *__restrict__ amask, const int *__restrict__ rev,
-    const double *__restrict__ fnbr, const double *__restrict__ eslot, double *__restrict__ f,
+    const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
     double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag, const int accumulate)
 {
   // U = list entries per lane in flight (x CL pair evaluations each)
@@ -1029,7 +1065,7 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
     }
   }
   lj_finish<CL, L, GATHER>(have, kc, s, lane, nlocal, real, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, cand_off, amask, rev,
-                           fnbr, eslot, f, eatom, acc, eflag, vflag, accumulate);
+                           fnbr, fown, f, eatom, acc, eflag, vflag, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1041,45 +1077,50 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
 // ------------------------------------------------------------------------------------------------
 #define MDP_TILE 16 // clusters per tile = 256 threads / 16 lanes per cluster
 
-template <bool EV, bool GATHER, int U, int WAVES>
+template <bool EV, bool GATHER, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
-    const double4 *__restrict__ xq, const int cap, const int capL, const int *__restrict__ tu,
-    const int *__restrict__ tile_nu, const long long *__restrict__ lj_off, const int *__restrict__ lj_split,
-    const unsigned short *__restrict__ lj16, const int *__restrict__ cand_off,
-    const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const double *__restrict__ fnbr,
-    const double *__restrict__ eslot, double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc,
+    const double4 *__restrict__ xq, const int cap, const int capL, const int skip_above,
+    const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
+    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, const int *__restrict__ cand_off,
+    const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const int *__restrict__ rev16,
+    const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
+    double *__restrict__ eatom, double *__restrict__ acc,
     const int eflag, const int vflag, const int accumulate)
 {
   constexpr int CL = 2, L = 16;
+  constexpr int U = 1; // row entries per lane and iteration (segments are padded to L entries, so U * L must be L)
   constexpr int SK = 3; // union members per thread whose index loads are issued unconditionally (cap >= 2048)
-  extern __shared__ double s_pos[]; // x[capL] | y[capL] | z[capL]
-  double *__restrict__ s_x = s_pos;
-  double *__restrict__ s_y = s_pos + capL;
-  double *__restrict__ s_z = s_pos + 2 * capL;
+  extern __shared__ double s_pos[]; // [capL][3]: x y z of union member u at s_pos + 3u (one address, three offsets)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int s = lane % L;
-  const int t = order ? order[first + blockIdx.x] : first + blockIdx.x;
-  const int kc0 = t * MDP_TILE + tid / L;
-  const bool have = kc0 < nclus;
-  const int kc = have ? kc0 : 0;
+  const int bx = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int t = order ? order[first + bx] : first + bx;
+  const int kc = t * MDP_TILE + tid / L; // row (every tile has MDP_TILE rows; absent clusters: all-dummy rows)
 
   // A workgroup lives for ~10 us, so a chain of dependent global round trips (~1 us each) at its head or
   // tail is what would bound the kernel.  Everything that depends on the tile number alone is therefore
   // requested at once: union size and member indices, row bounds, the cluster's own atoms ...
-  const int nU = tile_nu[t];
+  // Natural tile order (order == null, the single-GPU case) saves the round trip through the order list;
+  // the rare tiles whose union exceeds this launch's LDS allocation are then predicated to empty here (no
+  // branch, so the loads below stay independent of this one) and taken by the "large" launch.
+  const int nU_all = tile_nu[2 * t];
+  const bool live = nU_all <= skip_above;
+  const int nU = live ? nU_all : 0;
+  const bool have = kc < nclus && live;
   const int *__restrict__ mem = tu + (size_t) t * cap;
   int sidx[SK];
 #pragma unroll
   for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // rows are cap >= 2048 long: always in bounds
   const long long b = lj_off[kc];
-  const int cnt = have ? (int) (lj_off[kc + 1] - b) : 0;
-  const int split = have ? lj_split[kc] : 0;
+  // segment lengths are equal for the four clusters of a wave by construction (tile_scan_kernel): scalars
+  const int cnt = __builtin_amdgcn_readfirstlane(live ? (int) (lj_off[kc + 1] - b) : 0);
+  const int split = __builtin_amdgcn_readfirstlane(live ? lj_split[kc] : 0);
   const unsigned short *__restrict__ row = lj16 + b;
   double4 xa[CL];
 #pragma unroll
-  for (int c = 0; c < CL; c++) xa[c] = xq[kc * CL + c < nlocal ? kc * CL + c : nlocal - 1];
+  for (int c = 0; c < CL; c++) xa[c] = xq[have && kc * CL + c < nlocal ? kc * CL + c : nlocal - 1];
   // ... (second round) the coordinates of the union, the head of both row segments ...
   {
     double4 sv[SK]; // all gathers in flight together (index clamped instead of a branch around each load)
@@ -1089,47 +1130,73 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     for (int k = 0; k < SK; k++) {
       const int u = tid + 256 * k;
       if (u < nU) {
-        s_x[u] = sv[k].x;
-        s_y[u] = sv[k].y;
-        s_z[u] = sv[k].z;
+        s_pos[3 * u] = sv[k].x;
+        s_pos[3 * u + 1] = sv[k].y;
+        s_pos[3 * u + 2] = sv[k].z;
       }
     }
   }
   for (int u = tid + 256 * SK; u < nU; u += 256) {
     const double4 v = xq[mem[u]];
-    s_x[u] = v.x;
-    s_y[u] = v.y;
-    s_z[u] = v.z;
+    s_pos[3 * u] = v.x;
+    s_pos[3 * u + 1] = v.y;
+    s_pos[3 * u + 2] = v.z;
   }
-  if (tid == 0) { // slot nU: what the ragged row ends point at -- outside every window
-    s_x[nU] = 1.0e30;
-    s_y[nU] = 0.0;
-    s_z[nU] = 0.0;
+  if (tid == 0) { // slot nU: what the padding entries of the rows point at -- outside every window
+    s_pos[3 * nU] = 1.0e30;
+    s_pos[3 * nU + 1] = 0.0;
+    s_pos[3 * nU + 2] = 0.0;
   }
+  // (both row segments are padded to whole 16-lane steps with the dummy index, so no load below needs a
+  // bounds check; reads run at most a few steps past a segment into the following rows / the slack)
   int jh[2][3 * U]; // first 3U entries per lane of the Mo segment and of the S segment
 #pragma unroll
   for (int seg = 0; seg < 2; seg++) {
-    const int kb = seg ? split : 0, ke = seg ? cnt : split;
 #pragma unroll
-    for (int u = 0; u < 3 * U; u++) {
-      const int k = kb + u * L + s;
-      jh[seg][u] = k < ke ? (int) row[k] : nU;
-    }
+    for (int u = 0; u < 3 * U; u++) jh[seg][u] = (int) row[(seg ? split : 0) + u * L + s];
   }
-  // ... and the slot-gather bookkeeping of the tail
+  // ... and the REBO slot forces of this atom: own centre (-sum of its slot forces) plus what the neighbour
+  // centres push onto it through the reverse slots.  Done here, not after the loops, so that its three
+  // dependent loads (row bounds -> reverse slot -> slot force) overlap the staging chain; L/CL lanes per atom.
   const int mine = s % CL;
-  const int ia_g = kc * CL + mine;
-  const bool g_on = GATHER && have && ia_g < nlocal;
-  int g_off = 0, g_nc = 0, g_ra[2] = {-1, -1};
-  unsigned long long g_act = 0;
-  if (g_on) {
-    g_off = cand_off[ia_g];
-    g_nc = cand_off[ia_g + 1] - g_off;
-    g_act = amask[ia_g];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int tt = s / CL + h * (L / CL);
-      if (tt < g_nc) g_ra[h] = rev[g_off + tt];
+  double gx = 0, gy = 0, gz = 0, ge = 0;
+  if (GATHER) {
+    const int ia_g = kc * CL + mine;
+    const bool g_on = have && ia_g < nlocal;
+    const int ia_c = g_on ? ia_g : 0;
+    // two reverse slots per lane (8 lanes per atom cover 16), every load unconditional with a clamped
+    // address so that all of a level is in flight together
+    const int t0 = s / CL, t1 = t0 + L / CL;
+    const unsigned long long g_act = g_on ? amask[ia_c] : 0ull;
+    const int r0 = rev16[(size_t) ia_c * 16 + t0], r1 = rev16[(size_t) ia_c * 16 + t1];
+    const double4 own = reinterpret_cast<const double4 *>(fown)[ia_c]; // the centre's own share
+    const bool ok0 = ((g_act >> t0) & 1ull) && r0 >= 0, ok1 = ((g_act >> t1) & 1ull) && r1 >= 0;
+    const double4 a0 = reinterpret_cast<const double4 *>(fnbr)[ok0 ? r0 : 0];
+    const double4 a1 = reinterpret_cast<const double4 *>(fnbr)[ok1 ? r1 : 0];
+    if (g_on && t0 == 0) {
+      gx = own.x;
+      gy = own.y;
+      gz = own.z;
+      ge = own.w;
+    }
+    gx += (ok0 ? a0.x : 0.0) + (ok1 ? a1.x : 0.0);
+    gy += (ok0 ? a0.y : 0.0) + (ok1 ? a1.y : 0.0);
+    gz += (ok0 ? a0.z : 0.0) + (ok1 ? a1.z : 0.0);
+    ge += (ok0 ? a0.w : 0.0) + (ok1 ? a1.w : 0.0);
+    if (g_act >> 16) { // rare: more than 16 candidates, the rest through the row itself
+      const int g_off = cand_off[ia_c];
+      const int g_nc = cand_off[ia_c + 1] - g_off;
+      for (int tt = 16 + s / CL; tt < g_nc; tt += L / CL) {
+        if (!((g_act >> tt) & 1ull)) continue;
+        const int ra = rev[g_off + tt];
+        if (ra >= 0) {
+          const double4 oj = reinterpret_cast<const double4 *>(fnbr)[ra];
+          gx += oj.x;
+          gy += oj.y;
+          gz += oj.z;
+          ge += oj.w;
+        }
+      }
     }
   }
 
@@ -1146,7 +1213,10 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
       ta[c] = 0;
     }
     if (!real[c]) xa[c].x = -1.0e30;
-    fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
+    fx[c] = c == mine ? gx : 0.0;
+    fy[c] = c == mine ? gy : 0.0;
+    fz[c] = c == mine ? gz : 0.0;
+    ee[c] = 0.0;
   }
   __syncthreads();
 
@@ -1156,7 +1226,7 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   // LDS reads are issued and is needed again two iterations later.  No register is copied and the loads
   // are unconditional (address clamped, validity re-derived at use), so the only wait inside the loop is
   // for the load issued a full trip earlier.
-  bool cub = false;
+  unsigned long long cub = 0;
   auto segment = [&](auto segc) {
     constexpr int SEG = decltype(segc)::value;
     const int kb = SEG ? split : 0, ke = SEG ? cnt : split;
@@ -1165,24 +1235,23 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     for (int c = 0; c < CL; c++) q[c] = lj_select(P, ta[c], SEG);
     int je[U], jo[U];
     double4 xe[U], xo[U];
+    const unsigned short *__restrict__ rp = row + kb + s; // this lane's column of the segment
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      xe[u] = make_double4(s_x[jh[SEG][u]], s_y[jh[SEG][u]], s_z[jh[SEG][u]], 0.0); // iteration 0
-      jo[u] = jh[SEG][U + u];                                                        // iteration 1
-      je[u] = jh[SEG][2 * U + u];                                                    // iteration 2
+      const double *p = s_pos + 3 * jh[SEG][u]; // iteration 0
+      xe[u] = make_double4(p[0], p[1], p[2], 0.0);
+      jo[u] = jh[SEG][U + u];     // iteration 1
+      je[u] = jh[SEG][2 * U + u]; // iteration 2
     }
 #pragma unroll 1
     for (int k0 = kb; k0 < ke; k0 += 2 * U * L) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int li = k0 + U * L + u * L + s < ke ? jo[u] : nU;
-        xo[u] = make_double4(s_x[li], s_y[li], s_z[li], 0.0);
+        const double *p = s_pos + 3 * jo[u];
+        xo[u] = make_double4(p[0], p[1], p[2], 0.0);
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int k = k0 + 3 * U * L + u * L + s;
-        jo[u] = (int) row[k < ke ? k : 0];
-      }
+      for (int u = 0; u < U; u++) jo[u] = (int) rp[3 * U * L + u * L];
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
@@ -1191,14 +1260,12 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int li = k0 + 2 * U * L + u * L + s < ke ? je[u] : nU;
-        xe[u] = make_double4(s_x[li], s_y[li], s_z[li], 0.0);
+        const double *p = s_pos + 3 * je[u];
+        xe[u] = make_double4(p[0], p[1], p[2], 0.0);
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int k = k0 + 4 * U * L + u * L + s;
-        je[u] = (int) row[k < ke ? k : 0];
-      }
+      for (int u = 0; u < U; u++) je[u] = (int) rp[4 * U * L + u * L];
+      rp += 2 * U * L;
       if (k0 + U * L < ke) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1213,10 +1280,11 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   segment(std::integral_constant<int, 1>{});
 
   // rare: some pair sat on the cubic inner spline -- walk the row again and replace those pairs
-  if (__any(cub)) {
+  if (cub) {
     for (int k = s; k < cnt; k += L) {
       const int li = row[k], seg = k < split ? 0 : 1;
-      const double xjx = s_x[li], xjy = s_y[li], xjz = s_z[li];
+      if (li == nU) continue; // padding
+      const double xjx = s_pos[3 * li], xjy = s_pos[3 * li + 1], xjz = s_pos[3 * li + 2];
 #pragma unroll
       for (int c = 0; c < CL; c++) {
         if (!real[c]) continue;
@@ -1246,39 +1314,13 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     }
   }
 
-  // REBO slot forces: own centre (-sum of slot forces) + what the neighbour centres push onto this atom
-  // (reverse slots requested at the top; candidates beyond the first two per lane are rare)
   double e_lj = 0.0;
 #pragma unroll
   for (int c = 0; c < CL; c++) e_lj += real[c] ? ee[c] : 0.0;
-  if (GATHER) {
-    double gx = 0, gy = 0, gz = 0, ge = 0;
-    if (g_on) {
-      int h = 0;
-      for (int tt = s / CL; tt < g_nc; tt += L / CL, h++) {
-        if (!((g_act >> tt) & 1ull)) continue;
-        const int ra = h < 2 ? (h ? g_ra[1] : g_ra[0]) : rev[g_off + tt];
-        const double *o = fnbr + 3 * (size_t) (g_off + tt);
-        gx -= o[0];
-        gy -= o[1];
-        gz -= o[2];
-        if (ra >= 0) {
-          const double *oj = fnbr + 3 * (size_t) ra;
-          gx += oj[0];
-          gy += oj[1];
-          gz += oj[2];
-          if (eflag & MDP_EFLAG_ATOM) ge += eslot[g_off + tt] + eslot[ra];
-        }
-      }
-    }
+  if (GATHER) { // per-atom REBO energy rides along after the LJ total has been taken
 #pragma unroll
     for (int c = 0; c < CL; c++)
-      if (c == mine) {
-        fx[c] += gx;
-        fy[c] += gy;
-        fz[c] += gz;
-        ee[c] += ge;
-      }
+      if (c == mine) ee[c] += ge;
   }
   lj_store<CL, L>(have, kc, s, lane, nlocal, e_lj, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
                   accumulate);
@@ -1291,7 +1333,7 @@ __global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, cons
                                                           const unsigned long long *__restrict__ amask,
                                                           const int *__restrict__ rev,
                                                           const double *__restrict__ fnbr,
-                                                          const double *__restrict__ eslot, double *__restrict__ f,
+                                                          const double *__restrict__ fown, double *__restrict__ f,
                                                           double *__restrict__ eatom, const int eflag,
                                                           const double *__restrict__ vslot,
                                                           double *__restrict__ vatom)
@@ -1306,19 +1348,22 @@ __global__ __launch_bounds__(256) void rebo_gather_kernel(const int nlocal, cons
     const int off = cand_off[ia];
     const int nc = cand_off[ia + 1] - off;
     const unsigned long long act = amask[ia];
+    if (s == 0) { // the centre's own share (written by the centre kernel)
+      const double4 own = reinterpret_cast<const double4 *>(fown)[ia];
+      gx = own.x;
+      gy = own.y;
+      gz = own.z;
+      ge = own.w;
+    }
     for (int t = s; t < nc; t += L) {
       if (!((act >> t) & 1ull)) continue;
       const int ra = rev[off + t];
-      const double *o = fnbr + 3 * (size_t) (off + t);
-      gx -= o[0];
-      gy -= o[1];
-      gz -= o[2];
       if (ra >= 0) {
-        const double *oj = fnbr + 3 * (size_t) ra;
-        gx += oj[0];
-        gy += oj[1];
-        gz += oj[2];
-        if (eflag & MDP_EFLAG_ATOM) ge += eslot[off + t] + eslot[ra];
+        const double4 oj = reinterpret_cast<const double4 *>(fnbr)[ra];
+        gx += oj.x;
+        gy += oj.y;
+        gz += oj.z;
+        ge += oj.w;
         if (vslot) // what the neighbour centre's cluster energy contributes to this atom's virial
 #pragma unroll
           for (int k6 = 0; k6 < 6; k6++) gv[k6] += vslot[6 * (size_t) ra + k6];
@@ -1354,6 +1399,7 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
                                                             const int *__restrict__ lj,
                                                             const unsigned short *__restrict__ lj16,
                                                             const int *__restrict__ tu, const int cap,
+                                                            const int *__restrict__ tile_nu,
                                                             double *__restrict__ vatom)
 {
   constexpr int L = 8;
@@ -1367,7 +1413,9 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
   if (have && ta >= 0) {
     const int kc = a / CL;
     const int *mem = lj16 ? tu + (size_t) (kc / MDP_TILE) * cap : nullptr; // tile lists: rows index the union
+    const int nU = lj16 ? tile_nu[2 * (kc / MDP_TILE)] : -1;
     for (long long k = lj_off[kc] + s; k < lj_off[kc + 1]; k += L) {
+      if (lj16 && lj16[k] == nU) continue; // row padding
       const double4 xj = xq[lj16 ? mem[lj16[k]] : lj[k]];
       const int pt = ta * 2 + (int) xj.w;
       const LJPar q = lj_load(P, pt);
@@ -1386,6 +1434,30 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
     v[k6] = group_sum<L>(v[k6]);
     if (have && s == 0) vatom[6 * (size_t) a + k6] += v[k6];
   }
+}
+
+// launch classes of the Lennard-Jones units (tiles or clusters): key = 2 * (reaches a remote ghost) + (tile
+// union too large for the small LDS allocation).  One-hot flags, scanned separately, give a stable order
+// [interior small | interior large | boundary small | boundary large].
+__global__ void unit_class_kernel(const int n, const int *__restrict__ is_bnd, const int *__restrict__ tile_nu,
+                                  const int small_limit, int *__restrict__ flag /* [4][n+1] */)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int key = (is_bnd && is_bnd[k] ? 2 : 0) + (tile_nu && tile_nu[2 * k] > small_limit ? 1 : 0);
+#pragma unroll
+  for (int q = 0; q < 4; q++) flag[(size_t) q * (n + 1) + k] = q == key;
+}
+
+__global__ void unit_order_kernel(const int n, const int *__restrict__ flag, const int *__restrict__ pos /* [4][n+2] */,
+                                  const int b1, const int b2, const int b3, int *__restrict__ order)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int base[4] = {0, b1, b2, b3};
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (flag[(size_t) q * (n + 1) + k]) order[base[q] + pos[(size_t) q * (n + 2) + k]] = k;
 }
 
 // does the cluster's list reach a remote ghost (index >= remote_start)?  Such clusters wait for the halo.
@@ -1641,9 +1713,9 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   if (s_over || nU > cap - 1) { // (slot nU is the kernel's dummy entry, so nU <= cap-1)
     if (tid == 0) {
       atomicOr(&tile_flag[0], 1);
-      tile_nu[t] = 0;
+      tile_nu[2 * t] = tile_nu[2 * t + 1] = 0;
     }
-    if (tid < MDP_TILE && t * MDP_TILE + tid < nclus) cnt[t * MDP_TILE + tid] = split[t * MDP_TILE + tid] = 0;
+    if (tid < MDP_TILE) cnt[t * MDP_TILE + tid] = split[t * MDP_TILE + tid] = 0;
     return;
   }
   int base0 = 0, base1 = N0;
@@ -1680,39 +1752,58 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
     c0 += __shfl_xor(c0, o, 64);
     c1 += __shfl_xor(c1, o, 64);
   }
+  // Row layout: every tile has MDP_TILE rows (absent clusters get all-dummy rows); both segments are padded
+  // with the dummy index to whole 16-lane steps AND to the longest of the four clusters that share a wave
+  // in the compute kernel, so that its loops are wave-uniform (idle lanes would cost the same time).
+  int p0 = (c0 + 15) & ~15, p1 = (c1 + 15) & ~15;
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    p0 = max(p0, __shfl_xor(p0, o, 64));
+    p1 = max(p1, __shfl_xor(p1, o, 64));
+  }
   const int kc = t * MDP_TILE + gq;
-  if (sq == 0 && kc < nclus) {
-    cnt[kc] = c0 + c1;
-    split[kc] = c0;
+  if (sq == 0) {
+    cnt[kc] = p0 + p1;
+    split[kc] = p0;
   }
   if (tid == 0) {
-    tile_nu[t] = nU;
+    tile_nu[2 * t] = nU;
+    tile_nu[2 * t + 1] = N0;
     atomicMax(&tile_flag[1], nU);
   }
 }
 
-// Pass 2: each cluster (16 lanes) walks its tile's masks in union order and keeps the entries with its bit
+// Pass 2: each cluster (16 lanes) walks its tile's masks in union order and keeps the entries with its bit;
+// the Mo segment and the S segment are each padded to a whole 16-lane step with the dummy index nU
 __global__ __launch_bounds__(256) void tile_fill_kernel(const int nclus, const int cap,
                                                         const int *__restrict__ tile_nu,
                                                         const unsigned short *__restrict__ tmask,
                                                         const long long *__restrict__ off,
+                                                        const int *__restrict__ split,
                                                         unsigned short *__restrict__ lj16)
 {
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int gq = tid / 16, sq = tid % 16, glane0 = lane - sq;
   const int kc = t * MDP_TILE + gq;
   const bool have = kc < nclus;
-  const int nU = tile_nu[t];
+  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1];
   const unsigned short *mm = tmask + (size_t) t * cap;
-  unsigned short *row = have ? lj16 + off[kc] : nullptr;
+  const long long b = off[kc];
+  const int len[2] = {split[kc], (int) (off[kc + 1] - b) - split[kc]}; // padded segment lengths (tile_scan_kernel)
+  unsigned short *row = lj16 + b;
   const unsigned long long below = (1ull << sq) - 1ull;
-  int n = 0;
-  for (int base = 0; base < nU; base += 16) {
-    const int u = base + sq;
-    const bool k = have && u < nU && ((mm[u] >> gq) & 1);
-    const unsigned long long b = (__ballot(k) >> glane0) & 0xFFFFull;
-    if (k) row[n + __popcll(b & below)] = (unsigned short) u;
-    n += __popcll(b);
+  for (int seg = 0; seg < 2; seg++) {
+    const int ub = seg ? N0 : 0, ue = seg ? nU : N0;
+    int n = 0;
+    for (int base = ub; base < ue; base += 16) {
+      const int u = base + sq;
+      const bool k = have && u < ue && ((mm[u] >> gq) & 1);
+      const unsigned long long bal = (__ballot(k) >> glane0) & 0xFFFFull;
+      if (k) row[n + __popcll(bal & below)] = (unsigned short) u;
+      n += __popcll(bal);
+    }
+    for (int q = n + sq; q < len[seg]; q += 16) row[q] = (unsigned short) nU; // padding: the dummy slot
+    row += len[seg];
   }
 }
 
@@ -1726,7 +1817,7 @@ __global__ __launch_bounds__(256) void tile_boundary_kernel(const int ntile, con
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= ntile) return;
   const int *mem = tu + (size_t) t * cap;
-  const int nU = tile_nu[t];
+  const int nU = tile_nu[2 * t];
   int hit = 0;
   for (int u = lane; u < nU; u += 64) hit |= mem[u] >= remote_start;
   hit = __any(hit);
@@ -1847,9 +1938,11 @@ __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double
 }
 
 // rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
+// rev16: the first 16 reverse slots of every owned atom at a fixed stride (-1 beyond the row), so that the
+// gather reaches a slot record in two dependent loads instead of three (no row offset to fetch first)
 __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *__restrict__ cand_off,
                                                   const int *__restrict__ cand, int *__restrict__ rev,
-                                                  int *__restrict__ flags)
+                                                  int *__restrict__ rev16, int *__restrict__ flags)
 {
   const int s = threadIdx.x % RP_L;
   const long long a64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
@@ -1867,7 +1960,10 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
         break;
       }
     rev[off + t] = r;
+    if (t < 16) rev16[(size_t) a * 16 + t] = r;
   }
+  static_assert(RP_L == 16, "one lane per rev16 entry");
+  if (s >= nc) rev16[(size_t) a * 16 + s] = -1;
 }
 
 // current REBO coordination -> lane-group class, appended to the class lists (one atomic per wave
@@ -2013,9 +2109,10 @@ int mdp_rebomos_repack(mdp_ctx *c)
   c->cluster = cl;
   const int nclus = (nlocal + cl - 1) / cl;
   c->nclus = nclus;
-  MDP_HIP(c, c->lj_split.reserve(nclus + 1));
-  MDP_HIP(c, c->lj_cnt.reserve(nclus + 1));
-  MDP_HIP(c, c->lj_off.reserve(nclus + 2));
+  const int nrow_max = ((nclus + MDP_TILE - 1) / MDP_TILE) * MDP_TILE; // tile lists keep MDP_TILE rows per tile
+  MDP_HIP(c, c->lj_split.reserve(nrow_max + 1));
+  MDP_HIP(c, c->lj_cnt.reserve(nrow_max + 1));
+  MDP_HIP(c, c->lj_off.reserve(nrow_max + 2));
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
@@ -2056,7 +2153,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (tiled) {
     int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
     MDP_HIP(c, c->tile_flag.reserve(4));
-    MDP_HIP(c, c->tile_nu.reserve(ntile + 1));
+    MDP_HIP(c, c->tile_nu.reserve((size_t) 2 * ntile + 2));
     for (;;) {
       MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
       MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
@@ -2087,12 +2184,16 @@ int mdp_rebomos_repack(mdp_ctx *c)
   c->lj_tiled = tiled;
   c->ntile = tiled ? ntile : 0;
   if (tiled && getenv("MDP_DEBUG")) {
-    std::vector<int> h(ntile);
-    MDP_HIP(c, hipMemcpy(h.data(), c->tile_nu.p, sizeof(int) * ntile, hipMemcpyDeviceToHost));
+    std::vector<int> h(2 * (size_t) ntile);
+    MDP_HIP(c, hipMemcpy(h.data(), c->tile_nu.p, sizeof(int) * 2 * ntile, hipMemcpyDeviceToHost));
     double sum = 0;
-    for (int v : h) sum += v;
+    for (int k = 0; k < ntile; k++) sum += h[2 * k];
     fprintf(stderr, "[mdp] tile lists: %d tiles, cap %d, union mean %.1f max %d\n", ntile, c->tile_cap, sum / ntile,
             c->tile_maxu);
+
+    int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < ntile; k++) hist[h[2 * k] / 200 < 8 ? h[2 * k] / 200 : 8]++;
+    for (int k = 0; k < 9; k++) fprintf(stderr, "[mdp]   union %4d.. : %d tiles\n", 200 * k, hist[k]);
   }
   if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
@@ -2104,28 +2205,34 @@ int mdp_rebomos_repack(mdp_ctx *c)
     else MDP_CB(4, false, nullptr, nullptr);
   }
   MDP_HIP(c, hipGetLastError());
-  MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nclus));
+  const int nrow = tiled ? ntile * MDP_TILE : nclus;
+  MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nrow));
   int cand_total = 0;
   long long lj_total = 0;
   MDP_HIP(c, hipMemcpyAsync(&cand_total, c->cand_off.p + nall, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipMemcpyAsync(&lj_total, c->lj_off.p + nclus, sizeof(long long), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(&lj_total, c->lj_off.p + nrow, sizeof(long long), hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   c->cand_total = cand_total;
   c->lj_total = lj_total;
+  if (tiled && getenv("MDP_DEBUG"))
+    fprintf(stderr, "[mdp] row entries incl. padding: %lld (%.1f per cluster)\n", lj_total, (double) lj_total / nclus);
   MDP_HIP(c, c->cand.reserve((size_t) cand_total + 1));
   if (tiled)
-    MDP_HIP(c, c->lj16.reserve((size_t) lj_total + 1));
+    MDP_HIP(c, c->lj16.reserve((size_t) lj_total + 256)); // slack: rows are read a few steps past their end
   else
     MDP_HIP(c, c->lj.reserve((size_t) lj_total + 1));
   MDP_HIP(c, c->rev.reserve((size_t) cand_total + 1));
-  MDP_HIP(c, c->fnbr.reserve((size_t) 3 * cand_total + 3));
-  MDP_HIP(c, c->eslot.reserve((size_t) cand_total + 1));
+  MDP_HIP(c, c->rev16.reserve((size_t) 16 * nlocal + 16));
+  MDP_HIP(c, c->fnbr.reserve((size_t) 4 * cand_total + 4));
+  MDP_HIP(c, c->fown.reserve((size_t) 4 * nall + 4));
+  MDP_HIP(c, hipMemsetAsync(c->fown.p, 0, sizeof(double) * 4 * nall, st)); // atoms that are no centre (NULL type) keep 0
   if (nall)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p);
   if (tiled)
-    tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj16.p);
+    tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
+                                            c->lj16.p);
   if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
     if (cl == 1) MDP_CB(1, true, c->lj_off.p, c->lj.p);
@@ -2134,35 +2241,46 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
-  // interior / boundary partition of the launch units -- tiles, or clusters without tile lists -- (only
-  // meaningful with remote ghosts)
+  // launch classes of the units (tiles, or clusters without tile lists): interior/boundary for the halo
+  // overlap (only with remote ghosts), small/large union for the LDS allocation of the tile kernel
   const int nunit = tiled ? ntile : nclus;
   c->lj_units = nunit;
-  c->lj_units_interior = nunit;
-  c->nclus_interior = nclus;
   c->split_halo = false;
-  if (c->md && c->remote_start < nall && nunit > 0) {
-    MDP_HIP(c, c->cl_flag.reserve((size_t) 2 * (nunit + 1)));
-    MDP_HIP(c, c->cl_pos.reserve((size_t) 2 * (nunit + 2)));
+  c->lj_ordered = false;
+  for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
+  // 5 workgroups per CU need <= 32 KB each: unions up to kSmallUnion members (+ the dummy slot), 24 bytes apiece
+  constexpr int kSmallUnion = 1359;
+  c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
+  const bool remote = c->md && c->remote_start < nall;
+  if (nunit > 0 && (remote || (tiled && c->tile_maxu > kSmallUnion))) {
+    MDP_HIP(c, c->cl_flag.reserve((size_t) 6 * (nunit + 1)));
+    MDP_HIP(c, c->cl_pos.reserve((size_t) 4 * (nunit + 2)));
     MDP_HIP(c, c->cl_order.reserve(nunit + 1));
-    int *is_int = c->cl_flag.p, *is_bnd = c->cl_flag.p + (nunit + 1);
-    int *pos_int = c->cl_pos.p, *pos_bnd = c->cl_pos.p + (nunit + 2);
-    if (tiled)
-      tile_boundary_kernel<<<(ntile + 3) / 4, 256, 0, st>>>(ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
-                                                            c->tu.p, is_int, is_bnd);
-    else
-      cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p,
-                                                                 is_int, is_bnd);
+    int *flag4 = c->cl_flag.p, *is_int = c->cl_flag.p + (size_t) 4 * (nunit + 1), *is_bnd = is_int + (nunit + 1);
+    if (remote) {
+      if (tiled)
+        tile_boundary_kernel<<<(ntile + 3) / 4, 256, 0, st>>>(ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
+                                                              c->tu.p, is_int, is_bnd);
+      else
+        cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p,
+                                                                   is_int, is_bnd);
+    }
+    unit_class_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, remote ? is_bnd : nullptr,
+                                                           tiled ? c->tile_nu.p : nullptr, kSmallUnion, flag4);
     MDP_HIP(c, hipGetLastError());
-    MDP_TRY(mdp_scan_exclusive_int(c, is_int, pos_int, nunit));
-    MDP_TRY(mdp_scan_exclusive_int(c, is_bnd, pos_bnd, nunit));
-    int nint = 0;
-    MDP_HIP(c, hipMemcpyAsync(&nint, pos_int + nunit, sizeof(int), hipMemcpyDeviceToHost, st));
+    int total[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; q++) {
+      int *pos = c->cl_pos.p + (size_t) q * (nunit + 2);
+      MDP_TRY(mdp_scan_exclusive_int(c, flag4 + (size_t) q * (nunit + 1), pos, nunit));
+      MDP_HIP(c, hipMemcpyAsync(&total[q], pos + nunit, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     MDP_HIP(c, hipStreamSynchronize(st));
-    cluster_order_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, nint, is_int, pos_int, pos_bnd, c->cl_order.p);
+    for (int q = 0; q < 4; q++) c->lj_class_base[q + 1] = c->lj_class_base[q] + total[q];
+    unit_order_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, flag4, c->cl_pos.p, c->lj_class_base[1],
+                                                           c->lj_class_base[2], c->lj_class_base[3], c->cl_order.p);
     MDP_HIP(c, hipGetLastError());
-    c->lj_units_interior = nint;
-    c->split_halo = true;
+    c->lj_ordered = true;
+    c->split_halo = remote;
   }
   if (nall)
     classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
@@ -2170,7 +2288,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
-                                                                     c->flags.p);
+                                                                     c->rev16.p, c->flags.p);
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
@@ -2248,42 +2366,45 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
   const int grid = (n + per_block - 1) / per_block;
   rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
                                                      c->xq.p, c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
-                                                     c->eslot.p, c->acc.p, c->ovf.p, eflag, vflag);
+                                                     c->fown.p, c->acc.p, c->ovf.p, eflag, vflag);
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
-static int launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, int vflag, bool accumulate)
+// one launch class of the Lennard-Jones units (see unit_class_kernel): 0/1 interior, 2/3 boundary; odd = large unions
+static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, bool accumulate)
 {
+  int first = c->lj_class_base[klass], count = c->lj_class_base[klass + 1] - first;
   if (count <= 0) return MDP_OK;
   hipStream_t st = c->stream;
-  const int *order = c->split_halo ? c->cl_order.p : nullptr;
+  const int *order = c->lj_ordered ? c->cl_order.p : nullptr;
+  int skip_above = 1 << 30;
+  if (c->lj_tiled && order && !c->split_halo && klass == 0) { // natural order, large tiles predicated away
+    order = nullptr;
+    first = 0;
+    count = c->ntile;
+    skip_above = c->tile_small;
+  }
   const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
-  if (c->lj_tiled) { // first/count in tiles
-    const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  if (c->lj_tiled) {
+    const bool small = !(klass & 1);
+    const int capL = ((small ? c->tile_small : c->tile_maxu) + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 3 * sizeof(double);
-#define MDP_LJT3(EVV, GV, UV, WV)                                                                                   \
+#define MDP_LJT(EVV, GV, WV)                                                                                        \
   do {                                                                                                              \
     if (lds > 48 * 1024)                                                                                            \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile_kernel<EVV, GV, UV, WV>,                           \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile_kernel<EVV, GV, WV>,                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                       \
-    rebo_lj_tile_kernel<EVV, GV, UV, WV><<<count, 256, lds, st>>>(                                                  \
-        c->rebomos, c->nlocal, order, first, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p,           \
-        c->lj_off.p, c->lj_split.p, c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->fnbr.p, c->eslot.p, c->f.p,  \
-        c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                                    \
+    rebo_lj_tile_kernel<EVV, GV, WV><<<count, 256, lds, st>>>(                                                      \
+        c->rebomos, c->nlocal, order, first, c->nclus, c->xq.p, c->tile_cap, capL, skip_above, c->tu.p,            \
+        c->tile_nu.p, c->lj_off.p, c->lj_split.p, c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p,       \
+        c->fnbr.p,                                                                                                  \
+        c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                \
   } while (0)
-#define MDP_LJT(EVV, GV)                                                                                            \
-  do {                                                                                                              \
-    static const int variant = getenv("MDP_LJ_VARIANT") ? atoi(getenv("MDP_LJ_VARIANT")) : 0;                       \
-    if (variant == 1) MDP_LJT3(EVV, GV, 2, 3);                                                                      \
-    else if (variant == 2) MDP_LJT3(EVV, GV, 2, 4);                                                                 \
-    else if (variant == 3) MDP_LJT3(EVV, GV, 1, 3);                                                                 \
-    else MDP_LJT3(EVV, GV, 1, 4);                                                                                   \
-  } while (0)
-    if (ev && gather) MDP_LJT(true, true);
-    else if (ev) MDP_LJT(true, false);
-    else if (gather) MDP_LJT(false, true);
-    else MDP_LJT(false, false);
-#undef MDP_LJT3
+    // the force-only variants fit 5 waves per SIMD (<= 102 VGPRs); with small unions LDS allows 5 workgroups too
+    if (ev && gather) MDP_LJT(true, true, 4);
+    else if (ev) MDP_LJT(true, false, 4);
+    else if (gather) MDP_LJT(false, true, 4);
+    else MDP_LJT(false, false, 4);
 #undef MDP_LJT
     return MDP_OK;
   }
@@ -2292,7 +2413,7 @@ static int launch_lj(mdp_ctx *c, int first, int count, bool gather, int eflag, i
 #define MDP_LJ(CLV, EVV, GV)                                                                                        \
   rebo_lj_gather_kernel<CLV, L, EVV, GV><<<grid, 256, 0, st>>>(                                                      \
       c->rebomos, c->nlocal, order, first, count, c->xq.p, c->lj_off.p, c->lj_split.p, c->lj.p, c->cand_off.p,       \
-      c->amask.p, c->rev.p, c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0)
+      c->amask.p, c->rev.p, c->fnbr.p, c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0)
 #define MDP_LJ2(CLV)                                                                                                \
   do {                                                                                                              \
     if (ev && gather) MDP_LJ(CLV, true, true);                                                                      \
@@ -2323,7 +2444,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
   if (grid)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
                                                             c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
-                                                            c->eslot.p, nullptr, nullptr, c->acc.p, c->flags.p,
+                                                            c->fown.p, nullptr, nullptr, c->acc.p, c->flags.p,
                                                             eflag, vflag);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
@@ -2339,7 +2460,7 @@ static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
     const int grid = n / 8 + 1 < 2048 ? n / 8 + 1 : 2048;
     rebo_centre_general_kernel<true><<<grid, 256, 0, st>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
                                                            c->nlocal, c->xq.p, c->cand_off.p, c->cand.p, c->amask.p,
-                                                           c->fnbr.p, c->eslot.p, c->vslot.p, c->vatom.p, c->acc.p,
+                                                           c->fnbr.p, c->fown.p, c->vslot.p, c->vatom.p, c->acc.p,
                                                            c->flags.p, eflag, vflag);
   }
   MDP_HIP(c, hipGetLastError());
@@ -2363,7 +2484,8 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vslot.reserve((size_t) 6 * c->cand_total + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, c->stream));
   }
-  if (c->split_halo) MDP_TRY(launch_lj(c, 0, c->lj_units_interior, /*gather=*/false, eflag, vflag, /*accumulate=*/false));
+  if (c->split_halo)
+    for (int k = 0; k < 2; k++) MDP_TRY(launch_lj(c, k, /*gather=*/false, eflag, vflag, /*accumulate=*/false));
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -2380,24 +2502,21 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
     MDP_TRY(launch_centres(c, eflag, vflag));
   mdp_time_mark(c, 1);
   if (c->split_halo || va) {
-    if (c->split_halo)
-      MDP_TRY(launch_lj(c, c->lj_units_interior, c->lj_units - c->lj_units_interior, false, eflag, vflag, false));
-    else
-      MDP_TRY(launch_lj(c, 0, c->lj_units, false, eflag, vflag, false));
+    for (int k = c->split_halo ? 2 : 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
     if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
-                                                                   c->fnbr.p, c->eslot.p, c->f.p, c->eatom.p, eflag,
+                                                                   c->fnbr.p, c->fown.p, c->f.p, c->eatom.p, eflag,
                                                                    va ? c->vslot.p : nullptr, c->vatom.p);
       if (va) {
         const int grid = (c->nlocal + 31) / 32;
         const unsigned short *lj16 = c->lj_tiled ? c->lj16.p : nullptr;
-        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
-        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
-        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->vatom.p);
+        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p);
+        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p);
+        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p);
       }
     }
   } else {
-    MDP_TRY(launch_lj(c, 0, c->lj_units, /*gather=*/true, eflag, vflag, false));
+    for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, /*gather=*/true, eflag, vflag, false));
   }
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 2);

@@ -40,8 +40,10 @@ class RankPlan:
 
 
 class Decomposition:
-    def __init__(self, box: S.Box, x: np.ndarray, nranks: int, cutghost: float, sort_cell: float | None = 3.0):
-        """x: wrapped positions of ALL atoms (identical on every rank)"""
+    def __init__(self, box: S.Box, x: np.ndarray, nranks: int, cutghost: float, sort_cell: float | None = 3.0,
+                 type_=None):
+        """x: wrapped positions of ALL atoms (identical on every rank); type_: their types (groups the
+        storage order by element inside short stretches of the curve, see resident.spatial_order)"""
         from .resident import spatial_order
         self.box, self.nranks, self.cut = box, nranks, cutghost
         self.grid = np.array(proc_grid(nranks))
@@ -56,7 +58,7 @@ class Decomposition:
         for r in range(nranks):
             idx = np.nonzero(self.rank_of == r)[0]
             if sort_cell and len(idx):
-                idx = idx[spatial_order(x[idx], box.lo, sort_cell)]
+                idx = idx[spatial_order(x[idx], box.lo, sort_cell, group=None if type_ is None else np.asarray(type_)[idx])]
             self.owned.append(idx)
             self.local_index[idx] = np.arange(len(idx))
         # ghosts of every rank (every rank needs every other rank's list to know what to send)

@@ -72,10 +72,20 @@ def hilbert_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
-def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
-    """the order atoms are stored in on the device (MDP_ORDER=morton selects the Z-order curve)"""
+def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float, group=None, chunk: int = 96) -> np.ndarray:
+    """The order atoms are stored in on the device: along a Hilbert curve (MDP_ORDER=morton: Z-order), and,
+    when `group` (the atom types) is given, each stretch of `chunk` consecutive atoms additionally sorted by
+    type.  The second step makes the 2-atom clusters and 32-atom tiles of the Lennard-Jones lists
+    element-pure: pair cutoffs differ per element pair (Mo-Mo 10.5 A, S-S 7.8 A), a mixed cluster evaluates
+    both atoms against the larger neighbourhood, and the four clusters sharing a wavefront all run as long as
+    the longest list among them.  chunk = 3 tiles keeps every tile inside one compact stretch of the curve."""
     import os
-    return morton_order(x, lo, cell) if os.environ.get("MDP_ORDER", "hilbert") == "morton" else hilbert_order(x, lo, cell)
+    order = morton_order(x, lo, cell) if os.environ.get("MDP_ORDER", "hilbert") == "morton" else hilbert_order(x, lo, cell)
+    if group is not None and chunk > 0 and len(order) and os.environ.get("MDP_ORDER_GROUP", "1") != "0":
+        g = np.asarray(group)[order].astype(np.int64)
+        key = (np.arange(len(order), dtype=np.int64) // chunk) * (int(g.max()) + 1) + g
+        order = order[np.argsort(key, kind="stable")]
+    return order
 
 
 class Domain:
@@ -116,7 +126,7 @@ class Domain:
         v = np.zeros_like(x) if v0 is None else np.asarray(v0, dtype=np.float64)
         t, g = s.type, s.tag
         if sort:
-            order = spatial_order(x, s.box.lo, 3.0)
+            order = spatial_order(x, s.box.lo, 3.0, group=s.type)
             x, v, t, g = x[order], v[order], t[order], g[order]
         owner, shift = S.make_ghosts(s.box, x, cutghost)
         shift_cart = shift @ s.box.h.T
@@ -290,7 +300,7 @@ def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001
         return d
     from . import decomp
     xw = S.wrap(s.box, s.x)
-    dec = decomp.Decomposition(s.box, xw, dist.get_world_size(), cutghost)
+    dec = decomp.Decomposition(s.box, xw, dist.get_world_size(), cutghost, type_=s.type)
     plan = dec.plan(dist.get_rank())
     d = RankDomain.from_plan(ctx, style, s, xw, plan, skin, map_, v0=v0, dt=dt)
     d.tags_local = s.tag[plan.owned]
