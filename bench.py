@@ -231,7 +231,9 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get(f"{args.workload}:{'x'.join(map(str, args.replicate))}:{world}")
+            tab = json.load(open(pmc_file))
+            key = f"{args.workload}:{'x'.join(map(str, args.replicate))}:{world}"
+            traffic = tab.get(f"{key}:{knames[kdom]}", tab.get(key))
         except Exception:
             traffic = None
     out = {
