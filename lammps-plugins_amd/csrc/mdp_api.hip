@@ -201,6 +201,7 @@ int mdp_destroy(mdp_ctx *c)
   c->is_center.release();
   c->class_list.release();
   c->class_count.release();
+  c->pk_cand.release();
   c->amask.release();
   c->xhold_all.release();
   c->ovf.release();

@@ -154,6 +154,8 @@ struct mdp_ctx {
   DevBuf<int> is_center;          // [nall]
   DevBuf<int> class_list;         // [4][nall]
   DevBuf<int> class_count;        // [4]
+  DevBuf<int> pk_cand;            // per class, per centre: its first UA*G candidates, contiguous in class order
+  size_t pk_base[4] = {0, 0, 0, 0};
   int h_class_count[4] = {0, 0, 0, 0};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)

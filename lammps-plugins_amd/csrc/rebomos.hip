@@ -70,6 +70,27 @@ __device__ __forceinline__ int wave_max_int(int v)
   return v;
 }
 
+// 1/x to ~1 ulp: hardware seed + two Newton steps (5 instructions instead of the ~12 of an IEEE divide;
+// the result feeds products whose tolerance is 1e-9 relative)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// 1/sqrt(x) to ~1 ulp: hardware seed + two Newton steps (replaces an IEEE sqrt and an IEEE divide)
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+
 // switching function, pair_rebomos.h:195-211
 __device__ __forceinline__ double sp_switch(double r, double rmin, double rinv, double &dw)
 {
@@ -86,6 +107,26 @@ __device__ __forceinline__ double sp_switch(double r, double rmin, double rinv, 
   sincospi(t, &s, &c);
   dw = -0.5 * kPi * s * rinv;
   return 0.5 * (1.0 + c);
+}
+
+// sin(pi u) and cos(pi u) for u in [0, 1/2] (the only range the G(cos) blend needs): fold to [0, 1/4] and
+// evaluate the Taylor series in v^2 there (truncation < 5e-17); ~25 instructions instead of the general
+// sincospi's argument reduction and quadrant logic.
+__device__ __forceinline__ void sincospi_half(const double u, double &sn, double &cs)
+{
+  const bool fold = u > 0.25;
+  const double v = fold ? 0.5 - u : u;
+  const double w = v * v;
+  constexpr double S[8] = {3.14159265358979312e+00, -5.16771278004996937e+00, 2.55016403987734508e+00, -5.99264529320791883e-01, 8.21458866111281910e-02, -7.37043094571434784e-03, 4.66302805767612337e-04, -2.19153534478302037e-05};
+  constexpr double C[9] = {1.00000000000000000e+00, -4.93480220054467900e+00, 4.05871212641676760e+00, -1.33526276885458928e+00, 2.35330630358893123e-01, -2.58068913900140508e-02, 1.92957430940392206e-03, -1.04638104924845650e-04, 4.30306958703294391e-06};
+  double ps = S[7], pc = C[8];
+#pragma unroll
+  for (int k = 6; k >= 0; k--) ps = fma(ps, w, S[k]);
+#pragma unroll
+  for (int k = 7; k >= 0; k--) pc = fma(pc, w, C[k]);
+  ps *= v;
+  sn = fold ? pc : ps;
+  cs = fold ? ps : pc;
 }
 
 __device__ __forceinline__ double poly6(const double *c, double x, double &d)
@@ -139,10 +180,11 @@ __device__ __forceinline__ double gspline(const double *cb, const double *cg, do
   double dgcos, dgamma;
   const double gcos = poly6(cb, c, dgcos);
   const double gamma = poly6(cg, c, dgamma);
+  // psi = (1 - cos 2 pi u)/2 = sin^2(pi u),  psi' = pi sin 2 pi u = 2 pi sin(pi u) cos(pi u),  u = c - 1/2
   double s, co;
-  sincospi(2.0 * (c - 0.5), &s, &co);
-  const double psi = 0.5 * (1.0 - co);
-  const double dpsi = kPi * s;
+  sincospi_half(c - 0.5, s, co);
+  const double psi = s * s;
+  const double dpsi = 2.0 * kPi * s * co;
   dgdc = dgcos + dpsi * (gamma - gcos) + psi * (dgamma - dgcos);
   return gcos + psi * (gamma - gcos);
 }
@@ -152,6 +194,8 @@ __device__ __forceinline__ double gspline(const double *cb, const double *cg, do
 // ------------------------------------------------------------------------------------------------
 // per-slot LDS record of a centre's neighbour: dx dy dz r w dw C p 1/r V_A   (d = x_c - x_m)
 constexpr int kRec = 10;
+// the fast kernels need neither p nor V_A in LDS: dx dy dz r w dw C 1/r
+constexpr int kRecF = 9, kInvF = 7; // stride 9 doubles: 16 lanes reading 16 records touch 16 distinct bank pairs
 
 struct CentreOut {
   double e_acc, v0, v1, v2, v3, v4, v5;
@@ -175,9 +219,10 @@ __device__ __forceinline__ void finish_slot(const RebomosDev &P, const int tc, c
     const double pre = mw * P.A[pt] * ex;
     const double VR = pre * (1.0 + P.Q[pt] * mrinv);
     double dVR = pre * (-P.alpha[pt] - P.Q[pt] * mrinv * mrinv - P.Q[pt] * P.alpha[pt] * mrinv);
-    dVR += VR / mw * mdw;
+    const double swl = fast_rcp(mw) * mdw; // (dw/dr)/w
+    dVR += VR * swl;
     double dVA = -P.beta[pt] * mVA;
-    dVA += mVA / mw * mdw;
+    dVA += mVA * swl;
     radial += 0.5 * (dVR + mp * dVA);
     ehalf = 0.5 * (VR + mp * mVA);
   }
@@ -229,7 +274,7 @@ __device__ __forceinline__ void centre_tally(const CentreOut &o, double *__restr
 
 // phase A for one candidate: distance test against rcmax (pair_rebomos.cpp:337), ballot compaction into
 // the centre's LDS slots in candidate order.  Returns nothing; updates n / active / nsum.
-template <int G, int CAP>
+template <int G, int CAP, int REC>
 __device__ __forceinline__ void centre_take(const RebomosDev &P, const int tc, const double4 xc, const bool valid,
                                             const int t, const double4 xj, const int s, const int glane0,
                                             const int base, double *rec, int *je, int &n,
@@ -245,17 +290,18 @@ __device__ __forceinline__ void centre_take(const RebomosDev &P, const int tc, c
   const int pos = n + __popcll(gb & ((1ull << s) - 1ull));
   if (pred && pos < CAP) {
     const int pt = tc * 2 + tj;
-    const double r = sqrt(rsq);
+    const double rinv = rsqrt_nr(rsq); // r and 1/r from one reciprocal square root
+    const double r = rsq * rinv;
     double dw;
     const double w = sp_switch(r, P.rcmin[pt], P.rcinv[pt], dw);
-    double *q = rec + pos * kRec;
+    double *q = rec + pos * REC;
     q[0] = dx;
     q[1] = dy;
     q[2] = dz;
     q[3] = r;
     q[4] = w;
     q[5] = dw;
-    q[8] = 1.0 / r;
+    q[REC == kRec ? 8 : kInvF] = rinv; // the fast kernels' short record keeps 1/r in slot 7
     je[pos] = t | (tj << 30);
     nsum += w; // nM + nS (pair_rebomos.cpp:339-342); only their sum is ever used (:628, h:175)
   }
@@ -267,18 +313,14 @@ template <int G> struct CentreCfg {
   static constexpr int CAP = G;          // fast kernel: every neighbour has its own lane
   static constexpr int GPW = 64 / G;     // centres per wave
   static constexpr int WPB = 4;          // waves per block
-  static constexpr int STRIDE = CAP * kRec + 2; // small pad: spreads the groups over the LDS banks
-  // {G(cos), G'(cos)} per unordered neighbour pair
-  static constexpr int NPAIR = G * (G - 1) / 2;
-  static constexpr int MSTRIDE = 2 * NPAIR + 2;
+  static constexpr int STRIDE = CAP * kRecF + 2; // small pad: spreads the groups over the LDS banks
+  // {G(cos), G'(cos)} per unordered neighbour pair, circulant layout: the pair (m, m+d mod n) lives at
+  // [d-1][m], i.e. every entry is private to the lane that computes it (no index arithmetic, no conflicts)
+  static constexpr int MSTRIDE = 2 * (G / 2) * G + 2;
   static constexpr int UA = G >= 32 ? 1 : (G >= 16 ? 2 : 4); // candidate chunks in flight in phase A
 };
 
 // slot of the unordered pair (a < b) in the triangular matrix of a G-slot group
-template <int G> __device__ __forceinline__ int tri_index(int a, int b)
-{
-  return a * (2 * G - a - 1) / 2 + (b - a - 1);
-}
 
 // ---- fast centre kernel: G lanes per centre, at most G neighbours (slot m = lane) --------------------
 // A centre whose coordination has outgrown its lane group since the last list build is handed to
@@ -287,8 +329,8 @@ template <int G>
 __global__ __launch_bounds__(256) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
-    unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ fown,
-    double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag)
+    const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
+    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag)
 {
   using C = CentreCfg<G>;
   __shared__ double s_rec[C::WPB * C::GPW * C::STRIDE];
@@ -307,6 +349,13 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   double *mat = s_mat + (size_t) grp_in_block * C::MSTRIDE;
   int *je = s_je + grp_in_block * C::CAP;
 
+  // The first UA*G candidates of every centre of this class were packed contiguously in class order when the
+  // lists were built (pack_cand_kernel), so they are requested together with the centre's id: the head of the
+  // kernel is two dependent loads deep (id | candidates -> coordinates) instead of four.
+  constexpr int W = C::UA * G;
+  int jp[C::UA];
+#pragma unroll
+  for (int u = 0; u < C::UA; u++) jp[u] = have ? pk[(size_t) gid * W + u * G + s] : -1;
   int c = 0, off = 0, nc = 0, tc = 0;
   double4 xc = make_double4(0, 0, 0, 0);
   if (have) {
@@ -322,8 +371,16 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   int n = 0;
   double nsum = 0.0;
   unsigned long long active = 0ull; // bit t: candidate t is inside rcmax right now (group-uniform)
+  {
+    double4 xj[C::UA];
+#pragma unroll
+    for (int u = 0; u < C::UA; u++) xj[u] = xq[jp[u] >= 0 ? jp[u] : c];
+#pragma unroll
+    for (int u = 0; u < C::UA; u++)
+      centre_take<G, C::CAP, kRecF>(P, tc, xc, jp[u] >= 0, u * G + s, xj[u], s, glane0, u * G, rec, je, n, active, nsum);
+  }
   const int ncw = wave_max_int(nc);
-  for (int base = 0; base < ncw; base += C::UA * G) {
+  for (int base = W; base < ncw; base += W) { // rows longer than the packed part (rare)
     int jj[C::UA];
     double4 xj[C::UA];
 #pragma unroll
@@ -336,7 +393,7 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
 #pragma unroll
     for (int u = 0; u < C::UA; u++) {
       const int t = base + u * G + s;
-      centre_take<G, C::CAP>(P, tc, xc, t < nc, t, xj[u], s, glane0, base + u * G, rec, je, n, active, nsum);
+      centre_take<G, C::CAP, kRecF>(P, tc, xc, t < nc, t, xj[u], s, glane0, base + u * G, rec, je, n, active, nsum);
     }
   }
   if (have && s == 0) amask[c] = active;
@@ -368,66 +425,96 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   const bool act = m < n;
   double mx = 0, my = 0, mz = 0, mr = 1, mw = 0, mdw = 0, mri = 1;
   if (act) {
-    const double *q = rec + m * kRec;
+    const double *q = rec + m * kRecF;
     mx = q[0];
     my = q[1];
     mz = q[2];
     mr = q[3];
     mw = q[4];
     mdw = q[5];
-    mri = q[8];
+    mri = q[kInvF];
   }
   const double ux = mx * mri, uy = my * mri, uz = mz * mri;
   // -- every unordered pair (m,q) ONCE: circulant enumeration q = (m+d) mod n, d = 1..n/2 (for even n
-  //    the distance-n/2 pairs are taken by the lower half of the lanes); G and G' go to the LDS matrix
+  //    the distance-n/2 pairs are taken by the lower half of the lanes).  The lane of m evaluates G, G' and
+  //    keeps them in its private LDS column; what the pair contributes to the partner q is handed over with
+  //    a lane shuffle (lane q reads from lane q-d).  S_m = sum_q w_q G(m,q) (pair_rebomos.cpp:607-630) is
+  //    complete when the loop ends -- no second pass over the pairs.
+  const int lane_base = (threadIdx.x & 63) - s;
+  double S = 0.0;
   for (int d = 1; d <= nw / 2; d++) {
     const bool mine = act && (2 * d < n || (2 * d == n && m < d));
+    double give = 0.0; // w_m G(m,q): the partner's share
     if (mine) {
       int qi = m + d;
       qi = qi >= n ? qi - n : qi;
-      const double *q = rec + qi * kRec;
-      double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * q[8];
+      const double *q = rec + qi * kRecF;
+      double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * q[kInvF];
       cs = fmin(cs, 1.0);
       cs = fmax(cs, -1.0);
       double dg;
       const double g = gspline(cb, cg, cs, dg);
-      double *e = mat + 2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m);
+      double *e = mat + 2 * ((d - 1) * G + m);
       e[0] = g;
       e[1] = dg;
+      S += q[4] * g;
+      give = mw * g;
     }
+    int src = m - d;
+    src = src < 0 ? src + n : src;
+    const double got = __shfl(give, lane_base + (act ? src : m), 64);
+    S += act ? got : 0.0;
   }
-  wave_lds_fence();
   // -- phase B: p_cm, C_m (pair_rebomos.cpp:607-630)
-  double S = 0.0;
-  for (int qi = 0; qi < nw; qi++)
-    if (act && qi < n && qi != m) S += rec[qi * kRec + 4] * mat[2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m)];
   double mC = 0.0, mp = 0.0, mVA = 0.0;
   if (act) {
     const int pt = tc * 2 + (((unsigned) je[m]) >> 30);
-    mp = 1.0 / sqrt(1.0 + S + PS);
+    mp = rsqrt_nr(1.0 + S + PS);
     mVA = -mw * P.B[pt] * exp(-P.beta[pt] * mr);
     mC = (mw > kTol) ? 0.5 * mVA * (-0.5 * mp * mp * mp) : 0.0;
-    rec[m * kRec + 6] = mC;
+    rec[m * kRecF + 6] = mC;
   }
   const double Csum = group_sum<G>(mC);
   wave_lds_fence();
-  // -- phase C: forces on the slots (pair_rebomos.cpp:634-725)
+  // -- phase C: forces on the slots (pair_rebomos.cpp:634-725), again once per unordered pair: the lane of
+  //    m adds its own part and ships the partner's part (force on q and C_m G for q's radial term)
   double fx = 0, fy = 0, fz = 0, acc1 = 0;
-  for (int qi = 0; qi < nw; qi++) {
-    if (act && qi < n && qi != m) {
-      const double *q = rec + qi * kRec;
-      const double qrinv = q[8];
-      double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * qrinv;
+  for (int d = 1; d <= nw / 2; d++) {
+    const bool mine = act && (2 * d < n || (2 * d == n && m < d));
+    double sx = 0, sy = 0, sz = 0, sa = 0;
+    if (mine) {
+      int qi = m + d;
+      qi = qi >= n ? qi - n : qi;
+      const double *q = rec + qi * kRecF;
+      const double qrinv = q[kInvF];
+      const double qx = q[0] * qrinv, qy = q[1] * qrinv, qz = q[2] * qrinv;
+      double cs = ux * qx + uy * qy + uz * qz;
       cs = fmin(cs, 1.0);
       cs = fmax(cs, -1.0);
-      const double *e = mat + 2 * tri_index<G>(m < qi ? m : qi, m < qi ? qi : m);
+      const double *e = mat + 2 * ((d - 1) * G + m);
       const double g = e[0], dg = e[1];
-      // (C_m w_q + C_q w_m) G'(cos) d cos / d x_m ; d cos/d x_m = -(u_q - cos u_m)/r_m ; force = -gradient
-      const double coef = (mC * q[4] + q[6] * mw) * dg * mri;
-      fx += coef * (q[0] * qrinv - cs * ux);
-      fy += coef * (q[1] * qrinv - cs * uy);
-      fz += coef * (q[2] * qrinv - cs * uz);
+      // (C_m w_q + C_q w_m) G'(cos) d cos / d x ; d cos/d x_m = -(u_q - cos u_m)/r_m ; force = -gradient
+      const double common = (mC * q[4] + q[6] * mw) * dg;
+      const double cm = common * mri, cq = common * qrinv;
+      fx += cm * (qx - cs * ux);
+      fy += cm * (qy - cs * uy);
+      fz += cm * (qz - cs * uz);
       acc1 += q[6] * g;
+      sx = cq * (ux - cs * qx);
+      sy = cq * (uy - cs * qy);
+      sz = cq * (uz - cs * qz);
+      sa = mC * g;
+    }
+    int src = m - d;
+    src = src < 0 ? src + n : src;
+    const int from = lane_base + (act ? src : m);
+    const double rx = __shfl(sx, from, 64), ry = __shfl(sy, from, 64), rz = __shfl(sz, from, 64);
+    const double ra = __shfl(sa, from, 64);
+    if (act) {
+      fx += rx;
+      fy += ry;
+      fz += rz;
+      acc1 += ra;
     }
   }
   double eh = 0.0;
@@ -490,7 +577,7 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
       const int t = base + s;
       const int j = t < nc ? cand[off + t] : c;
       const double4 xj = xq[j];
-      centre_take<G, CAP>(P, tc, xc, t < nc, t, xj, s, glane0, base, rec, je, n, active, nsum);
+      centre_take<G, CAP, kRec>(P, tc, xc, t < nc, t, xj, s, glane0, base, rec, je, n, active, nsum);
     }
     if (n > CAP) {
       if (s == 0) atomicOr(&flags[0], 1);
@@ -672,16 +759,6 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
 // The per-atom gather x[j] is what bounds this loop (one 32-byte gather feeds ~25 flops and the L1
 // tag rate saturates), so MDP_CLUSTER consecutive (Morton-ordered, hence adjacent) atoms share ONE
 // union neighbour list: every gathered x[j] is tested against all four cluster atoms from registers.
-// 1/x to ~1 ulp: hardware seed + two Newton steps (5 instructions instead of the ~12 of an IEEE divide;
-// the result feeds products whose tolerance is 1e-9 relative)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
 
 // loop-invariant Lennard-Jones parameters of one (cluster atom, neighbour element) pair type
 struct LJPar {
@@ -2000,6 +2077,19 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
   }
 }
 
+// the first W candidates of every centre of one class, contiguous in class order (-1 beyond the row)
+__global__ __launch_bounds__(256) void pack_cand_kernel(const int n, const int W, const int *__restrict__ list,
+                                                        const int *__restrict__ cand_off,
+                                                        const int *__restrict__ cand, int *__restrict__ pk)
+{
+  const long long idx = (long long) blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long) n * W) return;
+  const int gid = (int) (idx / W), t = (int) (idx % W);
+  const int c = list[gid];
+  const int off = cand_off[c], nc = cand_off[c + 1] - off;
+  pk[idx] = t < nc ? cand[off + t] : -1;
+}
+
 __global__ void zero_small_kernel(double *acc, int n)
 {
   if (threadIdx.x < n) acc[threadIdx.x] = 0.0;
@@ -2297,6 +2387,24 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, hipStreamSynchronize(st));
   if (hflags[1])
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
+  { // packed candidate heads of the four lane-group classes (widths = UA*G of rebo_centre_kernel<G>)
+    const int width[4] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<16>::UA * 16, CentreCfg<32>::UA * 32};
+    size_t total = 0;
+    for (int k = 0; k < 4; k++) {
+      c->pk_base[k] = total;
+      total += (size_t) c->h_class_count[k] * width[k];
+    }
+    MDP_HIP(c, c->pk_cand.reserve(total + 1));
+    for (int k = 0; k < 4; k++) {
+      const long long n = (long long) c->h_class_count[k] * width[k];
+      if (n > 0)
+        pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], width[k],
+                                                                       c->class_list.p + (size_t) k * nall,
+                                                                       c->cand_off.p, c->cand.p,
+                                                                       c->pk_cand.p + c->pk_base[k]);
+    }
+    MDP_HIP(c, hipGetLastError());
+  }
   c->rebo_packed = true;
   c->stale_pending = false;
   c->style_builds++;
@@ -2365,7 +2473,8 @@ static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
   const int per_block = 256 / G;
   const int grid = (n + per_block - 1) / per_block;
   rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
-                                                     c->xq.p, c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
+                                                     c->xq.p, c->cand_off.p, c->cand.p, c->pk_cand.p + c->pk_base[k],
+                                                     c->amask.p, c->fnbr.p,
                                                      c->fown.p, c->acc.p, c->ovf.p, eflag, vflag);
 }
 
