@@ -2338,8 +2338,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   c->split_halo = false;
   c->lj_ordered = false;
   for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
-  // 5 workgroups per CU need <= 32 KB each: unions up to kSmallUnion members (+ the dummy slot), 24 bytes apiece
-  constexpr int kSmallUnion = 1359;
+  // the tile kernel is latency-bound (measured: t = 0.65 ms + 3.96 ms / resident workgroups per CU), so the
+  // common case is sized for FIVE workgroups per CU; the rare larger unions get their own launch
+  constexpr int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
   c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
   const bool remote = c->md && c->remote_start < nall;
   if (nunit > 0 && (remote || (tiled && c->tile_maxu > kSmallUnion))) {
@@ -2512,8 +2513,8 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
     // the force-only variants fit 5 waves per SIMD (<= 102 VGPRs); with small unions LDS allows 5 workgroups too
     if (ev && gather) MDP_LJT(true, true, 4);
     else if (ev) MDP_LJT(true, false, 4);
-    else if (gather) MDP_LJT(false, true, 4);
-    else MDP_LJT(false, false, 4);
+    else if (gather) MDP_LJT(false, true, 5);
+    else MDP_LJT(false, false, 5);
 #undef MDP_LJT
     return MDP_OK;
   }

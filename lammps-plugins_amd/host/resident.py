@@ -81,7 +81,7 @@ def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float, group=None, chunk:
     the longest list among them.  chunk = 3 tiles keeps every tile inside one compact stretch of the curve."""
     import os
     order = morton_order(x, lo, cell) if os.environ.get("MDP_ORDER", "hilbert") == "morton" else hilbert_order(x, lo, cell)
-    if group is not None and chunk > 0 and len(order) and os.environ.get("MDP_ORDER_GROUP", "1") != "0":
+    if group is not None and chunk > 0 and len(order) and os.environ.get("MDP_ORDER_GROUP", "0") != "0":
         g = np.asarray(group)[order].astype(np.int64)
         key = (np.arange(len(order), dtype=np.int64) // chunk) * (int(g.max()) + 1) + g
         order = order[np.argsort(key, kind="stable")]
