@@ -212,6 +212,11 @@ void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
  * [5]=#centres in 4-lane groups, [6]=#centres in 16-lane groups, [7]=style-list builds so far (rebomos) /
  * #angular atoms (aeam) */
 int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
+/* shape of the rebomos style's own Lennard-Jones lists after the last build (host and resident mode):
+ * out[0]=1 tile lists / 0 per-cluster lists (fallback), [1]=#tiles, [2]=union stride, [3]=largest union,
+ * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,
+ * [7]=style-list builds so far.  (No reference counterpart: the CPU style reads the host's list.) */
+int mdp_rebomos_list_info(mdp_ctx *ctx, long long out[8]);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):
  * rebomos: [0]=REBO centre kernels, [1]=LJ+gather kernel; aeam: [0]=density, [1]=embed, [2]=force.

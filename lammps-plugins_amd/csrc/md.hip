@@ -627,6 +627,21 @@ void *mdp_md_ptr(mdp_ctx *c, const char *name)
   return nullptr;
 }
 
+int mdp_rebomos_list_info(mdp_ctx *c, long long out[8])
+{
+  if (!c || !out) return MDP_EINVAL;
+  if (!c->rebo_packed) return mdp_fail(c, MDP_ESTATE, "rebomos lists not built yet");
+  out[0] = c->lj_tiled ? 1 : 0;
+  out[1] = c->ntile;
+  out[2] = c->tile_cap;
+  out[3] = c->tile_maxu;
+  out[4] = c->lj_total;
+  out[5] = c->nclus;
+  out[6] = (c->lj_class_base[2] - c->lj_class_base[1]) + (c->lj_class_base[4] - c->lj_class_base[3]);
+  out[7] = c->style_builds;
+  return MDP_OK;
+}
+
 int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
 {
   if (!c || !out) return MDP_EINVAL;

@@ -49,7 +49,7 @@ EXPORTS = [
     "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
-    "mdp_md_neighbor_stats", "mdp_set_timing", "mdp_get_timing",
+    "mdp_md_neighbor_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
 ]
 
 
@@ -309,6 +309,13 @@ class Context:
         if not p:
             raise MdpError(-1, f"mdp_md_ptr({name}) returned NULL")
         return int(p)
+
+    def rebomos_list_info(self):
+        """shape of the style's Lennard-Jones lists after the last build (see mdpair_hip.h)"""
+        out = (C.c_longlong * 8)()
+        self._ck(self.L.mdp_rebomos_list_info(self.h, out))
+        keys = ("tiled", "tiles", "union_stride", "union_max", "row_entries", "clusters", "large_tiles", "builds")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def md_neighbor_stats(self):
         out = (C.c_longlong * 8)()

@@ -195,3 +195,20 @@ def test_per_atom_virial_matches_oracle(ctx, oracle, P, fac, amp, seed):
     assert np.abs(g["vatom"] - va).max() < 1e-9 * scale
     assert np.allclose(g["vatom"].sum(axis=0), g["virial"], rtol=1e-9, atol=1e-8)
     _compare(g, o)
+
+
+def test_unsorted_host_atoms_fall_back_to_cluster_lists(oracle, P):
+    """A host hands atoms over in ITS order.  With no spatial order at all, 32 consecutive atoms are spread
+    over the whole box and the union of their neighbourhoods outgrows what LDS can stage: the style must
+    notice at list-build time, take the per-cluster-list kernel instead, and still match the oracle."""
+    s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (4, 4, 3)), 0.05, seed=21)
+    perm = np.random.default_rng(5).permutation(s.n)
+    s = S.System(s.box, s.x[perm], s.type[perm], s.tag[perm], s.mass)
+    eng = mdref.RebomosCPU(oracle, P, s)
+    c = capi.Context(0)
+    c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
+    g = _gpu_compute(c, eng, s.x)
+    info = c.rebomos_list_info()
+    c.close()
+    assert info["tiled"] == 0
+    _compare(g, eng.compute(s.x))

@@ -98,3 +98,43 @@ def test_rebuild_after_motion_keeps_energy_conserved():
     assert d.builds > builds0                      # the rebuild path really ran
     assert abs((t1["pe"] + t1["ke"]) - e0) / s.n < 2e-5
     ctx.close()
+
+
+def _forces(s, env):
+    """forces, energy and list shape of one resident compute under the given environment"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx, d = _domain(s, True)
+        d.build_neighbors()
+        d.compute(eflag=3, vflag=1)
+        th = d.thermo()
+        got = ctx.md_download(d.nlocal, want=("f", "eatom"))
+        order = np.argsort(np.asarray(d.order_tag))   # back to tag order: the storage order depends on env
+        info = ctx.rebomos_list_info()
+        ctx.close()
+        return got["f"][order], got["eatom"][order], th, info
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_tile_lists_against_the_per_cluster_path_and_large_union_classes():
+    """Two independent Lennard-Jones paths on 62 k jittered atoms: tile lists (LDS-staged unions, 16-bit
+    rows) and the per-cluster fallback (MDP_LJ_TILE=0).  A Z-order atom sequence has jumps, so some tile
+    unions exceed the small launch class: the large-union classes are exercised as well."""
+    s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (6, 6, 6)), 0.05, seed=3)
+    f0, e0, th0, i0 = _forces(s, {"MDP_LJ_TILE": "0"})
+    f1, e1, th1, i1 = _forces(s, {"MDP_LJ_TILE": "1"})
+    f2, e2, th2, i2 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_ORDER": "morton"})
+    assert i0["tiled"] == 0 and i1["tiled"] == 1 and i2["tiled"] == 1
+    assert i1["union_max"] < i1["union_stride"]
+    assert i2["large_tiles"] > 0                       # Morton jumps -> unions beyond the small class
+    for f, e, th in ((f1, e1, th1), (f2, e2, th2)):
+        assert np.abs(f - f0).max() < 1e-10
+        assert np.abs(e - e0).max() < 1e-10
+        assert th["pe"] == pytest.approx(th0["pe"], rel=1e-12)
+        assert np.allclose(th["virial"], th0["virial"], rtol=1e-10, atol=1e-7)
