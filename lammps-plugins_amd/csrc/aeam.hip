@@ -752,16 +752,13 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
   MDP_TRY(mdp_acc_end(c, true));
   hipStream_t st = c->stream;
   const int n = c->nlocal;
-  std::vector<double> he;
+  MDP_TRY(mdp_host_pinned_reserve(c, (size_t) n + 16));
+  double *he = c->h_down;
   MDP_HIP(c, hipMemcpyAsync(fp, c->fp.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (rho) MDP_HIP(c, hipMemcpyAsync(rho, c->rho.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  if (eflag & MDP_EFLAG_ATOM) {
-    he.resize(n);
-    MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  }
+  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, nullptr));
-  if (eflag & MDP_EFLAG_ATOM)
-    for (int i = 0; i < n; i++) eatom[i] += he[i];
+  if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) n);
   return MDP_OK;
 }
 
@@ -782,23 +779,17 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   MDP_TRY(mdp_acc_begin(c, true));
   MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * n, st));
   MDP_TRY(mdp_aeam_run_force(c, eflag, vflag));
-  std::vector<double> hf((size_t) 3 * nall), he;
-  MDP_HIP(c, hipMemcpyAsync(hf.data(), c->f.p, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
-  if (eflag & MDP_EFLAG_ATOM) {
-    he.resize(n);
-    MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  }
-  std::vector<double> hv;
-  if (vflag & MDP_VFLAG_ATOM) {
-    hv.resize((size_t) 6 * nall);
-    MDP_HIP(c, hipMemcpyAsync(hv.data(), c->vatom.p, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
-  }
-  MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  // results come back through the pinned buffer and are ADDED on the host (LAMMPS semantics; ghosts included)
+  MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nall + 16));
+  double *hf = c->h_down, *he = hf + (size_t) 3 * nall, *hv = he + nall;
+  MDP_HIP(c, hipMemcpyAsync(hf, c->f.p, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (vflag & MDP_VFLAG_ATOM)
-    for (size_t k = 0; k < (size_t) 6 * nall; k++) vatom[k] += hv[k];
-  for (size_t k = 0; k < (size_t) 3 * nall; k++) f[k] += hf[k];
-  if (eflag & MDP_EFLAG_ATOM)
-    for (int i = 0; i < n; i++) eatom[i] += he[i];
+    MDP_HIP(c, hipMemcpyAsync(hv, c->vatom.p, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
+  MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nall);
+  mdp_host_add(f, hf, (size_t) 3 * nall);
+  if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) n);
   return MDP_OK;
 }
 

@@ -427,6 +427,7 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
     ta[nlocal + g] = ghost_type[g];
     if (ghost_tag) ga[nlocal + g] = ghost_tag[g];
   }
+  c->md = true; // before the upload: resident atoms keep the caller's order and their staging arrays are temporaries
   MDP_TRY(mdp_set_atoms_host(c, nlocal, nghost, xa.data(), ta.data(), ga.data(), cfg->ntypes, map));
   for (int d = 0; d < 3; d++) { // resident mode bins over the caller's box
     c->bbox_lo[d] = cfg->bbox_lo[d];

@@ -4,6 +4,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <thread>
+
 #include <cmath>
 
 void mdp_rebomos_fill_dev(mdp_ctx *c, double skin);
@@ -48,6 +50,85 @@ __global__ void pack_xq_kernel(int n, const double *__restrict__ x3, const int *
   xq[i] = make_double4(x3[3 * (size_t) i], x3[3 * (size_t) i + 1], x3[3 * (size_t) i + 2], w);
 }
 
+// ---- host mode: the device keeps its own spatial order ------------------------------------------------
+// A host hands atoms over in its order; the tile lists (and every gather) want neighbours in space to be
+// neighbours in memory.  Owned atoms, and separately the ghosts, are therefore sorted along a Hilbert curve
+// on the device at every mdp_set_atoms_host; positions are permuted on upload and forces / per-atom
+// results permuted back before download -- invisible to the host.
+__global__ void hilbert_key_kernel(const int nall, const int nlocal, const double *__restrict__ x3, const double lo0,
+                                   const double lo1, const double lo2, const double sc0, const double sc1,
+                                   const double sc2, unsigned *__restrict__ keys, int *__restrict__ idx)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nall) return;
+  constexpr int B = 10; // bits per dimension: 1024 cells over the bounding box
+  const double lo[3] = {lo0, lo1, lo2}, sc[3] = {sc0, sc1, sc2};
+  unsigned X[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int g = (int) ((x3[3 * (size_t) i + d] - lo[d]) * sc[d]);
+    g = g < 0 ? 0 : (g > (1 << B) - 1 ? (1 << B) - 1 : g);
+    X[d] = (unsigned) g;
+  }
+  // Skilling, "Programming the Hilbert curve": axes -> transposed index
+  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1) {
+    const unsigned P = Q - 1;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (X[d] & Q)
+        X[0] ^= P;
+      else {
+        const unsigned t = (X[0] ^ X[d]) & P;
+        X[0] ^= t;
+        X[d] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0;
+  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t;
+  X[1] ^= t;
+  X[2] ^= t;
+  unsigned key = 0;
+  for (int b = B - 1; b >= 0; b--)
+#pragma unroll
+    for (int d = 0; d < 3; d++) key = (key << 1) | ((X[d] >> b) & 1u);
+  if (i >= nlocal) key |= 1u << 30; // ghosts stay behind the owned atoms
+  keys[i] = key;
+  idx[i] = i;
+}
+
+// xq[n] <- atom perm[n] of the host arrays (type null: keep the element already in xq[n].w)
+__global__ void pack_xq_perm_kernel(int n, const double *__restrict__ x3, const int *__restrict__ type,
+                                    const int *__restrict__ map, const int *__restrict__ perm,
+                                    double4 *__restrict__ xq)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int o = perm[i];
+  double w;
+  if (type) {
+    const int t = type[o];
+    w = (double) (map ? map[t] : t - 1);
+  } else {
+    w = xq[i].w;
+  }
+  xq[i] = make_double4(x3[3 * (size_t) o], x3[3 * (size_t) o + 1], x3[3 * (size_t) o + 2], w);
+}
+
+// dst (host order) <- src (device order), `w` doubles per atom
+__global__ void unpermute_kernel(int n, int w, const int *__restrict__ perm, const double *__restrict__ src,
+                                 double *__restrict__ dst)
+{
+  const long long k = (long long) blockIdx.x * 256 + threadIdx.x;
+  if (k >= (long long) n * w) return;
+  const int i = (int) (k / w), q = (int) (k % w);
+  dst[(size_t) perm[i] * w + q] = src[k];
+}
+
 __global__ void add_f_kernel(int n3, const double *__restrict__ src, double *__restrict__ dst)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -84,6 +165,65 @@ int mdp_acc_end(mdp_ctx *c, bool any)
   return MDP_OK;
 }
 
+// ---- host-mode transfers --------------------------------------------------------------------------------
+// Large host arrays (x, handed over every step) are page-locked in place the first time they are seen, so
+// that the upload is one DMA instead of a bounce through the runtime's staging buffers; results come back
+// into a pinned buffer of the context and are added into the host's array by a few threads.
+static void host_register(mdp_ctx *c, const void *ptr, size_t bytes)
+{
+  // small systems: not worth a system call; resident mode: the caller's arrays are one-shot temporaries
+  if (c->md || bytes < (8u << 20) || getenv("MDP_NO_HOST_REGISTER")) return;
+  for (auto &r : c->host_regs)
+    if (r.first == ptr) {
+      if (r.second >= bytes) return;
+      (void) hipHostUnregister(const_cast<void *>(ptr));
+      r.second = 0;
+    }
+  if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
+    bool reused = false;
+    for (auto &r : c->host_regs)
+      if (r.first == ptr) {
+        r.second = bytes;
+        reused = true;
+      }
+    if (!reused) c->host_regs.emplace_back(ptr, bytes);
+  } else {
+    (void) hipGetLastError(); // e.g. overlaps a range registered earlier: the plain copy still works
+  }
+}
+
+int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles)
+{
+  if (ndoubles <= c->h_down_cap) return MDP_OK;
+  if (c->h_down) (void) hipHostFree(c->h_down);
+  c->h_down = nullptr;
+  c->h_down_cap = 0;
+  MDP_HIP(c, hipHostMalloc((void **) &c->h_down, sizeof(double) * (ndoubles + ndoubles / 8 + 64), hipHostMallocDefault));
+  c->h_down_cap = ndoubles + ndoubles / 8 + 64;
+  return MDP_OK;
+}
+
+// dst[k] += src[k], split over a few threads for arrays that take milliseconds
+void mdp_host_add(double *dst, const double *src, size_t n)
+{
+  unsigned nt = n > (1u << 20) ? std::thread::hardware_concurrency() : 1;
+  nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+  if (nt == 1) {
+    for (size_t k = 0; k < n; k++) dst[k] += src[k];
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t++) {
+    const size_t b = t * chunk, e = b + chunk < n ? b + chunk : n;
+    if (b >= e) break;
+    th.emplace_back([=] {
+      for (size_t k = b; k < e; k++) dst[k] += src[k];
+    });
+  }
+  for (auto &t : th) t.join();
+}
+
 // xraw (device [n][3]) (+ device type[]) -> xq.  d_type null: keep the element already in xq.w
 int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type)
 {
@@ -95,8 +235,38 @@ int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type)
     // map lives at the tail of the type buffer
     d_map = c->type.p + c->nall;
   }
-  pack_xq_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, d_x3, d_type, d_map, c->xq.p);
+  if (c->host_sort)
+    pack_xq_perm_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, d_x3, d_type, d_map, c->host_perm.p, c->xq.p);
+  else
+    pack_xq_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, d_x3, d_type, d_map, c->xq.p);
   MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// host mode, rebomos: (re)derive the device's storage order from the positions just uploaded to xraw
+static int host_sort_atoms(mdp_ctx *c)
+{
+  const int nall = c->nall;
+  const char *e = getenv("MDP_HOST_SORT");
+  c->host_sort = !c->md && c->have_rebomos && !c->have_aeam && c->nlocal > 0 && !(e && atoi(e) == 0);
+  if (!c->host_sort) return MDP_OK;
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->sort_keys_a.reserve(nall + 1));
+  MDP_HIP(c, c->sort_keys_b.reserve(nall + 1));
+  MDP_HIP(c, c->cell_of.reserve(nall + 1));
+  MDP_HIP(c, c->host_perm.reserve(nall + 1));
+  double sc[3];
+  for (int d = 0; d < 3; d++) sc[d] = 1024.0 / (c->bbox_hi[d] - c->bbox_lo[d]);
+  hilbert_key_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->nlocal, c->xraw.p, c->bbox_lo[0], c->bbox_lo[1],
+                                                         c->bbox_lo[2], sc[0], sc[1], sc[2], c->sort_keys_a.p,
+                                                         c->cell_of.p);
+  MDP_HIP(c, hipGetLastError());
+  size_t tmp = 0;
+  MDP_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p, c->host_perm.p,
+                                       (size_t) nall, 0, 31, st));
+  MDP_HIP(c, c->scan_tmp.reserve(tmp + 16));
+  MDP_HIP(c, rocprim::radix_sort_pairs(c->scan_tmp.p, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p,
+                                       c->host_perm.p, (size_t) nall, 0, 31, st));
   return MDP_OK;
 }
 
@@ -207,6 +377,13 @@ int mdp_destroy(mdp_ctx *c)
   c->ovf.release();
   c->rev.release();
   c->rev16.release();
+  c->host_perm.release();
+  c->host_stage.release();
+  for (auto &r : c->host_regs)
+    if (r.second) (void) hipHostUnregister(const_cast<void *>(r.first));
+  c->host_regs.clear();
+  if (c->h_down) (void) hipHostFree(c->h_down);
+  c->h_down = nullptr;
   c->fnbr.release();
   c->fown.release();
   c->vslot.release();
@@ -316,6 +493,7 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
   MDP_HIP(c, c->f.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, c->eatom.reserve(nall + 1));
   hipStream_t st = c->stream;
+  host_register(c, x, sizeof(double) * 3 * nall);
   MDP_HIP(c, hipMemcpyAsync(c->xraw.p, x, sizeof(double) * 3 * nall, hipMemcpyHostToDevice, st));
   MDP_HIP(c, hipMemcpyAsync(c->type.p, type, sizeof(int) * nall, hipMemcpyHostToDevice, st));
   MDP_HIP(c, hipMemcpyAsync(c->type.p + nall, c->map, sizeof(int) * 16, hipMemcpyHostToDevice, st));
@@ -334,6 +512,7 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
       c->bbox_hi[d] = (nall ? hi[d] : 1.0) + 4.0;
     }
   }
+  MDP_TRY(host_sort_atoms(c));
   MDP_TRY(mdp_pack_xq(c, c->xraw.p, c->type.p));
   MDP_HIP(c, hipStreamSynchronize(st)); // host buffers may change after return
   c->neigh_set = false;
@@ -346,6 +525,7 @@ int mdp_set_positions_host(mdp_ctx *c, const double *x)
   if (!c || !x) return MDP_EINVAL;
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
   MDP_HIP(c, hipSetDevice(c->device));
+  host_register(c, x, sizeof(double) * 3 * c->nall);
   MDP_HIP(c, hipMemcpyAsync(c->xraw.p, x, sizeof(double) * 3 * c->nall, hipMemcpyHostToDevice, c->stream));
   MDP_TRY(mdp_pack_xq(c, c->xraw.p, nullptr));
   MDP_HIP(c, hipStreamSynchronize(c->stream));
@@ -463,23 +643,33 @@ int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
   // results come back through the staging buffer and are ADDED on the host (LAMMPS semantics)
-  std::vector<double> hf((size_t) 3 * nlocal), he;
-  MDP_HIP(c, hipMemcpyAsync(hf.data(), c->f.p, sizeof(double) * 3 * nlocal, hipMemcpyDeviceToHost, st));
-  if (eflag & MDP_EFLAG_ATOM) {
-    he.resize(nlocal);
-    MDP_HIP(c, hipMemcpyAsync(he.data(), c->eatom.p, sizeof(double) * nlocal, hipMemcpyDeviceToHost, st));
+  const double *df = c->f.p, *de = c->eatom.p, *dv = c->vatom.p;
+  if (c->host_sort && nlocal > 0) { // back to the host's atom order (owned atoms permute among themselves)
+    MDP_HIP(c, c->host_stage.reserve((size_t) 10 * nlocal + 10));
+    double *sf = c->host_stage.p, *se = sf + (size_t) 3 * nlocal, *sv = se + nlocal;
+    const auto blocks = [](long long n) { return (unsigned) ((n + 255) / 256); };
+    unpermute_kernel<<<blocks(3ll * nlocal), 256, 0, st>>>(nlocal, 3, c->host_perm.p, c->f.p, sf);
+    df = sf;
+    if (eflag & MDP_EFLAG_ATOM) {
+      unpermute_kernel<<<blocks(nlocal), 256, 0, st>>>(nlocal, 1, c->host_perm.p, c->eatom.p, se);
+      de = se;
+    }
+    if (vflag & MDP_VFLAG_ATOM) {
+      unpermute_kernel<<<blocks(6ll * nlocal), 256, 0, st>>>(nlocal, 6, c->host_perm.p, c->vatom.p, sv);
+      dv = sv;
+    }
+    MDP_HIP(c, hipGetLastError());
   }
-  std::vector<double> hv;
-  if (vflag & MDP_VFLAG_ATOM) {
-    hv.resize((size_t) 6 * nlocal);
-    MDP_HIP(c, hipMemcpyAsync(hv.data(), c->vatom.p, sizeof(double) * 6 * nlocal, hipMemcpyDeviceToHost, st));
-  }
-  MDP_TRY(fetch_acc(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nlocal + 16));
+  double *hf = c->h_down, *he = hf + (size_t) 3 * nlocal, *hv = he + nlocal;
+  MDP_HIP(c, hipMemcpyAsync(hf, df, sizeof(double) * 3 * nlocal, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, de, sizeof(double) * nlocal, hipMemcpyDeviceToHost, st));
   if (vflag & MDP_VFLAG_ATOM)
-    for (size_t k = 0; k < (size_t) 6 * nlocal; k++) vatom[k] += hv[k];
-  for (size_t k = 0; k < (size_t) 3 * nlocal; k++) f[k] += hf[k];
-  if (eflag & MDP_EFLAG_ATOM)
-    for (int i = 0; i < nlocal; i++) eatom[i] += he[i];
+    MDP_HIP(c, hipMemcpyAsync(hv, dv, sizeof(double) * 6 * nlocal, hipMemcpyDeviceToHost, st));
+  MDP_TRY(fetch_acc(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
+  if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nlocal);
+  mdp_host_add(f, hf, (size_t) 3 * nlocal);
+  if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) nlocal);
   return MDP_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mdpair_hip.h"
@@ -104,6 +105,12 @@ struct mdp_ctx {
   int map[16];
   DevBuf<double4> xq;   // x,y,z, w = element / type-1 as double
   DevBuf<double> xraw;  // staging for host x [nall][3]
+  bool host_sort = false;       // host mode, rebomos: device storage order = Hilbert order (host_perm: device -> host index)
+  DevBuf<int> host_perm;
+  DevBuf<double> host_stage;    // per-atom results back in host order before the download
+  std::vector<std::pair<const void *, size_t>> host_regs; // host arrays page-locked in place (large x arrays)
+  double *h_down = nullptr;     // pinned download buffer
+  size_t h_down_cap = 0;
   DevBuf<int> tag, type;
   DevBuf<double> f;     // [nall][3]
   DevBuf<double> eatom; // [nall]
@@ -235,5 +242,7 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
 int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
+int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
+void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]

@@ -197,18 +197,37 @@ def test_per_atom_virial_matches_oracle(ctx, oracle, P, fac, amp, seed):
     _compare(g, o)
 
 
-def test_unsorted_host_atoms_fall_back_to_cluster_lists(oracle, P):
-    """A host hands atoms over in ITS order.  With no spatial order at all, 32 consecutive atoms are spread
-    over the whole box and the union of their neighbourhoods outgrows what LDS can stage: the style must
-    notice at list-build time, take the per-cluster-list kernel instead, and still match the oracle."""
+@pytest.mark.parametrize("device_sort", [True, False])
+def test_unsorted_host_atoms(oracle, P, device_sort):
+    """A host hands atoms over in ITS order -- here a random permutation, the worst case.  By default the
+    library sorts its own copy along a Hilbert curve (and permutes results back), so the tile lists apply.
+    With MDP_HOST_SORT=0, 32 consecutive atoms are spread over the whole box and the union of their
+    neighbourhoods outgrows what LDS can stage: the style must notice at list-build time and take the
+    per-cluster-list kernel instead.  Either way the host sees the oracle's numbers in its own order."""
     s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (4, 4, 3)), 0.05, seed=21)
     perm = np.random.default_rng(5).permutation(s.n)
     s = S.System(s.box, s.x[perm], s.type[perm], s.tag[perm], s.mass)
     eng = mdref.RebomosCPU(oracle, P, s)
-    c = capi.Context(0)
-    c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
-    g = _gpu_compute(c, eng, s.x)
-    info = c.rebomos_list_info()
-    c.close()
-    assert info["tiled"] == 0
-    _compare(g, eng.compute(s.x))
+    old = os.environ.get("MDP_HOST_SORT")
+    os.environ["MDP_HOST_SORT"] = "1" if device_sort else "0"
+    try:
+        c = capi.Context(0)
+        c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
+        g = _gpu_compute(c, eng, s.x, vflag=5)
+        info = c.rebomos_list_info()
+        # a second step through the positions-only path, after moving the atoms a little
+        x2 = s.x + 0.01 * np.random.default_rng(6).standard_normal(s.x.shape)
+        g2 = _gpu_compute(c, eng, x2, first=False)
+        c.close()
+    finally:
+        if old is None:
+            os.environ.pop("MDP_HOST_SORT", None)
+        else:
+            os.environ["MDP_HOST_SORT"] = old
+    assert info["tiled"] == (1 if device_sort else 0)
+    o = eng.compute(s.x)
+    _compare(g, o)
+    va = o["vatom"][:eng.nlocal].copy()
+    np.add.at(va, eng.owner, o["vatom"][eng.nlocal:])
+    assert np.abs(g["vatom"] - va).max() < 1e-9 * max(1.0, np.abs(va).max())
+    _compare(g2, eng.compute(x2))
