@@ -651,9 +651,10 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
   out[1] = c->nb_total - c->nb_owned_total;
   out[2] = c->lj_total;
   out[3] = c->cand_total;
-  out[4] = (long long) c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
-  out[5] = c->h_class_count[0];
-  out[6] = c->h_class_count[2];
+  out[4] = 0;
+  for (int k = 0; k < 8; k++) out[4] += c->h_class_count[k];
+  out[5] = (long long) c->h_class_count[0] + c->h_class_count[1]; // 4-lane groups, both elements
+  out[6] = (long long) c->h_class_count[4] + c->h_class_count[5]; // 16-lane groups
   out[7] = c->cfg.style == 1 ? c->style_builds : c->h_ang_count;
   return MDP_OK;
 }

@@ -159,11 +159,11 @@ struct mdp_ctx {
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
-  DevBuf<int> class_list;         // [4][nall]
-  DevBuf<int> class_count;        // [4]
+  DevBuf<int> class_list;         // [8][nall]   class = 2 * (lane-group size index) + element
+  DevBuf<int> class_count;        // [8]
   DevBuf<int> pk_cand;            // per class, per centre: its first UA*G candidates, contiguous in class order
-  size_t pk_base[4] = {0, 0, 0, 0};
-  int h_class_count[4] = {0, 0, 0, 0};
+  size_t pk_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int h_class_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
-    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag)
+    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag,
+    const int tc /* element of every centre of this launch: a scalar, and with it all per-element constants */)
 {
   using C = CentreCfg<G>;
   __shared__ double s_rec[C::WPB * C::GPW * C::STRIDE];
@@ -356,14 +357,13 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   int jp[C::UA];
 #pragma unroll
   for (int u = 0; u < C::UA; u++) jp[u] = have ? pk[(size_t) gid * W + u * G + s] : -1;
-  int c = 0, off = 0, nc = 0, tc = 0;
+  int c = 0, off = 0, nc = 0;
   double4 xc = make_double4(0, 0, 0, 0);
   if (have) {
     c = centres[gid];
     off = cand_off[c];
     nc = cand_off[c + 1] - off;
     xc = xq[c];
-    tc = (int) xc.w;
   }
 
   // ---- phase A: filter the candidates to the current REBO set (pair_rebomos.cpp:328-344);
@@ -2065,9 +2065,10 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
     }
     // smallest lane group that holds the current coordination (one lane per neighbour, some to spare)
     k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 14) ? 2 : 3;
+    k = 2 * k + (ti != 0); // classes are per (lane-group size, element): the element is then uniform per launch
   }
 #pragma unroll
-  for (int kk = 0; kk < 4; kk++) {
+  for (int kk = 0; kk < 8; kk++) {
     const unsigned long long m = __ballot(k == kk);
     if (m == 0ull) continue;
     int base = 0;
@@ -2206,14 +2207,14 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
-  MDP_HIP(c, c->class_list.reserve((size_t) 4 * nall + 4));
-  MDP_HIP(c, c->class_count.reserve(4));
+  MDP_HIP(c, c->class_list.reserve((size_t) 8 * nall + 8));
+  MDP_HIP(c, c->class_count.reserve(8));
   MDP_HIP(c, c->xhold_all.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, sizeof(int) * (nall + 1), st));
   MDP_HIP(c, hipMemsetAsync(c->amask.p, 0, sizeof(unsigned long long) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, st));
-  MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * 4, st));
+  MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * 8, st));
   // one bin grid serves both lists (cell width >= (rcLJmax + s_in)/2)
   double ljcut = 0.0, candcut = 0.0;
   for (int k = 0; k < 4; k++) {
@@ -2383,23 +2384,23 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
-  MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   if (hflags[1])
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
-  { // packed candidate heads of the four lane-group classes (widths = UA*G of rebo_centre_kernel<G>)
+  { // packed candidate heads of the lane-group classes (widths = UA*G of rebo_centre_kernel<G>), per element
     const int width[4] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<16>::UA * 16, CentreCfg<32>::UA * 32};
     size_t total = 0;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 8; k++) {
       c->pk_base[k] = total;
-      total += (size_t) c->h_class_count[k] * width[k];
+      total += (size_t) c->h_class_count[k] * width[k / 2];
     }
     MDP_HIP(c, c->pk_cand.reserve(total + 1));
-    for (int k = 0; k < 4; k++) {
-      const long long n = (long long) c->h_class_count[k] * width[k];
+    for (int k = 0; k < 8; k++) {
+      const long long n = (long long) c->h_class_count[k] * width[k / 2];
       if (n > 0)
-        pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], width[k],
+        pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], width[k / 2],
                                                                        c->class_list.p + (size_t) k * nall,
                                                                        c->cand_off.p, c->cand.p,
                                                                        c->pk_cand.p + c->pk_base[k]);
@@ -2467,16 +2468,19 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
 }
 
 template <int G>
-static void launch_centre(mdp_ctx *c, int k, int eflag, int vflag)
+static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag)
 {
-  const int n = c->h_class_count[k];
-  if (n <= 0) return;
-  const int per_block = 256 / G;
-  const int grid = (n + per_block - 1) / per_block;
-  rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
-                                                     c->xq.p, c->cand_off.p, c->cand.p, c->pk_cand.p + c->pk_base[k],
-                                                     c->amask.p, c->fnbr.p,
-                                                     c->fown.p, c->acc.p, c->ovf.p, eflag, vflag);
+  for (int elem = 0; elem < 2; elem++) {
+    const int k = 2 * kg + elem;
+    const int n = c->h_class_count[k];
+    if (n <= 0) continue;
+    const int per_block = 256 / G;
+    const int grid = (n + per_block - 1) / per_block;
+    rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
+                                                       c->xq.p, c->cand_off.p, c->cand.p, c->pk_cand.p + c->pk_base[k],
+                                                       c->amask.p, c->fnbr.p, c->fown.p, c->acc.p, c->ovf.p, eflag, vflag,
+                                                       elem);
+  }
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
@@ -2549,7 +2553,8 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
   launch_centre<32>(c, 3, eflag, vflag);
   // centres that outgrew their lane group since the last build (normally none: the kernel reads the
   // count from the device and exits)
-  const int total = c->h_class_count[0] + c->h_class_count[1] + c->h_class_count[2] + c->h_class_count[3];
+  int total = 0;
+  for (int k = 0; k < 8; k++) total += c->h_class_count[k];
   const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
   if (grid)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
@@ -2564,7 +2569,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
 static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 8; k++) {
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
     const int grid = n / 8 + 1 < 2048 ? n / 8 + 1 : 2048;
