@@ -19,6 +19,8 @@
 #define MDP_CLUSTER 2
 #define MDP_ACC_SLOTS 512
 #define MDP_ACC_STRIDE 16
+// REBO centre classes: lane-group size (4, 8, 12, 16, 32) x element
+#define MDP_NCLASS 10
 
 // device buffer that only grows
 template <typename T> struct DevBuf {
@@ -159,11 +161,11 @@ struct mdp_ctx {
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
-  DevBuf<int> class_list;         // [8][nall]   class = 2 * (lane-group size index) + element
-  DevBuf<int> class_count;        // [8]
+  DevBuf<int> class_list;         // [MDP_NCLASS][nall]   class = 2 * (lane-group size index) + element
+  DevBuf<int> class_count;        // [MDP_NCLASS]
   DevBuf<int> pk_cand;            // per class, per centre: its first UA*G candidates, contiguous in class order
-  size_t pk_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int h_class_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t pk_base[MDP_NCLASS] = {};
+  int h_class_count[MDP_NCLASS] = {};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride

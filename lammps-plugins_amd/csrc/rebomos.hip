@@ -44,6 +44,10 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sum over the G consecutive lanes of a group, any G <= 16 (the xor butterfly needs a power of two):
+// bounded tree towards lane 0 of the group, then broadcast
+template <int G> __device__ __forceinline__ double group_sum_any(double v, const int s, const int lane);
+
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Work items that are neighbours
 // in space (consecutive along the Hilbert curve) share most of what they gather, so every XCD is given one
 // contiguous stretch of the items instead of every eighth one.
@@ -58,6 +62,21 @@ template <int W> __device__ __forceinline__ double group_sum(double v)
 #pragma unroll
   for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+template <int G> __device__ __forceinline__ double group_sum_any(double v, const int s, const int lane)
+{
+  if constexpr ((G & (G - 1)) == 0) {
+    return group_sum<G>(v);
+  } else {
+    static_assert(G <= 16, "tree below starts at offset 8");
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double t = __shfl_down(v, o, 64);
+      if (s < o && s + o < G) v += t;
+    }
+    return __shfl(v, lane - s, 64);
+  }
 }
 
 __device__ __forceinline__ int wave_max_int(int v)
@@ -311,13 +330,13 @@ __device__ __forceinline__ void centre_take(const RebomosDev &P, const int tc, c
 
 template <int G> struct CentreCfg {
   static constexpr int CAP = G;          // fast kernel: every neighbour has its own lane
-  static constexpr int GPW = 64 / G;     // centres per wave
-  static constexpr int WPB = 4;          // waves per block
+  static constexpr int GPW = 64 / G;     // centres per wave (G = 12: five, lanes 60..63 idle)
+  static constexpr int WPB = G == 12 ? 3 : 4; // waves per block (12-lane groups: 31 KB of LDS per block, 5 blocks/CU)
   static constexpr int STRIDE = CAP * kRecF + 2; // small pad: spreads the groups over the LDS banks
   // {G(cos), G'(cos)} per unordered neighbour pair, circulant layout: the pair (m, m+d mod n) lives at
   // [d-1][m], i.e. every entry is private to the lane that computes it (no index arithmetic, no conflicts)
   static constexpr int MSTRIDE = 2 * (G / 2) * G + 2;
-  static constexpr int UA = G >= 32 ? 1 : (G >= 16 ? 2 : 4); // candidate chunks in flight in phase A
+  static constexpr int UA = G >= 32 ? 1 : (G >= 12 ? 2 : 4); // candidate chunks in flight in phase A
 };
 
 // slot of the unordered pair (a < b) in the triangular matrix of a G-slot group
@@ -326,7 +345,7 @@ template <int G> struct CentreCfg {
 // A centre whose coordination has outgrown its lane group since the last list build is handed to
 // rebo_centre_general_kernel through the overflow list.
 template <int G>
-__global__ __launch_bounds__(256) void rebo_centre_kernel(
+__global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
@@ -342,9 +361,11 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
   const int lane = tid & 63;
   const int s = lane % G;          // lane within the centre's group
   const int glane0 = lane - s;     // first lane of the group
-  const int grp_in_block = tid / G;
-  const long long gid = (long long) blockIdx.x * (256 / G) + grp_in_block;
-  const bool have = gid < ncent;
+  const int gw = lane / G;         // group within the wave (G = 12: the last four lanes form no group)
+  const bool lane_ok = gw < C::GPW;
+  const int grp_in_block = (tid >> 6) * C::GPW + (lane_ok ? gw : C::GPW - 1);
+  const long long gid = (long long) blockIdx.x * (C::WPB * C::GPW) + grp_in_block;
+  const bool have = lane_ok && gid < ncent;
 
   double *rec = s_rec + (size_t) grp_in_block * C::STRIDE;
   double *mat = s_mat + (size_t) grp_in_block * C::MSTRIDE;
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     if (s == 0) ovf[1 + atomicAdd(&ovf[0], 1)] = c;
     n = 0;
   }
-  const double Ntot = group_sum<G>(nsum);
+  const double Ntot = group_sum_any<G>(nsum, s, lane);
   wave_lds_fence();
 
   // centre-element constants
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
     mC = (mw > kTol) ? 0.5 * mVA * (-0.5 * mp * mp * mp) : 0.0;
     rec[m * kRecF + 6] = mC;
   }
-  const double Csum = group_sum<G>(mC);
+  const double Csum = group_sum_any<G>(mC, s, lane);
   wave_lds_fence();
   // -- phase C: forces on the slots (pair_rebomos.cpp:634-725), again once per unordered pair: the lane of
   //    m adds its own part and ships the partner's part (force on q and C_m G for q's radial term)
@@ -523,8 +544,8 @@ __global__ __launch_bounds__(256) void rebo_centre_kernel(
                 fnbr, eh, o);
   // the centre's own share: minus the sum of its slot forces, plus the centre halves of the pair energies.
   // Written once here so that the gather only has to follow the reverse slots.
-  const double ox = group_sum<G>(act ? fx : 0.0), oy = group_sum<G>(act ? fy : 0.0), oz = group_sum<G>(act ? fz : 0.0);
-  const double oe = (eflag & MDP_EFLAG_ATOM) ? group_sum<G>(eh) : 0.0;
+  const double ox = group_sum_any<G>(act ? fx : 0.0, s, lane), oy = group_sum_any<G>(act ? fy : 0.0, s, lane), oz = group_sum_any<G>(act ? fz : 0.0, s, lane);
+  const double oe = (eflag & MDP_EFLAG_ATOM) ? group_sum_any<G>(eh, s, lane) : 0.0;
   if (owned && s == 0 && !outgrown) reinterpret_cast<double4 *>(fown)[c] = make_double4(-ox, -oy, -oz, oe);
   centre_tally(o, acc, eflag, vflag);
 }
@@ -2064,11 +2085,11 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
       n += (dx * dx + dy * dy + dz * dz) < P.rcmaxsq[ti * 2 + (int) xj.w];
     }
     // smallest lane group that holds the current coordination (one lane per neighbour, some to spare)
-    k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 14) ? 2 : 3;
+    k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 12) ? 2 : (n <= 14) ? 3 : 4; // groups of 4, 8, 12, 16, 32 lanes
     k = 2 * k + (ti != 0); // classes are per (lane-group size, element): the element is then uniform per launch
   }
 #pragma unroll
-  for (int kk = 0; kk < 8; kk++) {
+  for (int kk = 0; kk < MDP_NCLASS; kk++) {
     const unsigned long long m = __ballot(k == kk);
     if (m == 0ull) continue;
     int base = 0;
@@ -2207,14 +2228,14 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
-  MDP_HIP(c, c->class_list.reserve((size_t) 8 * nall + 8));
-  MDP_HIP(c, c->class_count.reserve(8));
+  MDP_HIP(c, c->class_list.reserve((size_t) MDP_NCLASS * nall + 8));
+  MDP_HIP(c, c->class_count.reserve(MDP_NCLASS));
   MDP_HIP(c, c->xhold_all.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, sizeof(int) * (nall + 1), st));
   MDP_HIP(c, hipMemsetAsync(c->amask.p, 0, sizeof(unsigned long long) * nall, st));
   MDP_HIP(c, hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, st));
-  MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * 8, st));
+  MDP_HIP(c, hipMemsetAsync(c->class_count.p, 0, sizeof(int) * MDP_NCLASS, st));
   // one bin grid serves both lists (cell width >= (rcLJmax + s_in)/2)
   double ljcut = 0.0, candcut = 0.0;
   for (int k = 0; k < 4; k++) {
@@ -2384,20 +2405,21 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
-  MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * MDP_NCLASS, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   if (hflags[1])
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
   { // packed candidate heads of the lane-group classes (widths = UA*G of rebo_centre_kernel<G>), per element
-    const int width[4] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<16>::UA * 16, CentreCfg<32>::UA * 32};
+    const int width[5] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<12>::UA * 12, CentreCfg<16>::UA * 16,
+                          CentreCfg<32>::UA * 32};
     size_t total = 0;
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < MDP_NCLASS; k++) {
       c->pk_base[k] = total;
       total += (size_t) c->h_class_count[k] * width[k / 2];
     }
     MDP_HIP(c, c->pk_cand.reserve(total + 1));
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < MDP_NCLASS; k++) {
       const long long n = (long long) c->h_class_count[k] * width[k / 2];
       if (n > 0)
         pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], width[k / 2],
@@ -2474,9 +2496,9 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag)
     const int k = 2 * kg + elem;
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
-    const int per_block = 256 / G;
+    constexpr int per_block = CentreCfg<G>::WPB * CentreCfg<G>::GPW;
     const int grid = (n + per_block - 1) / per_block;
-    rebo_centre_kernel<G><<<grid, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
+    rebo_centre_kernel<G><<<grid, 64 * CentreCfg<G>::WPB, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
                                                        c->xq.p, c->cand_off.p, c->cand.p, c->pk_cand.p + c->pk_base[k],
                                                        c->amask.p, c->fnbr.p, c->fown.p, c->acc.p, c->ovf.p, eflag, vflag,
                                                        elem);
@@ -2549,12 +2571,13 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
   MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));
   launch_centre<4>(c, 0, eflag, vflag);
   launch_centre<8>(c, 1, eflag, vflag);
-  launch_centre<16>(c, 2, eflag, vflag);
-  launch_centre<32>(c, 3, eflag, vflag);
+  launch_centre<12>(c, 2, eflag, vflag);
+  launch_centre<16>(c, 3, eflag, vflag);
+  launch_centre<32>(c, 4, eflag, vflag);
   // centres that outgrew their lane group since the last build (normally none: the kernel reads the
   // count from the device and exits)
   int total = 0;
-  for (int k = 0; k < 8; k++) total += c->h_class_count[k];
+  for (int k = 0; k < MDP_NCLASS; k++) total += c->h_class_count[k];
   const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
   if (grid)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
@@ -2569,7 +2592,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
 static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < MDP_NCLASS; k++) {
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
     const int grid = n / 8 + 1 < 2048 ? n / 8 + 1 : 2048;
