@@ -217,7 +217,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     if args.workload == "rebomos":
         lj = "rebo_lj_gather_kernel<16>" if os.environ.get("MDP_LJ_TILE", "1") == "0" else "rebo_lj_tile_kernel"
-        knames = ["rebo_centre_kernel<4|8|16|32>", lj]
+        knames = ["rebo_centre_kernel<4|8|12|16|32>", lj]
     else:
         knames = ["aeam_density_kernel", "aeam_embed_kernel", "aeam_force_kernel"]
     kdom = int(np.argmax(kms[:len(knames)]))
