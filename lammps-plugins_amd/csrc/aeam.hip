@@ -21,6 +21,8 @@
 // aeam_force_ang_kernel    one wave per owned angular atom, triplet forces              (A4)
 #include "mdp_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int AE_L = 8;      // lanes per atom in the list-streaming kernels
@@ -141,6 +143,285 @@ __global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, cons
   }
   acc = lane_sum<L>(acc);
   if (have && metal && s == 0) rho[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Tile-list variants (resident mode, two atom types, force-only steps).  Same scheme as the REBO-MoS
+// Lennard-Jones kernel (csrc/rebomos.hip): one workgroup = one tile of 16 two-atom clusters; the UNION of their
+// neighbourhoods is gathered once into LDS, the cluster rows are 16-bit indices into it, segmented by the
+// neighbour's type (so every table selector is a choice between two scalars by the cluster atom's type) and
+// padded to wave-uniform lengths with a dummy entry that lies outside every cutoff.  What remains in global
+// memory per pair are the spline rows themselves.
+// ------------------------------------------------------------------------------------------------------
+// r and 1/r from one reciprocal square root: hardware seed + two Newton steps (~1 ulp) instead of an IEEE sqrt
+// and an IEEE divide (~45 instructions); only the tile kernels use it (they are arithmetic-bound, the CSR
+// kernels are not)
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+
+constexpr int kTile = 16; // clusters per tile (= MDP_TILE of rebomos.hip)
+
+__device__ __forceinline__ int xcd_contiguous(const int b, const int n)
+{
+  const int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// parameters of the visit (i = cluster atom of type ta, j of type TJ), or transposed (i = j's type, j = ta)
+struct TilePar {
+  double cut, rdr;
+  int nr, trho, tz2r, pair; // pair = ti * 2 + tj of the visit
+};
+template <int TJ, bool TRANSPOSED> __device__ __forceinline__ TilePar tile_par(const AeamDev &A, const int ta)
+{
+  // ntypes == 2: pair index ti * 2 + tj
+  constexpr int p0 = TRANSPOSED ? TJ * 2 + 0 : 0 * 2 + TJ, p1 = TRANSPOSED ? TJ * 2 + 1 : 1 * 2 + TJ;
+  TilePar q;
+  q.cut = ta ? A.cut[p1] : A.cut[p0];
+  q.rdr = ta ? A.rdr[p1] : A.rdr[p0];
+  q.nr = ta ? A.nr[p1] : A.nr[p0];
+  q.trho = ta ? A.t2rhor[p1] : A.t2rhor[p0];
+  q.tz2r = ta ? A.t2z2r[p1] : A.t2z2r[p0];
+  q.pair = ta ? p1 : p0;
+  return q;
+}
+
+// pass 1, metal centres (pair_aeam.cpp:174-205)
+template <int CL>
+__global__ __launch_bounds__(256) void aeam_tile_density_kernel(
+    const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const int cap, const int capL,
+    const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
+    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, double *__restrict__ rho)
+{
+  constexpr int L = 16, SK = 3;
+  extern __shared__ double s_pos[]; // [capL][3]
+  const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int kc = t * kTile + tid / L;
+  const bool have = kc < nclus;
+  const int nU = tile_nu[2 * t];
+  const int *__restrict__ mem = tu + (size_t) t * cap;
+  int sidx[SK];
+#pragma unroll
+  for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k];
+  const long long b = lj_off[kc];
+  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
+  const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
+  const unsigned short *__restrict__ row = lj16 + b;
+  double4 xa[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) xa[c] = xq[have && kc * CL + c < nlocal ? kc * CL + c : nlocal - 1];
+  {
+    double4 sv[SK];
+#pragma unroll
+    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int u = tid + 256 * k;
+      if (u < nU) {
+        s_pos[3 * u] = sv[k].x;
+        s_pos[3 * u + 1] = sv[k].y;
+        s_pos[3 * u + 2] = sv[k].z;
+      }
+    }
+  }
+  for (int u = tid + 256 * SK; u < nU; u += 256) {
+    const double4 v = xq[mem[u]];
+    s_pos[3 * u] = v.x;
+    s_pos[3 * u + 1] = v.y;
+    s_pos[3 * u + 2] = v.z;
+  }
+  if (tid == 0) {
+    s_pos[3 * nU] = 1.0e30;
+    s_pos[3 * nU + 1] = 0.0;
+    s_pos[3 * nU + 2] = 0.0;
+  }
+  int ta[CL];
+  bool metal[CL];
+  double acc[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    ta[c] = (int) xa[c].w;
+    metal[c] = have && kc * CL + c < nlocal && ta[c] < A.nnonangular;
+    acc[c] = 0.0;
+  }
+  __syncthreads();
+  const int nm1 = A.nrmax + 1;
+  auto segment = [&](auto tjc) {
+    constexpr int TJ = decltype(tjc)::value;
+    const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
+    TilePar q[CL];
+#pragma unroll
+    for (int c = 0; c < CL; c++) q[c] = tile_par<TJ, false>(A, ta[c]);
+    for (int k = kb + s; k < ke; k += L) {
+      const double *p3 = s_pos + 3 * (int) row[k];
+      const double xj = p3[0], yj = p3[1], zj = p3[2];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        const double r = rsq * rsqrt_nr(rsq > 0.0 ? rsq : 1.0);
+        // rsq > 0: the union holds the cluster's own atoms too.  CutDec applies only when BOTH are angular
+        // (pair_aeam.cpp:187-190), never here.
+        const bool in = metal[c] && rsq > 0.0 && r <= q[c].cut;
+        double pf;
+        const int m = spline_index(in ? r : 0.0, q[c].rdr, q[c].nr, pf);
+        const double val = v4_val(A.rhor_v4[(size_t) q[c].trho * nm1 + m], pf);
+        acc[c] += in ? val : 0.0;
+      }
+    }
+  };
+  segment(std::integral_constant<int, 0>{});
+  segment(std::integral_constant<int, 1>{});
+#pragma unroll
+  for (int c = 0; c < CL; c++) acc[c] = lane_sum<L>(acc[c]);
+  if (s < CL) {
+#pragma unroll
+    for (int c = 0; c < CL; c++)
+      if (c == s && metal[c]) rho[kc * CL + c] = acc[c];
+  }
+}
+
+// pass 3, pair part (pair_aeam.cpp:309-393), force only: both visits that touch the cluster atom, as in
+// aeam_force_kernel.  LDS record of a union member: x y z q with q = Fptmp*F' of metal neighbours, 0 otherwise.
+template <int CL>
+__global__ __launch_bounds__(256) void aeam_tile_force_kernel(
+    const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const double *__restrict__ fp,
+    const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
+    const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16,
+    double *__restrict__ f)
+{
+  constexpr int L = 16, SK = 3;
+  extern __shared__ double s_rec[]; // [capL][4]
+  double4 *__restrict__ s4 = reinterpret_cast<double4 *>(s_rec);
+  const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int kc = t * kTile + tid / L;
+  const bool have = kc < nclus;
+  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1]; // members [0,N0) are of type 0
+  const int *__restrict__ mem = tu + (size_t) t * cap;
+  int sidx[SK];
+#pragma unroll
+  for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k];
+  const long long b = lj_off[kc];
+  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
+  const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
+  const unsigned short *__restrict__ row = lj16 + b;
+  double4 xa[CL];
+  double qa[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    const int ia = have && kc * CL + c < nlocal ? kc * CL + c : nlocal - 1;
+    xa[c] = xq[ia];
+    qa[c] = fp[ia];
+  }
+  {
+    double4 sv[SK];
+    double sq[SK];
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int j = tid + 256 * k < nU ? sidx[k] : 0;
+      sv[k] = xq[j];
+      sq[k] = fp[j];
+    }
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int u = tid + 256 * k;
+      if (u < nU) s4[u] = make_double4(sv[k].x, sv[k].y, sv[k].z, (u < N0 ? 0 : 1) < A.nnonangular ? sq[k] : 0.0);
+    }
+  }
+  for (int u = tid + 256 * SK; u < nU; u += 256) {
+    const int j = mem[u];
+    const double4 v = xq[j];
+    s4[u] = make_double4(v.x, v.y, v.z, (u < N0 ? 0 : 1) < A.nnonangular ? fp[j] : 0.0);
+  }
+  if (tid == 0) s4[nU] = make_double4(1.0e30, 0.0, 0.0, 0.0);
+  int ta[CL];
+  bool real[CL];
+  double fx[CL], fy[CL], fz[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    ta[c] = (int) xa[c].w;
+    real[c] = have && kc * CL + c < nlocal;
+    if (!(ta[c] < A.nnonangular)) qa[c] = 0.0; // (1 - deli): angular centres embed through the three-body kernel
+    fx[c] = fy[c] = fz[c] = 0.0;
+  }
+  __syncthreads();
+  const int nm1 = A.nrmax + 1;
+  auto segment = [&](auto tjc) {
+    constexpr int TJ = decltype(tjc)::value;
+    const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
+    TilePar qA[CL], qJ[CL];
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
+      qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
+    }
+    // (plain loops: batching the loads of several entries was tried and lost to the occupancy it costs)
+    for (int k = kb + s; k < ke; k += L) {
+      const double4 xj = s4[(int) row[k]];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        const double dx = xj.x - xa[c].x, dy = xj.y - xa[c].y, dz = xj.z - xa[c].z;
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        const bool pair = real[c] && rsq > 0.0; // (the union holds the cluster's own atoms too)
+        const double recip = rsqrt_nr(pair ? rsq : 1.0);
+        const double r = rsq * recip;
+        const bool in_a = pair && r <= qA[c].cut, in_j = pair && r <= qJ[c].cut;
+        if (!(in_a || in_j)) continue;
+        double fpair_a = 0.0, fpair_j = 0.0, dfa = 0.0;
+        if (in_a) {
+          double pf;
+          const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
+          const double4 *rec = A.pair_d8 + 2 * ((size_t) qA[c].pair * nm1 + m); // same row m for both (pair_aeam.cpp:367)
+          dfa = d4_der(rec[0], pf);
+          const double phip = d4_der(rec[1], pf);
+          fpair_a = -qa[c] * dfa * recip + 0.5 * (-phip * recip);
+        }
+        if (in_j) {
+          const double qj = xj.w;
+          if (TJ == ta[c] && in_a) { // same element: both visits read the same table rows
+            fpair_j = fpair_a + (qa[c] - qj) * dfa * recip;
+          } else {
+            double pf;
+            const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
+            const double4 *rec = A.pair_d8 + 2 * ((size_t) qJ[c].pair * nm1 + m);
+            const double dfja = d4_der(rec[0], pf);
+            const double phip = d4_der(rec[1], pf);
+            fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
+          }
+        }
+        const double ft = fpair_a + fpair_j;
+        fx[c] -= dx * ft;
+        fy[c] -= dy * ft;
+        fz[c] -= dz * ft;
+      }
+    }
+  };
+  segment(std::integral_constant<int, 0>{});
+  segment(std::integral_constant<int, 1>{});
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    fx[c] = lane_sum<L>(fx[c]);
+    fy[c] = lane_sum<L>(fy[c]);
+    fz[c] = lane_sum<L>(fz[c]);
+  }
+  if (s < CL) {
+#pragma unroll
+    for (int c = 0; c < CL; c++)
+      if (c == s && real[c]) { // plain += : only writer of owned f here (stream order); the angular kernel follows
+        double *fo = f + 3 * (size_t) (kc * CL + c);
+        fo[0] += fx[c];
+        fo[1] += fy[c];
+        fo[2] += fz[c];
+      }
+  }
 }
 
 // ---- angular centres: one wave per centre, in-range neighbours staged in LDS (list order kept) ------
@@ -568,6 +849,28 @@ __global__ void relay_kernel(const size_t nrows, const double *__restrict__ src,
   der4[i] = make_double4(c[0], c[1], c[2], 0.0);
 }
 
+// derivative coefficients of rho (c0..c2) and of phi (c0..c2) of ONE pair type side by side in a 64-byte
+// record: the pair-force visit needs both at the same row, and two 32-byte records from different arrays
+// cost two separate 128-byte L1 line fills
+__global__ void pair_der_kernel(const int npair, const int nm1, const int *__restrict__ t2rhor,
+                                const int *__restrict__ t2z2r, const double *__restrict__ rhor,
+                                const double *__restrict__ z2r, double *__restrict__ out /* [npair][nm1][8] */)
+{
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t) npair * nm1) return;
+  const int pt = (int) (i / nm1), m = (int) (i % nm1);
+  const double *a = rhor + ((size_t) t2rhor[pt] * nm1 + m) * 7, *b = z2r + ((size_t) t2z2r[pt] * nm1 + m) * 7;
+  double *o = out + 8 * i;
+  o[0] = a[0];
+  o[1] = a[1];
+  o[2] = a[2];
+  o[3] = 0.0;
+  o[4] = b[0];
+  o[5] = b[1];
+  o[6] = b[2];
+  o[7] = 0.0;
+}
+
 __global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
                                 int *__restrict__ count)
 {
@@ -595,6 +898,24 @@ int mdp_aeam_prepare(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   MDP_HIP(c, hipMemcpyAsync(&c->h_ang_count, c->ang_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
+  // resident mode, two atom types: tile lists next to the CSR list (which the angular kernels and the steps
+  // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
+  c->aeam_tiled = false;
+  const char *e = getenv("MDP_AEAM_TILE");
+  if (c->md && c->aeam.ntypes == 2 && c->nlocal > 0 && !(e && atoi(e) == 0)) {
+    double cutsq[4];
+    for (int ti = 0; ti < 2; ti++)
+      for (int tj = 0; tj < 2; tj++) { // either visit of the pair may need it
+        const double a = c->aeam.cut[ti * 2 + tj], b = c->aeam.cut[tj * 2 + ti];
+        const double rc = (a > b ? a : b) + c->cfg.skin;
+        cutsq[ti * 2 + tj] = rc * rc;
+      }
+    const char *ecl = getenv("MDP_AEAM_CLUSTER");
+    c->aeam_cl = ecl && atoi(ecl) == 2 ? 2 : 1;
+    bool ok = false;
+    MDP_TRY(mdp_tile_lists_build(c, cutsq, c->aeam_cl, &ok));
+    c->aeam_tiled = ok;
+  }
   return MDP_OK;
 }
 
@@ -606,7 +927,22 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   const int nlocal = c->nlocal;
   MDP_TRY(mdp_acc_begin(c, true));
   mdp_time_mark(c, 0);
-  if (nlocal) {
+  if (nlocal && c->aeam_tiled) {
+    const int capL = (c->tile_maxu + 1 + 7) & ~7;
+    const size_t lds = (size_t) capL * 3 * sizeof(double);
+#define MDP_ATD(CLV)                                                                                                 \
+  do {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                              \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_density_kernel<CLV>,                                    \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+    aeam_tile_density_kernel<CLV><<<c->ntile, 256, lds, st>>>(c->aeam, nlocal, c->nclus, c->xq.p, c->tile_cap, capL,    \
+                                                              c->tu.p, c->tile_nu.p, c->lj_off.p, c->lj_split.p,      \
+                                                              c->lj16.p, c->rho.p);                                   \
+  } while (0)
+    if (c->aeam_cl == 1) MDP_ATD(1);
+    else MDP_ATD(2);
+#undef MDP_ATD
+  } else if (nlocal) {
     const int grid = nblk(nlocal, 256 / AE_L);
     switch (c->aeam.ntypes) {
       case 1: aeam_density_kernel<AE_L, 1><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
@@ -639,7 +975,22 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, st));
   }
-  if (nlocal) {
+  if (nlocal && c->aeam_tiled && !(eflag || vflag)) { // force-only step: tile lists
+    const int capL = (c->tile_maxu + 1 + 7) & ~7;
+    const size_t lds = (size_t) capL * 4 * sizeof(double);
+#define MDP_ATF(CLV)                                                                                                 \
+  do {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                              \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV>,                                      \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+    aeam_tile_force_kernel<CLV><<<c->ntile, 256, lds, st>>>(c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap,   \
+                                                            capL, c->tu.p, c->tile_nu.p, c->lj_off.p, c->lj_split.p,  \
+                                                            c->lj16.p, c->f.p);                                       \
+  } while (0)
+    if (c->aeam_cl == 1) MDP_ATF(1);
+    else MDP_ATF(2);
+#undef MDP_ATF
+  } else if (nlocal) {
     const int grid = nblk(nlocal, 256 / AE_L);
     const bool ev = eflag || vflag;
 #define MDP_AF(NTV, EVV)                                                                                              \
@@ -718,6 +1069,21 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     A.rhor_d4 = c->aeam_rhor_d4.p;
     A.z2r_v4 = c->aeam_z2r_v4.p;
     A.z2r_d4 = c->aeam_z2r_d4.p;
+    // per pair type: {rho' coefficients | phi' coefficients} in one 64-byte record (tile force kernel)
+    const int npair = A.ntypes * A.ntypes, nm1 = A.nrmax + 1;
+    MDP_HIP(c, c->aeam_pair_d8.reserve((size_t) npair * nm1 * 8 + 8));
+    MDP_HIP(c, c->aeam_maps.reserve(32));
+    int h_map[32];
+    for (int k = 0; k < 16; k++) {
+      h_map[k] = A.t2rhor[k];
+      h_map[16 + k] = A.t2z2r[k];
+    }
+    MDP_HIP(c, hipMemcpyAsync(c->aeam_maps.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, c->stream));
+    pair_der_kernel<<<(int) (((size_t) npair * nm1 + 255) / 256), 256, 0, c->stream>>>(
+        npair, nm1, c->aeam_maps.p, c->aeam_maps.p + 16, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
+    MDP_HIP(c, hipGetLastError());
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    A.pair_d8 = reinterpret_cast<const double4 *>(c->aeam_pair_d8.p);
   }
   c->have_aeam = true;
   return MDP_OK;

@@ -85,6 +85,7 @@ struct AeamDev {
   int nrho[4], t2frho[4];
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
+  const double4 *pair_d8; // [ntypes*ntypes][nrmax+1][2]: {rho' c0..c2,0 | phi' c0..c2,0} of the pair type, 64 B per row
 };
 
 struct mdp_ctx {
@@ -100,6 +101,8 @@ struct mdp_ctx {
   AeamDev aeam;
   DevBuf<double> aeam_frho, aeam_rhor, aeam_z2r;
   DevBuf<double4> aeam_rhor_v4, aeam_rhor_d4, aeam_z2r_v4, aeam_z2r_d4;
+  DevBuf<double> aeam_pair_d8;
+  DevBuf<int> aeam_maps;
 
   // ---- atoms
   int nlocal = 0, nghost = 0, nall = 0, ntypes = 0;
@@ -186,6 +189,8 @@ struct mdp_ctx {
   DevBuf<int> ang_list;           // owned angular atoms
   DevBuf<int> ang_count;
   int h_ang_count = 0;
+  int aeam_cl = 1;                // atoms per cluster of the AEAM tile lists
+  bool aeam_tiled = false;        // resident mode, two types: tile lists (tu / lj16 ...) serve the force-only steps
 
   // ---- binning (shared by the master-list builder and the cluster-list builder)
   MdpGrid grid;
@@ -235,6 +240,7 @@ int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null); // x
 int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // d_out[n] = total (n+1 entries)
 int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n);
 int mdp_rebomos_repack(mdp_ctx *c);
+int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok); // tile lists (cl atoms per cluster) for a two-type style; needs the bin grid
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag);
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag);

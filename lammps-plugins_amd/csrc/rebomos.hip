@@ -2435,6 +2435,77 @@ int mdp_rebomos_repack(mdp_ctx *c)
   return MDP_OK;
 }
 
+// The same tile lists for another two-type style (AEAM, resident mode): `cutsq[ti*2+tj]` = squared list radius of
+// the pair; needs the bin grid of the current positions (mdp_bin_atoms).  Fills tu / tile_nu / lj_off / lj_split /
+// lj16 and c->nclus, ntile, tile_cap, tile_maxu; *ok = false when a union does not fit (caller keeps its CSR path).
+int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
+{
+  *ok = false;
+  const int nlocal = c->nlocal;
+  hipStream_t st = c->stream;
+  if (cl != 1) cl = 2;
+  const int nclus = (nlocal + cl - 1) / cl;
+  if (nclus <= 0) return MDP_OK;
+  const int ntile = (nclus + MDP_TILE - 1) / MDP_TILE;
+  const int nrow = ntile * MDP_TILE;
+  RebomosDev P = {};
+  for (int k = 0; k < 4; k++) P.ljlist_cutsq[k] = cutsq[k];
+  MDP_HIP(c, c->lj_split.reserve(nrow + 1));
+  MDP_HIP(c, c->lj_cnt.reserve(nrow + 1));
+  MDP_HIP(c, c->lj_off.reserve(nrow + 2));
+  MDP_HIP(c, c->tile_flag.reserve(4));
+  MDP_HIP(c, c->tile_nu.reserve((size_t) 2 * ntile + 2));
+  int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
+  for (;;) {
+    MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
+    MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
+    MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 2, st));
+    const size_t lds = (size_t) 14 * cap;
+    if (cl == 1) {
+      if (lds > 48 * 1024)
+        MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) lds));
+      tile_scan_kernel<1><<<ntile, 256, lds, st>>>(c->grid, P, nclus, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
+                                                   cap, c->tu.p, c->tmask.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p,
+                                                   c->tile_flag.p);
+    } else {
+      if (lds > 48 * 1024)
+        MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) lds));
+      tile_scan_kernel<2><<<ntile, 256, lds, st>>>(c->grid, P, nclus, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
+                                                   cap, c->tu.p, c->tmask.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p,
+                                                   c->tile_flag.p);
+    }
+    MDP_HIP(c, hipGetLastError());
+    int tf[2] = {0, 0};
+    MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipStreamSynchronize(st));
+    if (!tf[0]) {
+      c->tile_cap = cap;
+      c->tile_maxu = tf[1];
+      break;
+    }
+    cap *= 2;
+    if (cap > 4096) return MDP_OK; // *ok stays false
+  }
+  MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nrow));
+  long long total = 0;
+  MDP_HIP(c, hipMemcpyAsync(&total, c->lj_off.p + nrow, sizeof(long long), hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_HIP(c, c->lj16.reserve((size_t) total + 256));
+  tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
+                                          c->lj16.p);
+  MDP_HIP(c, hipGetLastError());
+  c->nclus = nclus;
+  c->ntile = ntile;
+  c->lj_total = total;
+  if (getenv("MDP_DEBUG"))
+    fprintf(stderr, "[mdp] tile lists (generic): %d tiles, cap %d, largest union %d, %.1f row entries per cluster\n", ntile,
+            c->tile_cap, c->tile_maxu, (double) total / nclus);
+  *ok = true;
+  return MDP_OK;
+}
+
 // `neigh_modify check yes`, done by the style for its own lists: has any atom (ghosts included) moved
 // more than half the inner skin since they were built?
 //   host mode     : checked before every compute (the host synchronises each step anyway)
