@@ -219,7 +219,9 @@ def main():
         lj = "rebo_lj_gather_kernel<16>" if os.environ.get("MDP_LJ_TILE", "1") == "0" else "rebo_lj_tile_kernel"
         knames = ["rebo_centre_kernel<4|8|12|16|32>", lj]
     else:
-        knames = ["aeam_density_kernel", "aeam_embed_kernel", "aeam_force_kernel"]
+        # timed phases of the AEAM path (each is the named kernels back to back on the compute stream)
+        knames = ["aeam_tile_density_kernel+aeam_density_ang_kernel", "aeam_embed_kernel",
+                  "aeam_tile_force_kernel+aeam_force_ang_kernel"]
     kdom = int(np.argmax(kms[:len(knames)]))
     # algorithmic bytes of ONE launch of the dominant kernel: SURVEY 8(d) per-atom figure x atoms per launch
     alg_bytes = B_ALG[args.workload] * dom.nlocal
