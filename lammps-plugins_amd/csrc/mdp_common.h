@@ -175,6 +175,9 @@ struct mdp_ctx {
   DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
   DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
+  double skin_inner_auto = 1.0;   // adaptive default of it (grows when the displacement trigger fires too often)
+  long long computes_since_build = 0;
+  bool stale_rebuild = false;     // the pending rebuild was asked for by the displacement trigger
   long long style_builds = 0;     // number of style-list builds so far
   long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
   hipEvent_t ev_stale = nullptr;

@@ -2205,8 +2205,19 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
   double s_in = c->skin > 0.0 ? c->skin : 2.0;
   {
-    double want = 1.0; // default inner skin (A); MDP_INNER_SKIN overrides, never above the host's skin
-    if (const char *e = getenv("MDP_INNER_SKIN")) want = atof(e);
+    // Inner skin (A): starts at 1.0 and ADAPTS -- when the displacement trigger fires again within 200 computes
+    // (thermal vibration reaching half the skin: every ~60 steps at 300 K), the next lists get 0.2 A more, up to
+    // the host's skin.  Rows grow ~5 % per step of 0.2 A; a rebuild costs ~10 steps' worth of compute.
+    // MDP_INNER_SKIN fixes the value instead.
+    double want = c->skin_inner_auto;
+    if (const char *e = getenv("MDP_INNER_SKIN")) {
+      want = atof(e);
+    } else if (c->stale_rebuild && c->computes_since_build < 200 && want + 0.2 < s_in + 1e-9) {
+      want += 0.2;
+      c->skin_inner_auto = want;
+    }
+    c->stale_rebuild = false;
+    c->computes_since_build = 0;
     if (want > 0.0 && want < s_in) s_in = want;
   }
   c->skin_inner = s_in;
@@ -2680,10 +2691,14 @@ static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
 // upkeep and the Lennard-Jones work of the interior clusters.  Runs while the halo exchange is in flight.
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 {
+  c->computes_since_build++;
   if (c->rebo_packed) {
     bool stale = false;
     MDP_TRY(rebomos_lists_stale(c, stale));
-    if (stale) c->rebo_packed = false;
+    if (stale) {
+      c->rebo_packed = false;
+      c->stale_rebuild = true; // the style's own trigger, not the host's reneighboring
+    }
   }
   if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
