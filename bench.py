@@ -254,7 +254,8 @@ def main():
         "ns_per_day": round(args.steps / elapsed * 0.001 * 86.4, 4),
         "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}", "transport": "rccl" if not stage_host else backend + "-staged (rehearsal)",
                    "initial_temp_K": args.temp, "skin": skin, "neighbor_rebuilds_in_timed_region": rebuilds,
-                   "inner_skin": float(os.environ.get("MDP_INNER_SKIN", "1.0")) if args.workload == "rebomos" else None,
+                   "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
+                                  else "adaptive from 1.0") if args.workload == "rebomos" else None,
                    "style_list_builds_in_timed_region_rank0": int(style_builds),
                    "pe_per_atom_start_eV": round(pe0 / s.n, 6)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
