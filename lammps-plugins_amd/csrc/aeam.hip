@@ -425,9 +425,9 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
 }
 
 // ---- angular centres: one wave per centre, in-range neighbours staged in LDS (list order kept) ------
-// slot record: dx dy dz r rsq f df flag   (d = x_j - x_i; flag bit0: inside cut - CutDec, the range of
+// slot record: dx dy dz r rsq f df fx fy fz   (d = x_j - x_i; the flag -- inside cut - CutDec, the range of
 // pass 1 and of the k loop of pass 3)
-constexpr int AREC = 8;
+constexpr int AREC = 10; // ... plus three force accumulators (pass 3)
 
 template <bool PASS3>
 __device__ __forceinline__ int ang_stage(const AeamDev &A, const double4 *__restrict__ xq, const double4 xi,
@@ -472,6 +472,7 @@ __device__ __forceinline__ int ang_stage(const AeamDev &A, const double4 *__rest
       q[4] = rsq;
       q[5] = fv;
       q[6] = dfv;
+      q[7] = q[8] = q[9] = 0.0;
       jdx[pos] = j | (inj1 << 30);
     }
     n += __popcll(bal);
@@ -746,69 +747,79 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
   const double K = -fp[i]; // -Fptmp fp
   const double third = 1.0 / 3.0;
   double fix = 0, fiy = 0, fiz = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-  for (int a = 0; a < n; a++) { // j = slot a (any staged neighbour), k = later slots inside cut-CutDec
-    const double *qa = rec + a * AREC;
+  // All (j,k) pairs -- j = slot a (any staged neighbour), k = a later slot b inside cut-CutDec -- are spread
+  // over the 64 lanes (the reference's double loop gives the wave only n-a-1 <= ~17 busy lanes per j).  The
+  // forces on j and k are summed per slot in LDS (native ds_add_f64) and flushed with one global atomic per
+  // neighbour and component afterwards.
+  const int npair = n * (n - 1) / 2;
+  for (int p0 = 0; p0 < npair; p0 += 64) {
+    const int p = p0 + lane;
+    if (p >= npair) continue;
+    // triangular decode: pairs with first index < a number a (2n - a - 1) / 2
+    int a = (int) (0.5 * ((2 * n - 1) - sqrt((double) ((2 * n - 1) * (2 * n - 1) - 8 * p))));
+    while (a > 0 && a * (2 * n - a - 1) / 2 > p) a--;
+    while ((a + 1) * (2 * n - a - 2) / 2 <= p) a++;
+    const int bq = p - a * (2 * n - a - 1) / 2 + a + 1;
+    if (!((unsigned) jdx[bq] >> 30)) continue;
+    double *qa = rec + a * AREC, *qb = rec + bq * AREC;
     const double r1 = qa[3], fij = qa[5], dfij = qa[6];
-    double fjx = 0, fjy = 0, fjz = 0;
-    for (int bq = a + 1 + lane; bq < n; bq += 64) {
-      if (!((unsigned) jdx[bq] >> 30)) continue;
-      const double *qb = rec + bq * AREC;
-      const double r2 = qb[3], fik = qb[5], dfik = qb[6];
-      const double ex = qb[0] - qa[0], ey = qb[1] - qa[1], ez = qb[2] - qa[2]; // x_k - x_j
-      const double rsq3 = ex * ex + ey * ey + ez * ez;
-      const double r3 = sqrt(rsq3);
-      const double cs = (qa[4] + qb[4] - rsq3) / (2 * r1 * r2);
-      const double dcosij = 1 / r2 - cs / r1;
-      const double dcosik = 1 / r1 - cs / r2;
-      const double dcosjk = -r3 / (r1 * r2);
-      const double delcs = cs + third;
-      const double ftet = delcs * delcs;
-      const double delcs2 = 2 * delcs;
-      const double DFij = 2.0 * (fik * dfij * ftet + fij * fik * delcs2 * dcosij); // ci = 2
-      const double DFik = 2.0 * (fij * dfik * ftet + fij * fik * delcs2 * dcosik);
-      const double DFjk = 2.0 * fij * fik * delcs2 * dcosjk;
-      const double FFij = K * DFij / r1, FFik = K * DFik / r2, FFjk = K * DFjk / r3;
-      const double gjx = qa[0] * FFij - ex * FFjk, gjy = qa[1] * FFij - ey * FFjk, gjz = qa[2] * FFij - ez * FFjk;
-      const double gkx = qb[0] * FFik + ex * FFjk, gky = qb[1] * FFik + ey * FFjk, gkz = qb[2] * FFik + ez * FFjk;
-      fjx += gjx;
-      fjy += gjy;
-      fjz += gjz;
-      const int kk = jdx[bq] & MDP_NEIGHMASK;
-      atomicAdd(&f[3 * (size_t) kk], gkx);
-      atomicAdd(&f[3 * (size_t) kk + 1], gky);
-      atomicAdd(&f[3 * (size_t) kk + 2], gkz);
-      fix -= gjx + gkx;
-      fiy -= gjy + gky;
-      fiz -= gjz + gkz;
-      if (vflag) { // ev_tally3(i,j,k,0,0,fj,fk,drji,drki)
-        const double t0 = qa[0] * gjx + qb[0] * gkx, t1 = qa[1] * gjy + qb[1] * gky, t2 = qa[2] * gjz + qb[2] * gkz;
-        const double t3 = qa[0] * gjy + qb[0] * gky, t4 = qa[0] * gjz + qb[0] * gkz, t5 = qa[1] * gjz + qb[1] * gkz;
-        v0 += t0;
-        v1 += t1;
-        v2 += t2;
-        v3 += t3;
-        v4 += t4;
-        v5 += t5;
-        if (vflag & MDP_VFLAG_ATOM) { // a third each to i, j, k (angular centres are rare: atomics)
-          const double tt[6] = {t0 * third, t1 * third, t2 * third, t3 * third, t4 * third, t5 * third};
-          const int jj = jdx[a] & MDP_NEIGHMASK;
+    const double r2 = qb[3], fik = qb[5], dfik = qb[6];
+    const double ex = qb[0] - qa[0], ey = qb[1] - qa[1], ez = qb[2] - qa[2]; // x_k - x_j
+    const double rsq3 = ex * ex + ey * ey + ez * ez;
+    const double r3 = sqrt(rsq3);
+    const double cs = (qa[4] + qb[4] - rsq3) / (2 * r1 * r2);
+    const double dcosij = 1 / r2 - cs / r1;
+    const double dcosik = 1 / r1 - cs / r2;
+    const double dcosjk = -r3 / (r1 * r2);
+    const double delcs = cs + third;
+    const double ftet = delcs * delcs;
+    const double delcs2 = 2 * delcs;
+    const double DFij = 2.0 * (fik * dfij * ftet + fij * fik * delcs2 * dcosij); // ci = 2
+    const double DFik = 2.0 * (fij * dfik * ftet + fij * fik * delcs2 * dcosik);
+    const double DFjk = 2.0 * fij * fik * delcs2 * dcosjk;
+    const double FFij = K * DFij / r1, FFik = K * DFik / r2, FFjk = K * DFjk / r3;
+    const double gjx = qa[0] * FFij - ex * FFjk, gjy = qa[1] * FFij - ey * FFjk, gjz = qa[2] * FFij - ez * FFjk;
+    const double gkx = qb[0] * FFik + ex * FFjk, gky = qb[1] * FFik + ey * FFjk, gkz = qb[2] * FFik + ez * FFjk;
+    atomicAdd(&qa[7], gjx);
+    atomicAdd(&qa[8], gjy);
+    atomicAdd(&qa[9], gjz);
+    atomicAdd(&qb[7], gkx);
+    atomicAdd(&qb[8], gky);
+    atomicAdd(&qb[9], gkz);
+    fix -= gjx + gkx;
+    fiy -= gjy + gky;
+    fiz -= gjz + gkz;
+    if (vflag) { // ev_tally3(i,j,k,0,0,fj,fk,drji,drki)
+      const double t0 = qa[0] * gjx + qb[0] * gkx, t1 = qa[1] * gjy + qb[1] * gky, t2 = qa[2] * gjz + qb[2] * gkz;
+      const double t3 = qa[0] * gjy + qb[0] * gky, t4 = qa[0] * gjz + qb[0] * gkz, t5 = qa[1] * gjz + qb[1] * gkz;
+      v0 += t0;
+      v1 += t1;
+      v2 += t2;
+      v3 += t3;
+      v4 += t4;
+      v5 += t5;
+      if (vflag & MDP_VFLAG_ATOM) { // a third each to i, j, k (angular centres are rare: atomics)
+        const double tt[6] = {t0 * third, t1 * third, t2 * third, t3 * third, t4 * third, t5 * third};
+        const int jj = jdx[a] & MDP_NEIGHMASK, kk = jdx[bq] & MDP_NEIGHMASK;
 #pragma unroll
-          for (int q6 = 0; q6 < 6; q6++) {
-            atomicAdd(&vatom[6 * (size_t) i + q6], tt[q6]);
-            atomicAdd(&vatom[6 * (size_t) jj + q6], tt[q6]);
-            atomicAdd(&vatom[6 * (size_t) kk + q6], tt[q6]);
-          }
+        for (int q6 = 0; q6 < 6; q6++) {
+          atomicAdd(&vatom[6 * (size_t) i + q6], tt[q6]);
+          atomicAdd(&vatom[6 * (size_t) jj + q6], tt[q6]);
+          atomicAdd(&vatom[6 * (size_t) kk + q6], tt[q6]);
         }
       }
     }
-    fjx = lane_sum<64>(fjx);
-    fjy = lane_sum<64>(fjy);
-    fjz = lane_sum<64>(fjz);
-    if (lane == 0 && (fjx != 0.0 || fjy != 0.0 || fjz != 0.0)) {
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int a = lane; a < n; a += 64) { // one flush per neighbour (ghosts included: the host's reverse comm folds them)
+    const double *qa = rec + a * AREC;
+    if (qa[7] != 0.0 || qa[8] != 0.0 || qa[9] != 0.0) {
       const int jj = jdx[a] & MDP_NEIGHMASK;
-      atomicAdd(&f[3 * (size_t) jj], fjx);
-      atomicAdd(&f[3 * (size_t) jj + 1], fjy);
-      atomicAdd(&f[3 * (size_t) jj + 2], fjz);
+      atomicAdd(&f[3 * (size_t) jj], qa[7]);
+      atomicAdd(&f[3 * (size_t) jj + 1], qa[8]);
+      atomicAdd(&f[3 * (size_t) jj + 2], qa[9]);
     }
   }
   fix = lane_sum<64>(fix);
