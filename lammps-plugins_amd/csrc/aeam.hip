@@ -259,8 +259,11 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     TilePar q[CL];
 #pragma unroll
     for (int c = 0; c < CL; c++) q[c] = tile_par<TJ, false>(A, ta[c]);
+    int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is requested one trip ahead
     for (int k = kb + s; k < ke; k += L) {
-      const double *p3 = s_pos + 3 * (int) row[k];
+      const int li = li_next;
+      li_next = k + L < ke ? (int) row[k + L] : nU;
+      const double *p3 = s_pos + 3 * li;
       const double xj = p3[0], yj = p3[1], zj = p3[2];
 #pragma unroll
       for (int c = 0; c < CL; c++) {
@@ -364,8 +367,10 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
       qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
     }
     // (plain loops: batching the loads of several entries was tried and lost to the occupancy it costs)
+    int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is requested one trip ahead
     for (int k = kb + s; k < ke; k += L) {
-      const double4 xj = s4[(int) row[k]];
+      const double4 xj = s4[li_next];
+      li_next = k + L < ke ? (int) row[k + L] : nU;
 #pragma unroll
       for (int c = 0; c < CL; c++) {
         const double dx = xj.x - xa[c].x, dy = xj.y - xa[c].y, dz = xj.z - xa[c].z;
