@@ -2031,8 +2031,10 @@ __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double
     far = far || d2 > trigsq;
     toofar = toofar || d2 > hardsq;
   }
-  if (__any(far) && (threadIdx.x & 63) == 0) atomicOr(&flag[0], 1);
-  if (__any(toofar) && (threadIdx.x & 63) == 0) atomicOr(&flag[1], 1);
+  // `flag` is pinned HOST memory (zeroed by the host before the launch): plain idempotent stores, visible when the
+  // kernel has completed -- no memset and no copy engine in the per-step path
+  if (__any(far) && (threadIdx.x & 63) == 0) flag[0] = 1;
+  if (__any(toofar) && (threadIdx.x & 63) == 0) flag[1] = 1;
 }
 
 // rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
@@ -2529,13 +2531,12 @@ static int rebomos_check_launch(mdp_ctx *c, const double trig)
 {
   hipStream_t st = c->stream;
   const int nall = c->nall;
-  MDP_HIP(c, hipMemsetAsync(c->flags.p + 2, 0, 2 * sizeof(int), st));
   const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
   const double hard = 0.5 * c->skin_inner;
-  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, c->flags.p + 2);
+  int *h = (int *) (c->h_pinned + 24); // no check is in flight here: the caller has waited for the previous one
+  h[0] = h[1] = 0;
+  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, h);
   MDP_HIP(c, hipGetLastError());
-  int *h = (int *) (c->h_pinned + 24);
-  MDP_HIP(c, hipMemcpyAsync(h, c->flags.p + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   return MDP_OK;
 }
 
@@ -2649,8 +2650,7 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
 
 static int launch_centres(mdp_ctx *c, int eflag, int vflag)
 {
-  hipStream_t st = c->stream;
-  MDP_HIP(c, hipMemsetAsync(c->ovf.p, 0, sizeof(int), st));
+  hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
   launch_centre<4>(c, 0, eflag, vflag);
   launch_centre<8>(c, 1, eflag, vflag);
   launch_centre<12>(c, 2, eflag, vflag);
