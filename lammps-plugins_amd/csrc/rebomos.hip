@@ -2375,7 +2375,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
   for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
   // the tile kernel is latency-bound (measured: t = 0.65 ms + 3.96 ms / resident workgroups per CU), so the
   // common case is sized for FIVE workgroups per CU; the rare larger unions get their own launch
-  constexpr int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
+  int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
+  if (const char *e = getenv("MDP_TILE_SMALL")) kSmallUnion = atoi(e) > 0 ? atoi(e) : kSmallUnion; // (tests)
   c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
   const bool remote = c->md && c->remote_start < nall;
   if (nunit > 0 && (remote || (tiled && c->tile_maxu > kSmallUnion))) {

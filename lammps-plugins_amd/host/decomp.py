@@ -58,7 +58,7 @@ class Decomposition:
         for r in range(nranks):
             idx = np.nonzero(self.rank_of == r)[0]
             if sort_cell and len(idx):
-                idx = idx[spatial_order(x[idx], box.lo, sort_cell, group=None if type_ is None else np.asarray(type_)[idx])]
+                idx = idx[spatial_order(x[idx], box.lo, sort_cell, group=None if type_ is None else np.asarray(type_)[idx], box=box)]
             self.owned.append(idx)
             self.local_index[idx] = np.arange(len(idx))
         # ghosts of every rank (every rank needs every other rank's list to know what to send)

@@ -72,7 +72,7 @@ def hilbert_order(x: np.ndarray, lo: np.ndarray, cell: float) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
-def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float, group=None, chunk: int = 96) -> np.ndarray:
+def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float, group=None, chunk: int = 96, box=None) -> np.ndarray:
     """The order atoms are stored in on the device: along a Hilbert curve (MDP_ORDER=morton: Z-order), and,
     when `group` (the atom types) is given, each stretch of `chunk` consecutive atoms additionally sorted by
     type.  The second step makes the 2-atom clusters and 32-atom tiles of the Lennard-Jones lists
@@ -80,6 +80,12 @@ def spatial_order(x: np.ndarray, lo: np.ndarray, cell: float, group=None, chunk:
     both atoms against the larger neighbourhood, and the four clusters sharing a wavefront all run as long as
     the longest list among them.  chunk = 3 tiles keeps every tile inside one compact stretch of the curve."""
     import os
+    if box is not None:
+        # Order in lamda (fractional) coordinates, rescaled to the edge lengths: in a TRICLINIC box (the
+        # in.rebomos-bulk cell has an xy tilt of half an edge) the atoms fill a parallelepiped inside their
+        # Cartesian bounding box and a curve over that box crosses its empty corners -- consecutive atoms jump.
+        x = box.x2lamda(x) * np.linalg.norm(box.h, axis=0)
+        lo = np.zeros(3)
     order = morton_order(x, lo, cell) if os.environ.get("MDP_ORDER", "hilbert") == "morton" else hilbert_order(x, lo, cell)
     if group is not None and chunk > 0 and len(order) and os.environ.get("MDP_ORDER_GROUP", "0") != "0":
         g = np.asarray(group)[order].astype(np.int64)
@@ -126,12 +132,12 @@ class Domain:
         v = np.zeros_like(x) if v0 is None else np.asarray(v0, dtype=np.float64)
         t, g = s.type, s.tag
         if sort:
-            order = spatial_order(x, s.box.lo, 3.0, group=s.type)
+            order = spatial_order(x, s.box.lo, 3.0, group=s.type, box=s.box)
             x, v, t, g = x[order], v[order], t[order], g[order]
         owner, shift = S.make_ghosts(s.box, x, cutghost)
         shift_cart = shift @ s.box.h.T
         if sort and len(owner):
-            go = spatial_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0)
+            go = spatial_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0, box=s.box)
             owner, shift_cart = owner[go], shift_cart[go]
         d = cls(ctx, style, s.box, np.ascontiguousarray(x), np.ascontiguousarray(v), t, g, s.mass, map_,
                 owner.astype(np.int32), np.ascontiguousarray(shift_cart), t[owner], g[owner], skin, dt,

@@ -124,15 +124,15 @@ def _forces(s, env):
 
 def test_tile_lists_against_the_per_cluster_path_and_large_union_classes():
     """Two independent Lennard-Jones paths on 62 k jittered atoms: tile lists (LDS-staged unions, 16-bit
-    rows) and the per-cluster fallback (MDP_LJ_TILE=0).  A Z-order atom sequence has jumps, so some tile
-    unions exceed the small launch class: the large-union classes are exercised as well."""
+    rows) and the per-cluster fallback (MDP_LJ_TILE=0).  A Z-order atom sequence and a lowered limit of the
+    small launch class put part of the tiles into the large-union classes, which are exercised as well."""
     s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (6, 6, 6)), 0.05, seed=3)
     f0, e0, th0, i0 = _forces(s, {"MDP_LJ_TILE": "0"})
     f1, e1, th1, i1 = _forces(s, {"MDP_LJ_TILE": "1"})
-    f2, e2, th2, i2 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_ORDER": "morton"})
+    f2, e2, th2, i2 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_ORDER": "morton", "MDP_TILE_SMALL": "700"})
     assert i0["tiled"] == 0 and i1["tiled"] == 1 and i2["tiled"] == 1
     assert i1["union_max"] < i1["union_stride"]
-    assert i2["large_tiles"] > 0                       # Morton jumps -> unions beyond the small class
+    assert 0 < i2["large_tiles"] < i2["tiles"]          # both launch classes populated
     for f, e, th in ((f1, e1, th1), (f2, e2, th2)):
         assert np.abs(f - f0).max() < 1e-10
         assert np.abs(e - e0).max() < 1e-10
