@@ -273,10 +273,11 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
         // rsq > 0: the union holds the cluster's own atoms too.  CutDec applies only when BOTH are angular
         // (pair_aeam.cpp:187-190), never here.
         const bool in = metal[c] && rsq > 0.0 && r <= q[c].cut;
-        double pf;
-        const int m = spline_index(in ? r : 0.0, q[c].rdr, q[c].nr, pf);
-        const double val = v4_val(A.rhor_v4[(size_t) q[c].trho * nm1 + m], pf);
-        acc[c] += in ? val : 0.0;
+        if (in) { // (a third of the entries are skin / padding: no spline row fetched for them)
+          double pf;
+          const int m = spline_index(r, q[c].rdr, q[c].nr, pf);
+          acc[c] += v4_val(A.rhor_v4[(size_t) q[c].trho * nm1 + m], pf);
+        }
       }
     }
   };
