@@ -208,8 +208,8 @@ int mdp_md_upload_x(mdp_ctx *ctx, const double *x);                             
 /* device pointers of resident arrays for zero-copy plumbing (name: "x","v","f","fp","eatom") */
 void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
 /* statistics of the last neighbor build: out[0]=total master entries (owned; 0 if not built),
- * [1]=ghost-list entries, [2]=LJ cluster-list entries (rebomos), [3]=REBO candidate entries, [4]=#centres,
- * [5]=#centres in 4-lane groups, [6]=#centres in 16-lane groups, [7]=style-list builds so far (rebomos) /
+ * [1]=ghost-list entries, [2]=LJ row entries incl. padding (rebomos), [3]=REBO candidate entries, [4]=#centres,
+ * [5]=#centres in 4-lane groups, [6]=#centres in 12- and 16-lane groups, [7]=style-list builds so far (rebomos) /
  * #angular atoms (aeam) */
 int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
 /* shape of the rebomos style's own Lennard-Jones lists after the last build (host and resident mode):

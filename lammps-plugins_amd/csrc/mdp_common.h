@@ -145,7 +145,7 @@ struct mdp_ctx {
   long long lj_total = 0;
   int nclus = 0, cluster = MDP_CLUSTER;
   // halo overlap (multi-GPU): clusters whose lists reach no remote ghost come first in cl_order
-  int remote_start = 1 << 30, nclus_interior = 0;
+  int remote_start = 1 << 30;
   bool split_halo = false;
   DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
@@ -154,7 +154,6 @@ struct mdp_ctx {
   // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
   bool lj_tiled = false;
   int ntile = 0, tile_cap = 0, tile_maxu = 0;
-  int lj_units = 0;               // launch units of the LJ kernel: tiles (tiled) or clusters
   int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: interior small/large, boundary small/large
   bool lj_ordered = false;        // cl_order in use (otherwise natural order, everything in class 0)
   int tile_small = 0;             // largest union of the "small" launch classes

@@ -2369,7 +2369,6 @@ int mdp_rebomos_repack(mdp_ctx *c)
   // launch classes of the units (tiles, or clusters without tile lists): interior/boundary for the halo
   // overlap (only with remote ghosts), small/large union for the LDS allocation of the tile kernel
   const int nunit = tiled ? ntile : nclus;
-  c->lj_units = nunit;
   c->split_halo = false;
   c->lj_ordered = false;
   for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
