@@ -86,8 +86,8 @@ def cpu_baseline(workload, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["rebomos", "aeam"], default="rebomos")
     ap.add_argument("--replicate", type=int, nargs=3, default=None)
     ap.add_argument("--temp", type=float, default=0.0, help="initial temperature (in.rebomos-bulk: 0 K)")
