@@ -104,3 +104,31 @@ def test_resident_mode_matches_oracle_and_conserves_energy(oracle, T, pot):
     assert abs(t1["pe"] + t1["ke"] - e0) / s.n < 5e-5   # velocity-Verlet fluctuation at 600 K, dt = 1 fs
     assert d.builds >= 2                                  # hot Al crosses skin/2 = 0.5 A within 200 steps
     ctx.close()
+
+
+@pytest.mark.parametrize("frac,amp", [(0.02, 0.03), (0.30, 0.05), (0.0, 0.02)])
+def test_resident_force_only_step_matches_oracle(oracle, T, pot, frac, amp):
+    """Force-only computes in resident mode take the tile-list kernels (aeam_tile_density/force_kernel); steps that
+    tally energy or virial take the CSR kernels.  Both must give the oracle's forces: dilute Si (the shipped
+    sample), an Si-rich alloy (type-1 row segments and different-element visits everywhere) and pure Al."""
+    af, tabs = pot
+    ctx = capi.Context(0)
+    ctx.aeam_set_tables(tabs)
+    s = S.jitter(S.fcc_cell(4.045, 6, frac_type2=frac, seed=11), amp, seed=12)
+    s.mass[1:3] = af.mass
+    cutghost = float(af.cut_table(tabs).max()) + 1.0
+    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
+    d.build_neighbors()
+    d.compute(eflag=0, vflag=0)                       # tile kernels
+    got = ctx.md_download(s.n, want=("x", "f"))
+    f_tile = got["f"].copy()
+    d.compute(eflag=3, vflag=1)                       # CSR kernels on the same positions
+    f_csr = ctx.md_download(s.n, want=("f",))["f"]
+    x_tag = np.zeros_like(got["x"])
+    x_tag[d.tags_local - 1] = got["x"]
+    eng = mdref.AeamCPU(oracle, T, S.System(s.box, x_tag, s.type, s.tag, s.mass))
+    o = eng.compute(x_tag)
+    ref = o["f_owned"][d.tags_local - 1]
+    assert np.abs(f_tile - ref).max() < 1e-9
+    assert np.abs(f_csr - ref).max() < 1e-9
+    ctx.close()

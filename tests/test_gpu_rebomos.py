@@ -95,8 +95,14 @@ def test_paged_list_entry_point_and_position_update(ctx, oracle, P):
     assert g2["eng"] == pytest.approx(o2["eng"], rel=1e-10)
 
 
-def test_force_only_call_leaves_energy_untouched(ctx, oracle, P):
+@pytest.mark.parametrize("fac,amp,seed", [(1.0, 0.0, 0), (1.12, 0.15, 1234), (0.93, 0.10, 77), (1.0, 0.4, 9)])
+def test_force_only_call_leaves_energy_untouched(ctx, oracle, P, fac, amp, seed):
+    """eflag = vflag = 0 takes the kernel variants without energy/virial arithmetic (what an MD step runs);
+    the strained / compressed / jittered cells put pairs on the cubic inner LJ spline and into the switching
+    interior, so the force-only correction pass is compared with the oracle too"""
     s = S.rebomos_bulk_cell()
+    if amp:
+        s = S.jitter(S.scale(s, fac), amp, seed=seed)
     eng = mdref.RebomosCPU(oracle, P, s)
     g = _gpu_compute(ctx, eng, s.x, eflag=0, vflag=0)
     assert g["eng"] == 0.0 and not g["virial"].any() and not g["eatom"].any()
