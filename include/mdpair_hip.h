@@ -54,6 +54,13 @@ int mdp_device_count(void);
 int mdp_create(mdp_ctx **ctx, int device);
 int mdp_destroy(mdp_ctx *ctx);
 const char *mdp_last_error(const mdp_ctx *ctx);
+/* bytes of device memory the library holds in this process: what Pair::memory_usage() should add for the style's
+ * device-side lists and work arrays (the reference reports the lists it holds: pair_rebomos.cpp:1113-1124) */
+double mdp_device_bytes(const mdp_ctx *ctx);
+/* host arrays are staged through pinned buffers of the context by default.  With MDP_HOST_REGISTER=1 large arrays
+ * (atom->x) are page-locked in place instead; a host that opts in must call this before it frees or re-allocates
+ * such an array (LAMMPS: when atom->nmax grows).  ptr = NULL releases every registration. */
+int mdp_host_release(mdp_ctx *ctx, const void *ptr);
 int mdp_set_stream(mdp_ctx *ctx, void *hip_stream); /* run everything on this hipStream_t (default: own stream) */
 int mdp_sync(mdp_ctx *ctx);
 
@@ -126,6 +133,13 @@ int mdp_set_neighbors_host(mdp_ctx *ctx, int inum, int gnum, const int *ilist, c
  * implies but its entries are not read, so a rebomos host only reports the skin (at every reneighboring,
  * after mdp_set_atoms_host).  neigh_modify exclusions are therefore not honoured. */
 int mdp_set_skin(mdp_ctx *ctx, double skin);
+/* guard that goes with mdp_set_skin: the reference iterates the host's entries (pair_rebomos.cpp:304-307, 328-330,
+ * 490-495), so exclusions, special_bonds or skip lists change ITS result.  Compares the host's owned-row entry count
+ * with the number of geometric pairs inside cutneigh (= sqrt(cutsq)+skin, the host's list cutoff) counted on the
+ * device from the atoms last uploaded, and scans a sample of rows for special-bond bits; MDP_EINVAL + message on
+ * any difference.  Call at every reneighboring after mdp_set_atoms_host.  MDP_SKIP_LIST_CHECK=1 disables it. */
+int mdp_rebomos_check_host_list(mdp_ctx *ctx, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
+                                double cutneigh);
 /* same as mdp_set_neighbors_host, from a CSR copy (tests / hosts that already hold a flat list): offset[nall+1] */
 int mdp_set_neighbors_csr_host(mdp_ctx *ctx, int nall, const int *numneigh, const long long *offset,
                                const int *neigh, double skin);

@@ -1111,9 +1111,9 @@ static int aeam_fetch(mdp_ctx *c, double *eng, double *virial)
   hipStream_t st = c->stream;
   MDP_HIP(c, hipMemcpyAsync(c->h_pinned, c->acc.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
   int *hflags = (int *) (c->h_pinned + 16);
-  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 5, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
-  if (hflags[0] & 2) return mdp_fail(c, MDP_EOVERFLOW, "aeam: an angular atom has more in-range neighbours than the LDS tile holds");
+  MDP_TRY(mdp_flags_check(c, hflags));
   if (eng) *eng += c->h_pinned[0];
   if (virial)
     for (int k = 0; k < 6; k++) virial[k] += c->h_pinned[1 + k];
@@ -1122,9 +1122,14 @@ static int aeam_fetch(mdp_ctx *c, double *eng, double *virial)
 
 int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double *eng_vdwl, double *eatom)
 {
-  if (!c || !fp) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
   if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
   if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
+  if (c->nlocal == 0) { // no owned atoms on this rank: nothing to tally, the host's arrays may be NULL
+    c->rebo_packed = true;
+    return MDP_OK;
+  }
+  if (!fp) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_density_host: fp missing for %d owned atoms", c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   if (!c->rebo_packed) { // reuse the flag: "style structures follow the current list"
     MDP_TRY(mdp_aeam_prepare(c));
@@ -1148,9 +1153,11 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
 int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
                         double *virial, double *eatom, double *vatom)
 {
-  if (!c || !fp_all || !f) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
   if (!c->have_aeam || !c->atoms_set || !c->neigh_set || !c->rebo_packed)
     return mdp_fail(c, MDP_ESTATE, "aeam: call mdp_aeam_density_host first");
+  if (c->nlocal == 0) return MDP_OK; // every force term starts from an owned atom (pair_aeam.cpp:337)
+  if (!fp_all || !f) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: fp / f missing for %d atoms", c->nall);
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;

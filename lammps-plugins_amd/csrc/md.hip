@@ -106,6 +106,43 @@ __global__ __launch_bounds__(256) void nbuild_kernel(const Grid g, const CutTabl
   if (!FILL) cnt[i] = n;
 }
 
+// Number of (i owned, j != i) pairs with rsq <= cutsq, both atoms of a mapped (non-NULL) type: what a plain
+// geometric full list of the host holds for its owned rows.  rsq is formed exactly as LAMMPS' builders form it
+// (delx*delx + dely*dely + delz*delz, no fused multiply-add), so the count is comparable entry for entry.
+__global__ __launch_bounds__(256) void host_list_count_kernel(const Grid g, const double cutsq, const int nall,
+                                                              const int nlocal, const double4 *__restrict__ xq,
+                                                              const int *__restrict__ perm,
+                                                              const int *__restrict__ cell_start,
+                                                              unsigned long long *__restrict__ total)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long n = 0;
+  if (t < nall) {
+    const int i = perm[t];
+    const double4 xi = xq[i];
+    if (i < nlocal && xi.w >= 0.0) {
+      int cx, cy, cz;
+      cell_index(g, xi, cx, cy, cz);
+      const int R = g.range;
+      for (int z = max(cz - R, 0); z <= min(cz + R, g.n[2] - 1); z++)
+        for (int y = max(cy - R, 0); y <= min(cy + R, g.n[1] - 1); y++) {
+          const int c0 = max(cx - R, 0) + g.n[0] * (y + g.n[1] * z);
+          const int c1 = min(cx + R, g.n[0] - 1) + g.n[0] * (y + g.n[1] * z);
+          const int pb = cell_start[c0], pe = cell_start[c1 + 1];
+          for (int p = pb; p < pe; p++) {
+            const int j = perm[p];
+            const double4 xj = xq[j];
+            const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const double rsq = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+            n += (rsq <= cutsq && j != i && xj.w >= 0.0) ? 1u : 0u;
+          }
+        }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+}
+
 __global__ void nve_initial_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
                                    const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq)
 {
@@ -487,7 +524,8 @@ int mdp_md_build_neighbors(mdp_ctx *c)
 
 int mdp_md_initial_integrate(mdp_ctx *c)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
   if (c->nlocal)
     nve_initial_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p,
@@ -501,7 +539,8 @@ int mdp_md_initial_integrate(mdp_ctx *c)
 
 int mdp_md_final_integrate(mdp_ctx *c)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
   if (c->nlocal) nve_final_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->rmass.p, c->f.p, c->v.p);
   MDP_HIP(c, hipGetLastError());
@@ -510,7 +549,9 @@ int mdp_md_final_integrate(mdp_ctx *c)
 
 int mdp_md_aeam_density(mdp_ctx *c, int eflag)
 {
-  if (!c || !c->md || c->cfg.style != 2) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  if (c->cfg.style != 2) return mdp_fail(c, MDP_EINVAL, "not an aeam sub-domain");
   MDP_TRY(mdp_aeam_run_density(c, eflag));
   // forward comm of fp on one rank: periodic self-images copy their owner's value
   if (c->nghost)
@@ -522,13 +563,16 @@ int mdp_md_aeam_density(mdp_ctx *c, int eflag)
 
 int mdp_md_aeam_force(mdp_ctx *c, int eflag, int vflag)
 {
-  if (!c || !c->md || c->cfg.style != 2) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  if (c->cfg.style != 2) return mdp_fail(c, MDP_EINVAL, "not an aeam sub-domain");
   return mdp_aeam_run_force(c, eflag, vflag);
 }
 
 int mdp_md_fold_self_ghost_f(mdp_ctx *c)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (c->nghost)
     fold_self_ghost_f_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p, c->f.p);
   MDP_HIP(c, hipGetLastError());
@@ -537,7 +581,8 @@ int mdp_md_fold_self_ghost_f(mdp_ctx *c)
 
 int mdp_md_compute(mdp_ctx *c, int eflag, int vflag)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
   if (c->cfg.style == 1) return mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true);
   // single-rank AEAM: density, self-image fp refresh, force, fold angular ghost forces
@@ -548,7 +593,8 @@ int mdp_md_compute(mdp_ctx *c, int eflag, int vflag)
 
 int mdp_md_compute_begin(mdp_ctx *c, int eflag, int vflag)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
   if (c->cfg.style == 1) return mdp_rebomos_run_begin(c, eflag, vflag);
   return MDP_OK;
@@ -556,14 +602,16 @@ int mdp_md_compute_begin(mdp_ctx *c, int eflag, int vflag)
 
 int mdp_md_compute_end(mdp_ctx *c, int eflag, int vflag)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (c->cfg.style == 1) return mdp_rebomos_run_end(c, eflag, vflag);
   return mdp_md_compute(c, eflag, vflag);
 }
 
 int mdp_md_thermo(mdp_ctx *c, double out[9])
 {
-  if (!c || !c->md || !out) return MDP_EINVAL;
+  if (!c || !out) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   hipStream_t st = c->stream;
   MDP_HIP(c, hipMemsetAsync(c->acc.p + 7, 0, sizeof(double) * 2, st));
   const int grid = c->nlocal > 0 ? (nblk(c->nlocal) < 1024 ? nblk(c->nlocal) : 1024) : 0;
@@ -573,10 +621,9 @@ int mdp_md_thermo(mdp_ctx *c, double out[9])
   MDP_HIP(c, hipGetLastError());
   MDP_HIP(c, hipMemcpyAsync(c->h_pinned, c->acc.p, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
   int *hflags = (int *) (c->h_pinned + 16);
-  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 5, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
-  if (hflags[0] & 1)
-    return mdp_fail(c, MDP_EOVERFLOW, "REBO neighbor count exceeds the lane-group capacity (Neighbor list overflow)");
+  MDP_TRY(mdp_flags_check(c, hflags));
   out[0] = c->h_pinned[7];
   out[1] = c->h_pinned[0];
   for (int k = 0; k < 6; k++) out[2 + k] = c->h_pinned[1 + k];
@@ -586,7 +633,8 @@ int mdp_md_thermo(mdp_ctx *c, double out[9])
 
 int mdp_md_download(mdp_ctx *c, double *x, double *v, double *f, double *eatom)
 {
-  if (!c || !c->md) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   hipStream_t st = c->stream;
   const int n = c->nlocal;
   if (x && n) {
@@ -602,7 +650,8 @@ int mdp_md_download(mdp_ctx *c, double *x, double *v, double *f, double *eatom)
 
 int mdp_md_upload_x(mdp_ctx *c, const double *x)
 {
-  if (!c || !c->md || !x) return MDP_EINVAL;
+  if (!c || !x) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   hipStream_t st = c->stream;
   const int n = c->nlocal;
   if (n) {
@@ -614,6 +663,56 @@ int mdp_md_upload_x(mdp_ctx *c, const double *x)
                                                           c->xq.p);
   MDP_HIP(c, hipGetLastError());
   MDP_HIP(c, hipStreamSynchronize(st));
+  return MDP_OK;
+}
+
+// Guard for hosts whose list is not the plain geometric one.  The REBO-MoS device path derives its lists from
+// the positions (mdp_set_skin); the reference iterates the HOST's entries (pair_rebomos.cpp:304-307, 328-330,
+// 490-495), so `neigh_modify exclude`, special_bonds weights or a hybrid skip list would silently change the
+// reference's result but not this one.  Compare the host's owned-row entry count with the geometric count at the
+// host's list cutoff and look for special-bond bits in a sample of rows; fail loudly on any difference.
+int mdp_rebomos_check_host_list(mdp_ctx *c, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
+                                double cutneigh)
+{
+  if (!c || inum < 0 || !(cutneigh > 0.0)) return MDP_EINVAL;
+  if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (const char *e = getenv("MDP_SKIP_LIST_CHECK"))
+    if (atoi(e) != 0) return MDP_OK;
+  if (inum != c->nlocal) return mdp_fail(c, MDP_EINVAL, "host neighbor list has %d owned rows, expected nlocal = %d", inum, c->nlocal);
+  if (inum == 0) return MDP_OK;
+  if (!ilist || !numneigh || !firstneigh) return mdp_fail(c, MDP_EINVAL, "host neighbor list arrays missing");
+  MDP_HIP(c, hipSetDevice(c->device));
+  unsigned long long host_total = 0;
+  const int stride = inum > 65536 ? inum / 65536 : 1;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    if (i < 0 || i >= c->nlocal) return mdp_fail(c, MDP_EINVAL, "host neighbor list: owned row %d names atom %d", ii, i);
+    host_total += (unsigned long long) numneigh[i];
+    if (ii % stride == 0) {
+      const int *row = firstneigh[i];
+      for (int k = 0; k < numneigh[i]; k++)
+        if (row[k] & ~MDP_NEIGHMASK)
+          return mdp_fail(c, MDP_EINVAL,
+                          "host neighbor list carries special-bond bits (atom %d): the MI355X rebomos style builds its "
+                          "own lists from the positions and cannot honour special_bonds", i);
+    }
+  }
+  hipStream_t st = c->stream;
+  MDP_TRY(mdp_bin_atoms(c, cutneigh, c->bbox_lo, c->bbox_hi));
+  MDP_HIP(c, c->scan_tmp.reserve(64));
+  unsigned long long *d_total = reinterpret_cast<unsigned long long *>(c->scan_tmp.p);
+  MDP_HIP(c, hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+  host_list_count_kernel<<<nblk(c->nall), 256, 0, st>>>(c->grid, cutneigh * cutneigh, c->nall, c->nlocal, c->xq.p,
+                                                        c->cell_perm.p, c->cell_start.p, d_total);
+  MDP_HIP(c, hipGetLastError());
+  unsigned long long dev_total = 0;
+  MDP_HIP(c, hipMemcpyAsync(&dev_total, d_total, sizeof dev_total, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  if (dev_total != host_total)
+    return mdp_fail(c, MDP_EINVAL,
+                    "host neighbor list is not the plain geometric list (%llu entries, %llu pairs within %.6g): exclusions / "
+                    "skip lists are not supported by the MI355X rebomos style, which builds its own lists",
+                    host_total, dev_total, cutneigh);
   return MDP_OK;
 }
 

@@ -129,13 +129,21 @@ __global__ void unpermute_kernel(int n, int w, const int *__restrict__ perm, con
   dst[(size_t) perm[i] * w + q] = src[k];
 }
 
-// start of every compute: energy/virial accumulators (+ their slots), the four flag words, the overflow counter
+// start of every compute: energy/virial accumulators (+ their slots), the four flag words, the overflow counter.
+// flags[0] (overflow bits of the compute just finished) is folded into the STICKY word flags[4] first: force-only
+// steps of a resident run never read the flags, and a truncated neighbour set must still stop the run at the next
+// host read (mdp_flags_check), as "Neighbor list overflow" stops the reference (pair_rebomos.cpp:350).
 __global__ void acc_zero_kernel(double *__restrict__ acc, const int n, int *__restrict__ flags, int *__restrict__ ovf)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) acc[i] = 0.0;
-  if (i < 4) flags[i] = 0;
-  if (i == 0 && ovf) ovf[0] = 0;
+  if (i == 0) {
+    const int f0 = flags[0];
+    if (f0) flags[4] |= f0;
+    flags[0] = 0;
+    if (ovf) ovf[0] = 0;
+  } else if (i < 4)
+    flags[i] = 0;
 }
 
 __global__ void add_f_kernel(int n3, const double *__restrict__ src, double *__restrict__ dst)
@@ -167,6 +175,21 @@ int mdp_acc_begin(mdp_ctx *c, bool any)
   return MDP_OK;
 }
 
+// hflags: 5 words copied from c->flags after the stream was synchronised.  Overflow bits of the last compute
+// (word 0) or of any compute since the last read (sticky word 4) stop the caller; the sticky word is cleared.
+int mdp_flags_check(mdp_ctx *c, const int *hflags)
+{
+  const int bits = hflags[0] | hflags[4];
+  if (!bits) return MDP_OK;
+  (void) hipMemsetAsync(c->flags.p + 4, 0, sizeof(int), c->stream);
+  if (bits & 1)
+    return mdp_fail(c, MDP_EOVERFLOW, "REBO neighbor count exceeds the lane-group capacity (Neighbor list overflow)");
+  if (bits & 2)
+    return mdp_fail(c, MDP_EOVERFLOW, "aeam: an angular atom has more in-range neighbours than the LDS tile holds "
+                                      "(Neighbor list overflow)");
+  return mdp_fail(c, MDP_EOVERFLOW, "Neighbor list overflow (flags %d)", bits);
+}
+
 int mdp_acc_end(mdp_ctx *c, bool any)
 {
   if (any) {
@@ -177,30 +200,81 @@ int mdp_acc_end(mdp_ctx *c, bool any)
 }
 
 // ---- host-mode transfers --------------------------------------------------------------------------------
-// Large host arrays (x, handed over every step) are page-locked in place the first time they are seen, so
-// that the upload is one DMA instead of a bounce through the runtime's staging buffers; results come back
-// into a pinned buffer of the context and are added into the host's array by a few threads.
-static void host_register(mdp_ctx *c, const void *ptr, size_t bytes)
+// The host's x array (handed over every step, 115 MB at 4 M atoms) is NOT page-locked in place by default: the
+// library does not own that memory, LAMMPS re-allocates it whenever nmax grows (memory->grow at migration), and a
+// registration that outlives the allocation leaves stale pinned ranges behind (or, worse, a range HIP still treats
+// as pinned after the address was reused).  Instead the upload goes through two pinned staging buffers owned by
+// the context: a few threads copy chunk k+1 into one while the DMA engine drains chunk k from the other.
+//
+// MDP_HOST_REGISTER=1 opts into in-place registration (one DMA, no staging copy) for hosts that promise to call
+// mdp_host_release(ptr) before they free or re-allocate a registered array; every range is re-validated against
+// the (pointer, size) of the current call and dropped when either changed.
+static void host_unregister_all(mdp_ctx *c)
 {
-  // small systems: not worth a system call; resident mode: the caller's arrays are one-shot temporaries
-  if (c->md || bytes < (8u << 20) || getenv("MDP_NO_HOST_REGISTER")) return;
   for (auto &r : c->host_regs)
-    if (r.first == ptr) {
-      if (r.second >= bytes) return;
-      (void) hipHostUnregister(const_cast<void *>(ptr));
-      r.second = 0;
-    }
+    if (r.second) (void) hipHostUnregister(const_cast<void *>(r.first));
+  c->host_regs.clear();
+  (void) hipGetLastError();
+}
+
+static bool host_register(mdp_ctx *c, const void *ptr, size_t bytes)
+{
+  const char *e = getenv("MDP_HOST_REGISTER");
+  if (!e || atoi(e) == 0 || c->md || bytes < (8u << 20)) return false;
+  for (auto &r : c->host_regs)
+    if (r.first == ptr && r.second == bytes) return true; // same array, same extent as last time
+  host_unregister_all(c); // pointer or extent changed: the old range may be gone already
   if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
-    bool reused = false;
-    for (auto &r : c->host_regs)
-      if (r.first == ptr) {
-        r.second = bytes;
-        reused = true;
-      }
-    if (!reused) c->host_regs.emplace_back(ptr, bytes);
-  } else {
-    (void) hipGetLastError(); // e.g. overlaps a range registered earlier: the plain copy still works
+    c->host_regs.emplace_back(ptr, bytes);
+    return true;
   }
+  (void) hipGetLastError();
+  return false;
+}
+
+static void host_copy_threads(char *dst, const char *src, size_t n)
+{
+  unsigned nt = n > (4u << 20) ? std::thread::hardware_concurrency() : 1;
+  nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+  if (nt == 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t chunk = ((n + nt - 1) / nt + 4095) & ~(size_t) 4095;
+  for (unsigned t = 0; t < nt; t++) {
+    const size_t b = t * chunk, e2 = b + chunk < n ? b + chunk : n;
+    if (b >= e2) break;
+    th.emplace_back([=] { memcpy(dst + b, src + b, e2 - b); });
+  }
+  for (auto &t : th) t.join();
+}
+
+// host array -> device, asynchronously on the context's stream; the host array may be reused on return
+static int host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+{
+  hipStream_t st = c->stream;
+  if (!bytes) return MDP_OK;
+  if (bytes < (1u << 20) || host_register(c, h_src, bytes)) { // small, or page-locked in place on request
+    MDP_HIP(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+    return MDP_OK;
+  }
+  constexpr size_t kChunk = 16u << 20;
+  if (!c->h_up[0]) {
+    for (int k = 0; k < 2; k++) {
+      MDP_HIP(c, hipHostMalloc((void **) &c->h_up[k], kChunk, hipHostMallocDefault));
+      MDP_HIP(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
+    }
+  }
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += kChunk, k ^= 1) {
+    const size_t n = bytes - off < kChunk ? bytes - off : kChunk;
+    if (off >= 2 * kChunk) MDP_HIP(c, hipEventSynchronize(c->ev_up[k])); // the DMA out of this buffer has finished
+    host_copy_threads(c->h_up[k], (const char *) h_src + off, n);
+    MDP_HIP(c, hipMemcpyAsync((char *) d_dst + off, c->h_up[k], n, hipMemcpyHostToDevice, st));
+    MDP_HIP(c, hipEventRecord(c->ev_up[k], st));
+  }
+  return MDP_OK;
 }
 
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles)
@@ -332,7 +406,8 @@ int mdp_create(mdp_ctx **out, int device)
   }
   c->own_stream = true;
   if (c->acc.reserve((size_t) MDP_ACC_STRIDE * (2 + MDP_ACC_SLOTS)) != hipSuccess || c->flags.reserve(8) != hipSuccess ||
-      hipHostMalloc((void **) &c->h_pinned, 64 * sizeof(double)) != hipSuccess) {
+      hipHostMalloc((void **) &c->h_pinned, 64 * sizeof(double)) != hipSuccess ||
+      hipMemset(c->flags.p, 0, 8 * sizeof(int)) != hipSuccess) {
     mdp_destroy(c);
     return MDP_ENOMEM;
   }
@@ -392,9 +467,13 @@ int mdp_destroy(mdp_ctx *c)
   c->rev16.release();
   c->host_perm.release();
   c->host_stage.release();
-  for (auto &r : c->host_regs)
-    if (r.second) (void) hipHostUnregister(const_cast<void *>(r.first));
-  c->host_regs.clear();
+  host_unregister_all(c);
+  for (int k = 0; k < 2; k++) {
+    if (c->h_up[k]) (void) hipHostFree(c->h_up[k]);
+    if (c->ev_up[k]) (void) hipEventDestroy(c->ev_up[k]);
+    c->h_up[k] = nullptr;
+    c->ev_up[k] = nullptr;
+  }
   if (c->h_down) (void) hipHostFree(c->h_down);
   c->h_down = nullptr;
   c->fnbr.release();
@@ -438,6 +517,25 @@ int mdp_set_stream(mdp_ctx *c, void *s)
   }
   c->stream = (hipStream_t) s;
   c->own_stream = false;
+  return MDP_OK;
+}
+
+double mdp_device_bytes(const mdp_ctx *c)
+{
+  (void) c;
+  return (double) mdp_device_bytes_counter();
+}
+
+int mdp_host_release(mdp_ctx *c, const void *ptr)
+{
+  if (!c) return MDP_EINVAL;
+  for (size_t k = 0; k < c->host_regs.size(); k++)
+    if (!ptr || c->host_regs[k].first == ptr) {
+      if (c->host_regs[k].second) (void) hipHostUnregister(const_cast<void *>(c->host_regs[k].first));
+      c->host_regs.erase(c->host_regs.begin() + k);
+      k--;
+    }
+  (void) hipGetLastError();
   return MDP_OK;
 }
 
@@ -488,10 +586,12 @@ int mdp_rebomos_set_params(mdp_ctx *c, const mdp_rebomos_params *p)
 int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, const int *type, const int *tag,
                        int ntypes, const int *map)
 {
-  if (!c || nlocal < 0 || nghost < 0 || !x || !type || ntypes < 1 || ntypes > 15)
+  if (!c || nlocal < 0 || nghost < 0 || ntypes < 1 || ntypes > 15)
     return mdp_fail(c, MDP_EINVAL, "mdp_set_atoms_host: bad arguments");
-  MDP_HIP(c, hipSetDevice(c->device));
   const int nall = nlocal + nghost;
+  // an empty sub-domain (slab / vacuum runs) hands over no arrays at all: atom->x may be NULL when nmax == 0
+  if (nall > 0 && (!x || !type)) return mdp_fail(c, MDP_EINVAL, "mdp_set_atoms_host: x / type missing for %d atoms", nall);
+  MDP_HIP(c, hipSetDevice(c->device));
   if ((long long) nall >= (1ll << 29)) return mdp_fail(c, MDP_EINVAL, "too many atoms for NEIGHMASK");
   c->nlocal = nlocal;
   c->nghost = nghost;
@@ -506,11 +606,12 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
   MDP_HIP(c, c->f.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, c->eatom.reserve(nall + 1));
   hipStream_t st = c->stream;
-  host_register(c, x, sizeof(double) * 3 * nall);
-  MDP_HIP(c, hipMemcpyAsync(c->xraw.p, x, sizeof(double) * 3 * nall, hipMemcpyHostToDevice, st));
-  MDP_HIP(c, hipMemcpyAsync(c->type.p, type, sizeof(int) * nall, hipMemcpyHostToDevice, st));
+  if (nall) {
+    MDP_TRY(host_upload(c, c->xraw.p, x, sizeof(double) * 3 * nall));
+    MDP_HIP(c, hipMemcpyAsync(c->type.p, type, sizeof(int) * nall, hipMemcpyHostToDevice, st));
+  }
   MDP_HIP(c, hipMemcpyAsync(c->type.p + nall, c->map, sizeof(int) * 16, hipMemcpyHostToDevice, st));
-  if (tag) MDP_HIP(c, hipMemcpyAsync(c->tag.p, tag, sizeof(int) * nall, hipMemcpyHostToDevice, st));
+  if (tag && nall) MDP_HIP(c, hipMemcpyAsync(c->tag.p, tag, sizeof(int) * nall, hipMemcpyHostToDevice, st));
   c->atoms_set = true;
   if (!c->md) { // host mode: bounding box for the device binning, padded so that motion inside the skin stays inside
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -535,11 +636,12 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
 
 int mdp_set_positions_host(mdp_ctx *c, const double *x)
 {
-  if (!c || !x) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (c->nall == 0) return MDP_OK; // empty sub-domain: nothing to move (x may be NULL)
+  if (!x) return mdp_fail(c, MDP_EINVAL, "mdp_set_positions_host: x missing for %d atoms", c->nall);
   MDP_HIP(c, hipSetDevice(c->device));
-  host_register(c, x, sizeof(double) * 3 * c->nall);
-  MDP_HIP(c, hipMemcpyAsync(c->xraw.p, x, sizeof(double) * 3 * c->nall, hipMemcpyHostToDevice, c->stream));
+  MDP_TRY(host_upload(c, c->xraw.p, x, sizeof(double) * 3 * c->nall));
   MDP_TRY(mdp_pack_xq(c, c->xraw.p, nullptr));
   MDP_HIP(c, hipStreamSynchronize(c->stream));
   return MDP_OK;
@@ -567,7 +669,9 @@ static int upload_csr(mdp_ctx *c, double skin)
 int mdp_set_neighbors_host(mdp_ctx *c, int inum, int gnum, const int *ilist, const int *numneigh,
                            int *const *firstneigh, double skin)
 {
-  if (!c || inum < 0 || gnum < 0 || !ilist || !numneigh || !firstneigh) return MDP_EINVAL;
+  if (!c || inum < 0 || gnum < 0) return MDP_EINVAL;
+  if (inum + gnum > 0 && (!ilist || !numneigh || !firstneigh))
+    return mdp_fail(c, MDP_EINVAL, "mdp_set_neighbors_host: list arrays missing for %d rows", inum + gnum);
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
   if (inum != c->nlocal) return mdp_fail(c, MDP_EINVAL, "inum (%d) != nlocal (%d)", inum, c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
@@ -631,10 +735,9 @@ static int fetch_acc(mdp_ctx *c, double *eng, double *virial)
   hipStream_t st = c->stream;
   MDP_HIP(c, hipMemcpyAsync(c->h_pinned, c->acc.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
   int *hflags = (int *) (c->h_pinned + 16);
-  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 5, hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
-  if (hflags[0] & 1)
-    return mdp_fail(c, MDP_EOVERFLOW, "REBO neighbor count exceeds the lane-group capacity (Neighbor list overflow)");
+  MDP_TRY(mdp_flags_check(c, hflags));
   c->last_eng = c->h_pinned[0];
   for (int k = 0; k < 6; k++) c->last_virial[k] = c->h_pinned[1 + k];
   if (eng) *eng += c->h_pinned[0];
@@ -646,9 +749,15 @@ static int fetch_acc(mdp_ctx *c, double *eng, double *virial)
 int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double *eng_vdwl, double *virial,
                              double *eatom, double *vatom)
 {
-  if (!c || !f) return MDP_EINVAL;
+  if (!c) return MDP_EINVAL;
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (c->nlocal == 0) { // a rank without owned atoms contributes nothing (f may be NULL); the reference loops over zero atoms
+    c->last_eng = 0.0;
+    for (int k = 0; k < 6; k++) c->last_virial[k] = 0.0;
+    return MDP_OK;
+  }
+  if (!f) return mdp_fail(c, MDP_EINVAL, "mdp_rebomos_compute_host: f missing for %d owned atoms", c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;

@@ -22,6 +22,13 @@
 // REBO centre classes: lane-group size (4, 8, 12, 16, 32) x element
 #define MDP_NCLASS 10
 
+// bytes of device memory currently held by the library's buffers in this process (memory_usage(), pair_rebomos.cpp:1113-1124)
+inline long long &mdp_device_bytes_counter()
+{
+  static long long bytes = 0;
+  return bytes;
+}
+
 // device buffer that only grows
 template <typename T> struct DevBuf {
   T *p = nullptr;
@@ -40,6 +47,7 @@ template <typename T> struct DevBuf {
       if (e != hipSuccess) return e;
     }
     if (p) (void) hipFree(p);
+    mdp_device_bytes_counter() += (long long) ((ncap - cap) * sizeof(T));
     p = q;
     cap = ncap;
     return hipSuccess;
@@ -47,6 +55,7 @@ template <typename T> struct DevBuf {
   void release()
   {
     if (p) (void) hipFree(p);
+    mdp_device_bytes_counter() -= (long long) (cap * sizeof(T));
     p = nullptr;
     cap = 0;
   }
@@ -114,6 +123,8 @@ struct mdp_ctx {
   DevBuf<int> host_perm;
   DevBuf<double> host_stage;    // per-atom results back in host order before the download
   std::vector<std::pair<const void *, size_t>> host_regs; // host arrays page-locked in place (large x arrays)
+  char *h_up[2] = {nullptr, nullptr};          // pinned upload staging (double-buffered chunks)
+  hipEvent_t ev_up[2] = {nullptr, nullptr};
   double *h_down = nullptr;     // pinned download buffer
   size_t h_down_cap = 0;
   DevBuf<int> tag, type;
@@ -256,3 +267,4 @@ int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned d
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]
+int mdp_flags_check(mdp_ctx *c, const int *hflags5); // overflow bits (last compute | sticky) -> MDP_EOVERFLOW

@@ -258,29 +258,39 @@ int mdp_aeam_file_info(const mdp_aeam_file *F, int *nelements, int *nnonangular,
   return MDP_OK;
 }
 
-// interpolate, pair_aeam.cpp:915-942 (rows 1..n, row 0 unused)
-static void interpolate(int n, double delta, const double *f, double *spline)
+// One tabulated function y[1..n] on a uniform grid of spacing h -> n spline rows of 7 doubles,
+//   row[6] = value, row[5] = knot slope (per grid step), row[4], row[3] = quadratic / cubic Hermite terms of the
+//   interval [m, m+1], row[2..0] = the derivative polynomial per unit of the abscissa.
+// Same numbers, coefficient by coefficient, as PairAEAM::interpolate (pair_aeam.cpp:915-942) -- the operand order
+// inside each expression is part of the parity contract -- produced here in one sweep over the knots.
+static void spline_rows(int n, double h, const double *y, double *rows)
 {
-#define S(m, c) spline[(size_t) (m) *7 + (c)]
-  for (int m = 1; m <= n; m++) S(m, 6) = f[m];
-  S(1, 5) = S(2, 6) - S(1, 6);
-  S(2, 5) = 0.5 * (S(3, 6) - S(1, 6));
-  S(n - 1, 5) = 0.5 * (S(n, 6) - S(n - 2, 6));
-  S(n, 5) = S(n, 6) - S(n - 1, 6);
-  for (int m = 3; m <= n - 2; m++)
-    S(m, 5) = ((S(m - 2, 6) - S(m + 2, 6)) + 8.0 * (S(m + 1, 6) - S(m - 1, 6))) / 12.0;
-  for (int m = 1; m <= n - 1; m++) {
-    S(m, 4) = 3.0 * (S(m + 1, 6) - S(m, 6)) - 2.0 * S(m, 5) - S(m + 1, 5);
-    S(m, 3) = S(m, 5) + S(m + 1, 5) - 2.0 * (S(m + 1, 6) - S(m, 6));
-  }
-  S(n, 4) = 0.0;
-  S(n, 3) = 0.0;
+  // five-point slope inside, centred difference next to the ends, one-sided difference at the ends
+  const auto knot_slope = [n, y](int m) -> double {
+    if (m == 1) return y[2] - y[1];
+    if (m == n) return y[n] - y[n - 1];
+    if (m == 2 || m == n - 1) return 0.5 * (y[m + 1] - y[m - 1]);
+    return ((y[m - 2] - y[m + 2]) + 8.0 * (y[m + 1] - y[m - 1])) / 12.0;
+  };
+  double s_here = knot_slope(1);
   for (int m = 1; m <= n; m++) {
-    S(m, 2) = S(m, 5) / delta;
-    S(m, 1) = 2.0 * S(m, 4) / delta;
-    S(m, 0) = 3.0 * S(m, 3) / delta;
+    double *row = rows + (size_t) 7 * m;
+    double quad = 0.0, cubic = 0.0, s_next = 0.0;
+    if (m < n) { // the last row has no interval to its right
+      s_next = knot_slope(m + 1);
+      const double rise = y[m + 1] - y[m];
+      quad = 3.0 * rise - 2.0 * s_here - s_next;
+      cubic = s_here + s_next - 2.0 * rise;
+    }
+    row[6] = y[m];
+    row[5] = s_here;
+    row[4] = quad;
+    row[3] = cubic;
+    row[2] = s_here / h;
+    row[1] = 2.0 * quad / h;
+    row[0] = 3.0 * cubic / h;
+    s_here = s_next;
   }
-#undef S
 }
 
 // file2array + array2spline for `ntypes` atom types, map[1..ntypes] = element index or -1 (NULL)
@@ -296,23 +306,23 @@ int mdp_aeam_file_build(mdp_aeam_file *F, int ntypes, const int *map, mdp_aeam_t
   F->type2frho.assign(ntypes + 1, 0);
   F->type2rhor.assign((size_t) (ntypes + 1) * (ntypes + 1), 0);
   F->type2z2r.assign((size_t) (ntypes + 1) * (ntypes + 1), 0);
-  int mapp = 0;
-  for (int i = 1; i <= ntypes; i++) {
-    F->type2frho[i] = map[i] >= 0 ? map[i] : F->nfrho - 1; // :785-790
-    for (int j = 1; j <= ntypes; j++) {
-      F->type2rhor[(size_t) i * (ntypes + 1) + j] = mapp++; // :816-821 (as written: stride ntypes)
-      int irow = map[i], icol = map[j];
-      if (irow == -1 || icol == -1) {
-        F->type2z2r[(size_t) i * (ntypes + 1) + j] = 0; // :858-861
-        continue;
+  const size_t ts = (size_t) ntypes + 1; // row stride of the 1-based type-pair maps
+  for (int ti = 1; ti <= ntypes; ti++) {
+    const int ei = map[ti];
+    F->type2frho[ti] = ei >= 0 ? ei : F->nfrho - 1; // NULL types use the all-zero table (pair_aeam.cpp:785-790)
+    for (int tj = 1; tj <= ntypes; tj++) {
+      const int ej = map[tj];
+      // rho(r) tables are numbered by TYPE pair with stride ntypes, exactly as the reference numbers them
+      // (pair_aeam.cpp:816-821) -- not by element pair
+      F->type2rhor[ti * ts + tj] = (ti - 1) * ntypes + (tj - 1);
+      // phi(r) tables are stored for element pairs hi >= lo in packed lower-triangular order (:858-869);
+      // a pair with a NULL partner points at table 0 and is never evaluated
+      int tri = 0;
+      if (ei >= 0 && ej >= 0) {
+        const int hi = ei > ej ? ei : ej, lo = ei > ej ? ej : ei;
+        tri = hi * (hi + 1) / 2 + lo;
       }
-      if (irow < icol) {
-        irow = map[j];
-        icol = map[i];
-      }
-      int n = 0;
-      for (int m = 0; m < irow; m++) n += m + 1;
-      F->type2z2r[(size_t) i * (ntypes + 1) + j] = n + icol; // :862-869
+      F->type2z2r[ti * ts + tj] = tri;
     }
   }
   F->frho_spline.assign(fs * 7 * F->nfrho, 0.0);
@@ -321,14 +331,14 @@ int mdp_aeam_file_build(mdp_aeam_file *F, int ntypes, const int *map, mdp_aeam_t
   std::vector<double> zero(fs, 0.0);
   for (int i = 0; i < F->nfrho; i++) { // :889-898
     const bool last = i == F->nfrho - 1;
-    interpolate(last ? F->nrho[0] : F->nrho[i], last ? F->drho[0] : F->drho[i],
+    spline_rows(last ? F->nrho[0] : F->nrho[i], last ? F->drho[0] : F->drho[i],
                 last ? zero.data() : &F->frho_raw[fs * i], &F->frho_spline[fs * 7 * i]);
   }
-  for (int k = 0; k < F->nrhor; k++) interpolate(F->nr[k], F->dr[k], &F->rhor_raw[rs * k], &F->rhor_spline[rs * 7 * k]);
+  for (int k = 0; k < F->nrhor; k++) spline_rows(F->nr[k], F->dr[k], &F->rhor_raw[rs * k], &F->rhor_spline[rs * 7 * k]);
   int n = 0;
   for (int i = 0; i < ne; i++)
     for (int j = 0; j <= i; j++, n++)
-      interpolate(F->nr[i * ne + j], F->dr[i * ne + j], &F->z2r_raw[rs * n], &F->z2r_spline[rs * 7 * n]);
+      spline_rows(F->nr[i * ne + j], F->dr[i * ne + j], &F->z2r_raw[rs * n], &F->z2r_spline[rs * 7 * n]);
   out->ntypes = ntypes;
   out->nelements = ne;
   out->nnonangular = F->nnonangular;

@@ -50,6 +50,7 @@ EXPORTS = [
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
     "mdp_md_neighbor_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
+    "mdp_device_bytes", "mdp_host_release", "mdp_rebomos_check_host_list",
 ]
 
 
@@ -71,6 +72,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.mdp_last_error.restype = C.c_char_p
         _lib.mdp_md_ptr.restype = C.c_void_p
+        _lib.mdp_device_bytes.restype = C.c_double
     return _lib
 
 
@@ -213,6 +215,19 @@ class Context:
 
     def set_skin(self, skin):
         self._ck(self.L.mdp_set_skin(self.h, C.c_double(skin)))
+
+    def device_bytes(self) -> float:
+        return float(self.L.mdp_device_bytes(self.h))
+
+    def rebomos_check_host_list(self, ilist, numneigh, rows, cutneigh):
+        """rows: list of int32 arrays, one per atom index (the LAMMPS firstneigh[] shape)"""
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        ptrs = (C.POINTER(C.c_int) * len(rows))()
+        for i, r in enumerate(rows):
+            ptrs[i] = r.ctypes.data_as(C.POINTER(C.c_int))
+        self._ck(self.L.mdp_rebomos_check_host_list(self.h, C.c_int(len(ilist)), _ip(ilist), _ip(numneigh), ptrs,
+                                                    C.c_double(cutneigh)))
 
     def set_neighbors_paged_host(self, inum, gnum, ilist, numneigh, rows, skin):
         """rows: list of int32 arrays (one per atom index) -- exercises the LAMMPS int** path"""

@@ -211,7 +211,7 @@ void PairAEAM::compute(int eflag, int vflag)
     if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
     nall_uploaded = nall;
   } else {
-    rc = mdp_set_positions_host(dev, atom->x[0]);
+    rc = mdp_set_positions_host(dev, nall ? atom->x[0] : nullptr);
     if (rc != MDP_OK) fail_one(rc, "position upload");
   }
 
@@ -266,5 +266,6 @@ double PairAEAM::memory_usage()
   double bytes = (double) maxeatom * sizeof(double);
   bytes += (double) maxvatom * 6 * sizeof(double);
   bytes += 2.0 * nmax * sizeof(double);
+  if (dev) bytes += mdp_device_bytes(dev); // repacked list, spline tables and work arrays held on the GPU
   return bytes;
 }

@@ -184,9 +184,14 @@ void PairREBOMoS::compute(int eflag, int vflag)
     if (list->inum != nlocal) error->one(FLERR, "Pair style rebomos (MI355X): neighbor list does not match nlocal");
     rc = mdp_set_skin(dev, neighbor->skin);
     if (rc != MDP_OK) fail_one(rc, "skin upload");
+    // ... which is only the reference's result when the host's list is the plain geometric one: the reference
+    // walks the host's entries (pair_rebomos.cpp:328-330, 490-495), so exclusions or special bonds must stop the run
+    rc = mdp_rebomos_check_host_list(dev, list->inum, list->ilist, list->numneigh, list->firstneigh,
+                                     cut3rebo + neighbor->skin);
+    if (rc != MDP_OK) fail_one(rc, "neighbor list check");
     nall_uploaded = nall;
   } else {
-    rc = mdp_set_positions_host(dev, atom->x[0]);
+    rc = mdp_set_positions_host(dev, nall ? atom->x[0] : nullptr);
     if (rc != MDP_OK) fail_one(rc, "position upload");
   }
 
@@ -199,8 +204,10 @@ void PairREBOMoS::compute(int eflag, int vflag)
 
 double PairREBOMoS::memory_usage()
 {
-  // host side holds nothing per atom; report the staging copies the C-ABI layer keeps on the host
-  double bytes = 0.0;
+  // the reference reports the REBO lists it holds (pair_rebomos.cpp:1113-1124); here they live on the device:
+  // candidate / tile lists, slot forces, staging of x and f -- plus the pinned host staging of one x and one f array
+  device_bytes = dev ? mdp_device_bytes(dev) : 0.0;
+  double bytes = device_bytes;
   bytes += (double) (atom->nlocal + atom->nghost) * (3 * sizeof(double) + sizeof(int));
   return bytes;
 }

@@ -130,5 +130,5 @@ def test_plans_are_consistent_for_1_2_4_8_ranks():
             assert len(plans[0].ghost_global) == 4285        # log.rebomos-bulk.1:74
         if n == 4:
             assert [len(p.owned) for p in plans] == [72] * 4  # log.rebomos-bulk.4:72
-            for p in plans:
-                assert 2768 - 40 <= len(p.ghost_global) <= 2775 + 40   # log.rebomos-bulk.4:74 (2768-2775)
+            # log.rebomos-bulk.4:74-75: "Nghost: 2771.5 ave 2775 max 2768 min", histogram 2 | 2
+            assert sorted(len(p.ghost_global) for p in plans) == [2768, 2768, 2775, 2775]
