@@ -219,6 +219,7 @@ int mdp_md_aeam_force(mdp_ctx *ctx, int eflag, int vflag);
 int mdp_md_thermo(mdp_ctx *ctx, double out[9]);
 int mdp_md_download(mdp_ctx *ctx, double *x, double *v, double *f, double *eatom); /* owned atoms; NULLs skipped */
 int mdp_md_upload_x(mdp_ctx *ctx, const double *x);                             /* owned atoms [nlocal][3] */
+int mdp_md_download_x_all(mdp_ctx *ctx, double *x_all); /* owned atoms then ghosts, [nlocal+nghost][3] (diagnostics) */
 /* device pointers of resident arrays for zero-copy plumbing (name: "x","v","f","fp","eatom") */
 void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
 /* statistics of the last neighbor build: out[0]=total master entries (owned; 0 if not built),
@@ -231,6 +232,53 @@ int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
  * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,
  * [7]=style-list builds so far.  (No reference counterpart: the CPU style reads the host's list.) */
 int mdp_rebomos_list_info(mdp_ctx *ctx, long long out[8]);
+
+/* ---- resident mode, domain decomposition on the device ----------------------------------------------------------
+ * What the reference gets from the LAMMPS host at every reneighboring -- Domain::remap, Comm::exchange,
+ * Comm::borders (the REQ_GHOST list of pair_rebomos.cpp:218 presupposes them; processor grid of
+ * log.rebomos-bulk.4:22) -- done per rank on the GPU: one brick of the periodic (triclinic) box per context.
+ * The library packs and unpacks DEVICE buffers; the caller moves the bytes between ranks (RCCL all-to-all) and sees
+ * only per-rank counts.  Sequence at a reneighboring (every rank, same step):
+ *     mdp_dd_migrate_begin  -> counts of atoms leaving for each rank        [exchange counts]
+ *     mdp_dd_migrate_pack   -> 8 doubles per leaver, rank-major             [exchange records]
+ *     mdp_dd_migrate_end    <- arrivals; owned atoms re-ordered along a Hilbert curve over the brick
+ *     mdp_dd_borders_begin  -> counts of ghost entries for each rank        [exchange counts]
+ *     mdp_dd_borders_pack   -> 6 doubles per entry, rank-major              [exchange records]
+ *     mdp_dd_borders_end    <- remote ghosts; then mdp_md_build_neighbors
+ * and per step mdp_dd_forward_pack / _unpack (3 doubles per send-list entry).  A one-rank run needs no transport:
+ * mdp_dd_reneighbor does the whole sequence.  All three dimensions are periodic (as in both bundled inputs). */
+typedef struct {
+  double boxlo[3];
+  double h[6];        /* xprd, yprd, zprd, yz, xz, xy  (LAMMPS Domain::h) */
+  int procgrid[3];    /* bricks per dimension; rank = (ix*py + iy)*pz + iz */
+  int rank;
+  double cutghost;    /* ghost-shell width: the host's list cutoff, pair cutoff + skin (log.rebomos-bulk.1:43) */
+} mdp_dd_config;
+
+int mdp_dd_setup(mdp_ctx *ctx, const mdp_dd_config *cfg); /* after mdp_md_setup (owned atoms in any order, ghosts optional) */
+int mdp_dd_reneighbor(mdp_ctx *ctx);                       /* one-rank runs: remap, order, self-image ghosts, lists */
+int mdp_dd_migrate_begin(mdp_ctx *ctx, int *send_counts /* [nranks] */);
+int mdp_dd_migrate_pack(mdp_ctx *ctx, double *d_buf);
+int mdp_dd_migrate_end(mdp_ctx *ctx, int narrive, const double *d_buf);
+int mdp_dd_borders_begin(mdp_ctx *ctx, int *send_counts /* [nranks] */);
+int mdp_dd_borders_pack(mdp_ctx *ctx, double *d_buf);
+int mdp_dd_borders_end(mdp_ctx *ctx, const int *recv_counts /* [nranks] */, const double *d_buf);
+/* out[0]=nlocal [1]=periodic self-image ghosts [2]=send-list entries [3]=remote ghosts [4]=reneighborings so far
+ * [5]=atoms that left at the last one [6]=nranks [7]=rank; per-rank counts of the per-step halo (may be NULL) */
+int mdp_dd_info(mdp_ctx *ctx, long long out[8], int *send_counts, int *recv_counts);
+int mdp_dd_forward_pack(mdp_ctx *ctx, double *d_buf);          /* x of the send list (+ image shift) */
+int mdp_dd_forward_unpack(mdp_ctx *ctx, const double *d_buf);  /* -> remote ghosts */
+int mdp_dd_forward_scalar_pack(mdp_ctx *ctx, double *d_buf);   /* AEAM fp (pair_aeam.cpp:307, 946-963) */
+int mdp_dd_forward_scalar_unpack(mdp_ctx *ctx, const double *d_buf);
+int mdp_dd_reverse_pack(mdp_ctx *ctx, double *d_buf);          /* forces on remote ghosts (AEAM angular terms) */
+int mdp_dd_reverse_unpack(mdp_ctx *ctx, const double *d_buf);  /* += onto the send-list atoms */
+/* `neigh_modify every 1 delay 0 check yes` (sample.in:17-18, log.rebomos-bulk.1:46) without a host round trip per
+ * step: *moved = outcome of the check launched by the PREVIOUS call (0 right after a reneighboring), then a check of
+ * the current positions is launched.  Trigger: an owned atom moved more than skin/2 - 0.1 A since the last build
+ * (the margin covers the step the answer is late by); *dangerous = an atom was beyond skin/2 itself. */
+int mdp_md_moved_async(mdp_ctx *ctx, int *moved, int *dangerous);
+/* owned atoms' "tag" / "type" in device order (the device re-orders atoms at every reneighboring) */
+int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):
  * rebomos: [0]=REBO centre kernels, [1]=LJ+gather kernel; aeam: [0]=density, [1]=embed, [2]=force.

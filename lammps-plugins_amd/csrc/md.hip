@@ -478,6 +478,7 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
   MDP_HIP(c, c->ghost_shift.reserve((size_t) 3 * nghost + 3));
   MDP_HIP(c, c->rho.reserve(nall + 1));
   MDP_HIP(c, c->fp.reserve(nall + 1));
+  for (int t = 0; t < 16; t++) c->h_mass[t] = t <= cfg->ntypes ? mass[t] : 0.0; // migrated atoms look their mass up
   std::vector<double> rm(nlocal);
   for (int i = 0; i < nlocal; i++) {
     if (type[i] < 1 || type[i] > cfg->ntypes) return mdp_fail(c, MDP_EINVAL, "atom type out of range");
@@ -501,7 +502,11 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
   return MDP_OK;
 }
 
-int mdp_md_build_neighbors(mdp_ctx *c)
+int mdp_md_build_neighbors(mdp_ctx *c) { return mdp_md_build_neighbors_impl(c); }
+
+} // extern "C"
+
+int mdp_md_build_neighbors_impl(mdp_ctx *c)
 {
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
@@ -521,6 +526,8 @@ int mdp_md_build_neighbors(mdp_ctx *c)
   }
   return mdp_aeam_prepare(c);
 }
+
+extern "C" {
 
 int mdp_md_initial_integrate(mdp_ctx *c)
 {
@@ -644,6 +651,21 @@ int mdp_md_download(mdp_ctx *c, double *x, double *v, double *f, double *eatom)
   if (v && n) MDP_HIP(c, hipMemcpyAsync(v, c->v.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
   if (f && n) MDP_HIP(c, hipMemcpyAsync(f, c->f.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
   if (eatom && n) MDP_HIP(c, hipMemcpyAsync(eatom, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  return MDP_OK;
+}
+
+int mdp_md_download_x_all(mdp_ctx *c, double *x_all)
+{
+  if (!c || !x_all) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  hipStream_t st = c->stream;
+  const int n = c->nall;
+  if (n) {
+    MDP_HIP(c, c->xraw.reserve((size_t) 3 * n + 3));
+    xq_to_x3_kernel<<<nblk(n), 256, 0, st>>>(n, c->xq.p, c->xraw.p);
+    MDP_HIP(c, hipMemcpyAsync(x_all, c->xraw.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  }
   MDP_HIP(c, hipStreamSynchronize(st));
   return MDP_OK;
 }

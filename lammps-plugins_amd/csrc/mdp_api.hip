@@ -70,32 +70,7 @@ __global__ void hilbert_key_kernel(const int nall, const int nlocal, const doubl
     g = g < 0 ? 0 : (g > (1 << B) - 1 ? (1 << B) - 1 : g);
     X[d] = (unsigned) g;
   }
-  // Skilling, "Programming the Hilbert curve": axes -> transposed index
-  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1) {
-    const unsigned P = Q - 1;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      if (X[d] & Q)
-        X[0] ^= P;
-      else {
-        const unsigned t = (X[0] ^ X[d]) & P;
-        X[0] ^= t;
-        X[d] ^= t;
-      }
-    }
-  }
-  X[1] ^= X[0];
-  X[2] ^= X[1];
-  unsigned t = 0;
-  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1)
-    if (X[2] & Q) t ^= Q - 1;
-  X[0] ^= t;
-  X[1] ^= t;
-  X[2] ^= t;
-  unsigned key = 0;
-  for (int b = B - 1; b >= 0; b--)
-#pragma unroll
-    for (int d = 0; d < 3; d++) key = (key << 1) | ((X[d] >> b) & 1u);
+  unsigned key = mdp_hilbert30(X[0], X[1], X[2]);
   if (i >= nlocal) key |= 1u << 30; // ghosts stay behind the owned atoms
   keys[i] = key;
   idx[i] = i;

@@ -97,6 +97,68 @@ struct AeamDev {
   const double4 *pair_d8; // [ntypes*ntypes][nrmax+1][2]: {rho' c0..c2,0 | phi' c0..c2,0} of the pair type, 64 B per row
 };
 
+// 30-bit key of a cell (10 bits per axis) along a 3-D Hilbert curve (Skilling, "Programming the Hilbert curve":
+// axes -> transposed index).  A Hilbert curve has no jumps: any run of consecutive keys is a compact blob, which
+// is what bounds the neighbour unions of the tile lists.
+__device__ __forceinline__ unsigned mdp_hilbert30(unsigned x0, unsigned x1, unsigned x2)
+{
+  constexpr int B = 10;
+  unsigned X[3] = {x0, x1, x2};
+  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1) {
+    const unsigned P = Q - 1;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (X[d] & Q)
+        X[0] ^= P;
+      else {
+        const unsigned t = (X[0] ^ X[d]) & P;
+        X[0] ^= t;
+        X[d] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0;
+  for (unsigned Q = 1u << (B - 1); Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t;
+  X[1] ^= t;
+  X[2] ^= t;
+  unsigned key = 0;
+  for (int b = B - 1; b >= 0; b--)
+#pragma unroll
+    for (int d = 0; d < 3; d++) key = (key << 1) | ((X[d] >> b) & 1u);
+  return key;
+}
+
+// ---- brick domain decomposition (domain.hip): geometry as the kernels see it
+struct DdGeom {
+  double lo[3];
+  double h[6], hinv[6]; // LAMMPS Domain::h order: xprd, yprd, zprd, yz, xz, xy
+  int g[3];             // bricks per dimension
+  int me[3], rank, nranks;
+  double cutl[3];       // ghost-shell width in lamda (fractional) units
+  int ns[3];            // periodic image shifts tested per dimension: -ns .. ns
+};
+
+struct MdpDomain {
+  bool on = false;
+  DdGeom G;
+  double cutghost = 0.0;
+  std::vector<int> mig_send, bord_send, bord_recv; // per rank
+  int mig_total = 0, nself = 0, nsend = 0, nrecv = 0, nent = 0;
+  int nlocal_old = 0, nghost_old = 0;
+  long long reneighbors = 0;
+  DevBuf<int> dest, counters, idx_a, idx_b, ent_atom, ent_code, ent_cnt, ent_off, sendlist, type_tmp, tag_tmp;
+  DevBuf<unsigned long long> key_a, key_b;
+  DevBuf<double> sendshift, v_tmp;
+  DevBuf<double4> xq_tmp;
+  // deferred displacement trigger of the host-level skin (neigh_modify check yes)
+  hipEvent_t ev_moved = nullptr;
+  bool moved_pending = false;
+};
+
 struct mdp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -217,7 +279,9 @@ struct mdp_ctx {
   DevBuf<double> rmass;      // [nlocal]
   DevBuf<int> ghost_owner;   // [nghost]
   DevBuf<double> ghost_shift;// [nghost][3]
-  DevBuf<double> mass_type;
+  DevBuf<double> mass_type;  // [ntypes+1] per-type masses on the device (rmass of migrated atoms)
+  double h_mass[16] = {};
+  MdpDomain dd;
   // binning scratch
   DevBuf<int> cell_of, cell_perm, cell_start;
   DevBuf<unsigned> sort_keys_a, sort_keys_b;
@@ -261,6 +325,7 @@ int mdp_aeam_prepare(mdp_ctx *c);
 int mdp_aeam_run_density(mdp_ctx *c, int eflag);
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
+int mdp_md_build_neighbors_impl(mdp_ctx *c);
 int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)

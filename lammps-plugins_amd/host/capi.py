@@ -39,6 +39,12 @@ class MdConfig(C.Structure):
                 ("master_list", C.c_int)]
 
 
+class DdConfig(C.Structure):
+    """mirror of mdp_dd_config"""
+    _fields_ = [("boxlo", C.c_double * 3), ("h", C.c_double * 6), ("procgrid", C.c_int * 3), ("rank", C.c_int),
+                ("cutghost", C.c_double)]
+
+
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
 EXPORTS = [
     "mdp_abi_version", "mdp_device_count", "mdp_create", "mdp_destroy", "mdp_last_error", "mdp_set_stream",
@@ -51,6 +57,10 @@ EXPORTS = [
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
     "mdp_md_neighbor_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
     "mdp_device_bytes", "mdp_host_release", "mdp_rebomos_check_host_list",
+    "mdp_dd_setup", "mdp_dd_reneighbor", "mdp_dd_migrate_begin", "mdp_dd_migrate_pack", "mdp_dd_migrate_end",
+    "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
+    "mdp_dd_forward_unpack", "mdp_dd_forward_scalar_pack", "mdp_dd_forward_scalar_unpack", "mdp_dd_reverse_pack",
+    "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_download_int", "mdp_md_download_x_all",
 ]
 
 
@@ -69,6 +79,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} not built: run `python __graft_entry__.py` (make -C lammps-plugins_amd)")
+        try:
+            # ONE HIP runtime per process: torch ships its own libamdhip64 under the same soname.  Whichever copy is
+            # loaded first serves both; loaded after ours, torch finds "No HIP GPUs".  So torch goes first.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mdp_last_error.restype = C.c_char_p
         _lib.mdp_md_ptr.restype = C.c_void_p
@@ -145,11 +161,31 @@ def rebomos_params_from_oracle(P) -> RebomosParams:
     return out
 
 
+class _SerialLib:
+    """the library behind one process-wide lock: used when several ranks run as threads of one process
+    (resident.run_ranks); RCCL runs have one process per GPU and call the library directly"""
+    import threading as _threading
+    lock = _threading.RLock()
+
+    def __init__(self, L):
+        self._L = L
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+        lock = self.lock
+
+        def call(*a):
+            with lock:
+                return fn(*a)
+        return call
+
+
 class Context:
     """one mdp_ctx (one GPU sub-domain)"""
+    serialize = False   # set by resident.run_ranks around threaded rehearsals
 
     def __init__(self, device: int = 0):
-        self.L = lib()
+        self.L = _SerialLib(lib()) if Context.serialize else lib()
         self.h = C.c_void_p()
         rc = self.L.mdp_create(C.byref(self.h), C.c_int(device))
         if rc:
@@ -315,6 +351,11 @@ class Context:
         arrs["eatom"] = ea
         return arrs
 
+    def md_download_x_all(self, nall):
+        x = np.zeros((max(nall, 1), 3))
+        self._ck(self.L.mdp_md_download_x_all(self.h, _dp(x)))
+        return x[:nall]
+
     def md_upload_x(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         self._ck(self.L.mdp_md_upload_x(self.h, _dp(x)))
@@ -336,6 +377,84 @@ class Context:
         out = (C.c_longlong * 8)()
         self._ck(self.L.mdp_md_neighbor_stats(self.h, out))
         return list(out)
+
+    # ---------------- domain decomposition on the device (csrc/domain.hip)
+    def dd_setup(self, box, procgrid, rank, cutghost):
+        """box: host.system.Box (restricted triclinic); procgrid: bricks per dimension"""
+        cfg = DdConfig()
+        xy, xz, yz = (float(t) for t in box.tilt)
+        for d in range(3):
+            cfg.boxlo[d] = float(box.lo[d])
+            cfg.procgrid[d] = int(procgrid[d])
+        for k, val in enumerate((box.prd[0], box.prd[1], box.prd[2], yz, xz, xy)):
+            cfg.h[k] = float(val)
+        cfg.rank, cfg.cutghost = int(rank), float(cutghost)
+        self._ck(self.L.mdp_dd_setup(self.h, C.byref(cfg)))
+        self._dd_nranks = int(procgrid[0]) * int(procgrid[1]) * int(procgrid[2])
+
+    def dd_reneighbor(self):
+        self._ck(self.L.mdp_dd_reneighbor(self.h))
+
+    def dd_migrate_begin(self):
+        cnt = (C.c_int * self._dd_nranks)()
+        self._ck(self.L.mdp_dd_migrate_begin(self.h, cnt))
+        return np.array(cnt, dtype=np.int64)
+
+    def dd_migrate_pack(self, d_buf):
+        self._ck(self.L.mdp_dd_migrate_pack(self.h, C.c_void_p(d_buf)))
+
+    def dd_migrate_end(self, narrive, d_buf):
+        self._ck(self.L.mdp_dd_migrate_end(self.h, C.c_int(int(narrive)), C.c_void_p(d_buf)))
+
+    def dd_borders_begin(self):
+        cnt = (C.c_int * self._dd_nranks)()
+        self._ck(self.L.mdp_dd_borders_begin(self.h, cnt))
+        return np.array(cnt, dtype=np.int64)
+
+    def dd_borders_pack(self, d_buf):
+        self._ck(self.L.mdp_dd_borders_pack(self.h, C.c_void_p(d_buf)))
+
+    def dd_borders_end(self, recv_counts, d_buf):
+        rc = (C.c_int * self._dd_nranks)(*[int(v) for v in recv_counts])
+        self._ck(self.L.mdp_dd_borders_end(self.h, rc, C.c_void_p(d_buf)))
+
+    def dd_info(self):
+        out = (C.c_longlong * 8)()
+        sc, rc = (C.c_int * self._dd_nranks)(), (C.c_int * self._dd_nranks)()
+        self._ck(self.L.mdp_dd_info(self.h, out, sc, rc))
+        keys = ("nlocal", "nself", "nsend", "nrecv", "reneighbors", "left_last", "nranks", "rank")
+        d = dict(zip(keys, (int(v) for v in out)))
+        d["send_counts"], d["recv_counts"] = np.array(sc, dtype=np.int64), np.array(rc, dtype=np.int64)
+        return d
+
+    def dd_forward_pack(self, d_buf):
+        self._ck(self.L.mdp_dd_forward_pack(self.h, C.c_void_p(d_buf)))
+
+    def dd_forward_unpack(self, d_buf):
+        self._ck(self.L.mdp_dd_forward_unpack(self.h, C.c_void_p(d_buf)))
+
+    def dd_forward_scalar_pack(self, d_buf):
+        self._ck(self.L.mdp_dd_forward_scalar_pack(self.h, C.c_void_p(d_buf)))
+
+    def dd_forward_scalar_unpack(self, d_buf):
+        self._ck(self.L.mdp_dd_forward_scalar_unpack(self.h, C.c_void_p(d_buf)))
+
+    def dd_reverse_pack(self, d_buf):
+        self._ck(self.L.mdp_dd_reverse_pack(self.h, C.c_void_p(d_buf)))
+
+    def dd_reverse_unpack(self, d_buf):
+        self._ck(self.L.mdp_dd_reverse_unpack(self.h, C.c_void_p(d_buf)))
+
+    def md_moved_async(self):
+        """(moved, dangerous) of the check launched by the previous call; launches the next one"""
+        m, d = C.c_int(0), C.c_int(0)
+        self._ck(self.L.mdp_md_moved_async(self.h, C.byref(m), C.byref(d)))
+        return bool(m.value), bool(d.value)
+
+    def md_download_int(self, name: str, nlocal: int):
+        out = np.zeros(max(nlocal, 1), dtype=np.int32)
+        self._ck(self.L.mdp_md_download_int(self.h, name.encode(), _ip(out)))
+        return out[:nlocal]
 
     # halo plumbing (device pointers as ints)
     def md_pack_x(self, n, d_sendlist, d_shift, d_buf):

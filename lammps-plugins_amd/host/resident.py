@@ -323,3 +323,319 @@ def reneighbor(dom: Domain, s: S.System, cutghost, map_, dist=None, device=None)
     d.builds = dom.builds
     d.build_neighbors()
     return d
+
+
+# ---------------------------------------------------------------------------------------------------
+# Device-side domain decomposition (csrc/domain.hip): every rank keeps ONE brick, remaps / migrates /
+# re-derives its ghosts on the GPU at each reneighboring and only exchanges counts and packed records.
+# This is the path bench.py runs; Domain / RankDomain above (host-planned with numpy) stay as the
+# independent reference the tests compare it with.
+# ---------------------------------------------------------------------------------------------------
+
+class Transport:
+    """all-to-all of device buffers between the ranks of a torch.distributed group.  backend "nccl" is
+    RCCL over xGMI (device buffers go straight in); any other backend is a rehearsal path for boxes with
+    fewer GPUs than ranks: buffers are staged through the host around each collective."""
+
+    def __init__(self, dist_module, device, stage_host: bool):
+        import torch
+        self.torch, self.dist, self.device, self.stage_host = torch, dist_module, device, stage_host
+        self.world = dist_module.get_world_size()
+        self.rank = dist_module.get_rank()
+
+    def counts(self, send_counts: np.ndarray) -> np.ndarray:
+        """recv[q] = what rank q sends to me"""
+        torch = self.torch
+        dev = "cpu" if self.stage_host else self.device
+        s = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=dev)
+        r = torch.empty_like(s)
+        self.dist.all_to_all_single(r, s)
+        return r.cpu().numpy()
+
+    def exchange(self, send, send_counts, recv_counts, width: int, recv=None, async_op=False):
+        """send: flat float64 device tensor of sum(send_counts)*width; returns (recv tensor, work or None)"""
+        torch = self.torch
+        nrecv = int(np.sum(recv_counts)) * width
+        if recv is None:
+            recv = torch.empty(max(nrecv, 1), dtype=torch.float64, device=self.device)
+        ins = [int(c) * width for c in send_counts]
+        outs = [int(c) * width for c in recv_counts]
+        nsend = sum(ins)
+        if not self.stage_host:
+            w = self.dist.all_to_all_single(recv[:nrecv], send[:nsend], outs, ins, async_op=async_op)
+            return recv, w
+        torch.cuda.synchronize()
+        o, i = recv[:nrecv].cpu(), send[:nsend].cpu()
+        self.dist.all_to_all_single(o, i, outs, ins)
+        recv[:nrecv].copy_(o)
+        torch.cuda.synchronize()
+        return recv, None
+
+    def any(self, flag: bool) -> bool:
+        torch = self.torch
+        t = torch.tensor([1.0 if flag else 0.0], device="cpu" if self.stage_host else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
+    def sum(self, values):
+        torch = self.torch
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.stage_host else self.device)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+
+class DeviceDomain:
+    """One brick of the periodic box per GPU, all bookkeeping on the device.
+
+    s: the GLOBAL system (every rank builds the same synthetic system and keeps the atoms of its brick --
+    setup only; nothing global exists afterwards).  transport=None: one GPU, no communication."""
+
+    def __init__(self, ctx: capi.Context, style: int, s: S.System, cutghost: float, skin: float, map_, v0=None,
+                 dt: float = 0.001, transport: Transport | None = None, master_list: bool = False):
+        from . import decomp
+        self.ctx, self.style, self.box, self.skin, self.dt = ctx, style, s.box, skin, dt
+        self.tr = transport
+        self.world = 1 if transport is None else transport.world
+        self.rank = 0 if transport is None else transport.rank
+        self.grid = decomp.proc_grid(self.world)
+        self.natoms_total = s.n
+        xw = S.wrap(s.box, s.x)
+        if self.world > 1:
+            g = np.array(self.grid)
+            lam = s.box.x2lamda(xw)
+            cell = np.clip(np.floor(lam * g).astype(np.int64), 0, g - 1)
+            mine = ((cell[:, 0] * g[1] + cell[:, 1]) * g[2] + cell[:, 2]) == self.rank
+        else:
+            mine = np.ones(s.n, dtype=bool)
+        x = np.ascontiguousarray(xw[mine])
+        v = np.zeros_like(x) if v0 is None else np.ascontiguousarray(np.asarray(v0, dtype=np.float64)[mine])
+        cfg = capi.MdConfig()
+        cfg.style, cfg.nlocal, cfg.nghost, cfg.ntypes = style, len(x), 0, len(s.mass) - 1
+        cfg.skin, cfg.dt, cfg.ftm2v, cfg.mvv2e = skin, dt, S.FTM2V, S.MVV2E
+        cfg.master_list = 1 if master_list else 0
+        cfg.nghost_self = 0
+        corners = s.box.lamda2x(np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)], dtype=float))
+        for d in range(3):   # provisional: the library sets the bounds of the brick at every reneighboring
+            cfg.bbox_lo[d], cfg.bbox_hi[d] = corners[:, d].min() - cutghost - 2.0, corners[:, d].max() + cutghost + 2.0
+        e3, e1 = np.zeros((0, 3)), np.zeros(0, dtype=np.int32)
+        if transport is not None and not transport.stage_host:
+            # pack -> all_to_all -> unpack are only ordered when the context launches on the stream the
+            # collectives synchronise with (torch's current stream)
+            ctx.set_stream(transport.torch.cuda.current_stream().cuda_stream)
+        ctx.md_setup(cfg, x, v, s.type[mine], s.tag[mine], s.mass, map_, e1, e3, e1, e1)
+        ctx.dd_setup(s.box, self.grid, self.rank, cutghost)
+        self.send3 = self.recv3 = self.send1 = self.recv1 = None
+        self.builds = 0
+        self.dangerous = 0
+        self.reneighbor()
+
+    # ------------------------------------------------------------------ reneighboring
+    def reneighbor(self):
+        """Comm::exchange + Comm::borders + Neighbor::build, per rank on the device"""
+        ctx, tr = self.ctx, self.tr
+        if tr is None:
+            ctx.dd_reneighbor()
+        else:
+            torch = tr.torch
+            f64 = dict(dtype=torch.float64, device=tr.device)
+            sc = ctx.dd_migrate_begin()
+            rc = tr.counts(sc)
+            send = torch.empty(max(int(sc.sum()) * 8, 1), **f64)
+            ctx.dd_migrate_pack(send.data_ptr())
+            recv, _ = tr.exchange(send, sc, rc, 8)
+            if not tr.stage_host:
+                torch.cuda.current_stream().synchronize()
+            ctx.dd_migrate_end(int(rc.sum()), recv.data_ptr())
+            sc = ctx.dd_borders_begin()
+            rc = tr.counts(sc)
+            send = torch.empty(max(int(sc.sum()) * 6, 1), **f64)
+            ctx.dd_borders_pack(send.data_ptr())
+            recv, _ = tr.exchange(send, sc, rc, 6)
+            ctx.dd_borders_end(rc, recv.data_ptr())
+            ctx.md_build_neighbors()
+            self.send_counts, self.recv_counts = sc, rc
+            ns, nr = int(sc.sum()), int(rc.sum())
+            self.send3 = torch.empty(max(ns, 1) * 3, **f64)
+            self.recv3 = torch.empty(max(nr, 1) * 3, **f64)
+            self.send1 = torch.empty(max(ns, 1), **f64)
+            self.recv1 = torch.empty(max(nr, 1), **f64)
+            self._keep = (send, recv)   # until the stream has consumed them
+        info = ctx.dd_info()
+        self.nlocal, self.nself, self.nsend, self.nrecv = info["nlocal"], info["nself"], info["nsend"], info["nrecv"]
+        self.nghost = self.nself + self.nrecv
+        self.builds += 1
+        self.fresh_ghosts = True
+
+    @property
+    def tags_local(self):
+        return self.ctx.md_download_int("tag", self.nlocal)
+
+    # ------------------------------------------------------------------ halo
+    def _active(self):
+        return self.tr is not None and (self.nsend or self.nrecv)
+
+    def forward_positions(self, async_op=False):
+        self.ctx.dd_forward_pack(self.send3.data_ptr())
+        _, w = self.tr.exchange(self.send3, self.send_counts, self.recv_counts, 3, recv=self.recv3, async_op=async_op)
+        if async_op:
+            return w
+        self.ctx.dd_forward_unpack(self.recv3.data_ptr())
+
+    def forward_fp(self):
+        self.ctx.dd_forward_scalar_pack(self.send1.data_ptr())
+        self.tr.exchange(self.send1, self.send_counts, self.recv_counts, 1, recv=self.recv1)
+        self.ctx.dd_forward_scalar_unpack(self.recv1.data_ptr())
+
+    def reverse_forces(self):
+        self.ctx.md_fold_self_ghost_f()
+        if not self._active():
+            return
+        self.ctx.dd_reverse_pack(self.recv3.data_ptr())
+        self.tr.exchange(self.recv3, self.recv_counts, self.send_counts, 3, recv=self.send3)
+        self.ctx.dd_reverse_unpack(self.send3.data_ptr())
+
+    # ------------------------------------------------------------------ MD
+    def compute(self, eflag=0, vflag=0):
+        """Pair::compute for the current positions (ghosts must be current)"""
+        if self.style == capi.STYLE_REBOMOS or not self._active():
+            self.ctx.md_compute(eflag, vflag)
+            return
+        self.ctx.md_aeam_density(eflag)
+        self.forward_fp()
+        self.ctx.md_aeam_force(eflag, vflag)
+        self.reverse_forces()
+
+    def step(self, eflag=0, vflag=0, rebuild=False):
+        """one velocity-Verlet step, Verlet::run order: initial_integrate, [reneighbor], forward comm, force,
+        final_integrate.  REBO-MoS on several GPUs hides the ghost exchange behind the interior Lennard-Jones work."""
+        ctx = self.ctx
+        ctx.md_initial_integrate()
+        if rebuild:
+            self.reneighbor()               # the border exchange carries the current positions
+        fresh, self.fresh_ghosts = self.fresh_ghosts and rebuild, False
+        if not self._active():
+            ctx.md_compute(eflag, vflag)
+        elif self.style == capi.STYLE_REBOMOS:
+            work = None if fresh else self.forward_positions(async_op=True)   # pack + all-to-all in flight
+            ctx.md_compute_begin(eflag, vflag)
+            if not fresh:
+                if work is not None:
+                    work.wait()
+                ctx.dd_forward_unpack(self.recv3.data_ptr())
+            ctx.md_compute_end(eflag, vflag)
+        else:
+            if not fresh:
+                self.forward_positions()
+            self.compute(eflag, vflag)
+        ctx.md_final_integrate()
+
+    def thermo(self, reduce=True):
+        """KE, PE, virial (summed over ranks), T and P of the whole system"""
+        t = self.ctx.md_thermo()
+        if self.tr is not None and reduce:
+            tot = self.tr.sum([t["ke"], t["pe"], *t["virial"], ])
+            t["ke"], t["pe"], t["virial"] = float(tot[0]), float(tot[1]), tot[2:8]
+        t["temp"] = S.temperature(t["ke"], self.natoms_total)
+        t["press"] = S.pressure(t["ke"], t["virial"], self.natoms_total, self.box.volume)
+        return t
+
+    def moved(self) -> bool:
+        """deferred `neigh_modify check yes` flag (see mdp_md_moved_async); one GPU only -- several ranks must
+        agree on the step they reneighbor at, see needs_rebuild"""
+        m, d = self.ctx.md_moved_async()
+        self.dangerous += int(d)
+        return m
+
+    def needs_rebuild(self, margin: float = 0.0) -> bool:
+        """blocking check, collective over the ranks: some owned atom moved more than skin/2 - margin"""
+        t = self.ctx.md_thermo()
+        need = t["maxdisp2"] > max(0.5 * self.skin - margin, 0.25 * self.skin) ** 2
+        return self.tr.any(need) if self.tr is not None else need
+
+
+class ThreadTransport:
+    """Rehearsal transport: N ranks as N threads of ONE process, each with its own context on the same GPU.
+    A GPU box admits few processes on its card, so this is how the 4- and 8-brick decompositions (migration,
+    borders, per-step halo) are exercised on one GPU; the rank code is exactly what runs over RCCL.
+    Exchanges are device-to-device copies between the ranks' torch buffers, fenced by thread barriers."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared: "ThreadTransport.Shared", rank: int, ctx: capi.Context, device):
+        import torch
+        self.torch, self.sh, self.rank, self.world, self.ctx, self.device = torch, shared, rank, shared.world, ctx, device
+        self.stage_host = True   # every exchange is synchronous (no overlap in the rehearsal)
+
+    def _all(self, value):
+        self.sh.barrier.wait()
+        self.sh.slots[self.rank] = value
+        self.sh.barrier.wait()
+        return list(self.sh.slots)
+
+    def counts(self, send_counts):
+        allc = self._all(np.asarray(send_counts, dtype=np.int64).copy())
+        return np.array([allc[q][self.rank] for q in range(self.world)], dtype=np.int64)
+
+    def exchange(self, send, send_counts, recv_counts, width, recv=None, async_op=False):
+        torch = self.torch
+        nrecv = int(np.sum(recv_counts)) * width
+        if recv is None:
+            recv = torch.empty(max(nrecv, 1), dtype=torch.float64, device=self.device)
+        self.ctx.sync()                       # my pack kernel has finished
+        off = np.concatenate([[0], np.cumsum(np.asarray(send_counts, dtype=np.int64) * width)])
+        peers = self._all((send, off))
+        at = 0
+        for q in range(self.world):
+            n = int(recv_counts[q]) * width
+            if n:
+                src, soff = peers[q]
+                recv[at:at + n].copy_(src[int(soff[self.rank]):int(soff[self.rank]) + n])
+            at += n
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()                # nobody reuses a send buffer before every peer has copied
+        return recv, None
+
+    def any(self, flag):
+        return any(self._all(bool(flag)))
+
+    def sum(self, values):
+        return np.sum(np.array(self._all(np.asarray(list(values), dtype=np.float64))), axis=0)
+
+
+def run_ranks(world: int, fn, device=0):
+    """run fn(rank, make_transport) on `world` threads; make_transport(ctx) gives the rank's ThreadTransport.
+    Returns the list of results; the first exception of any rank is re-raised."""
+    import threading
+    import torch
+    shared = ThreadTransport.Shared(world)
+    out, err = [None] * world, [None] * world
+    dev = torch.device("cuda", device)
+
+    def body(r):
+        try:
+            torch.cuda.set_device(device)
+            out[r] = fn(r, lambda ctx: ThreadTransport(shared, r, ctx, dev))
+        except BaseException as e:   # noqa: BLE001 -- re-raised below
+            err[r] = e
+            shared.barrier.abort()
+
+    import os
+    old = capi.Context.serialize
+    capi.Context.serialize = os.environ.get("MDP_THREAD_SERIALIZE", "1") != "0"
+    try:
+        th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        capi.Context.serialize = old
+    real = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real or any(e is not None for e in err):
+        raise (real[0] if real else [e for e in err if e is not None][0])
+    return out

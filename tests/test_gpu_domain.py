@@ -1,0 +1,234 @@
+"""GPU: the device-side domain decomposition (csrc/domain.hip) -- remap, migration, Hilbert ordering, ghost
+derivation, per-step halo -- against the reference's published counts (log.rebomos-bulk.1:72-75, .4:72-75),
+against the host-planned numpy decomposition (host/decomp.py, independent code) and against the CPU oracle.
+Several ranks run as threads of this one process (resident.ThreadTransport): a GPU box admits few processes
+on its card, and the rank code is the same that runs over RCCL."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, POT_AEAM, POT_REBOMOS
+from lammps_plugins_amd.host import capi, decomp, resident, system as S
+import mdref
+
+pytestmark = pytest.mark.gpu
+MAP = [0, 0, 1]
+
+
+@pytest.fixture(scope="module")
+def log():
+    return json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+
+
+def _rebo_ctx():
+    ctx = capi.Context(0)
+    p = capi.read_rebomos_file(POT_REBOMOS)
+    ctx.rebomos_set_params(p)
+    return ctx, 3.0 * p.rcmax[0][0] + 2.0
+
+
+def _by_tag(dom, want=("x", "v", "f")):
+    got = dom.ctx.md_download(dom.nlocal, want=want)
+    tags = dom.tags_local
+    return tags, {k: got[k] for k in want}
+
+
+def test_one_rank_reproduces_the_reference_log(log):
+    """288 atoms, 4285 ghosts (log.rebomos-bulk.1:72-75), thermo rows of steps 0/10/20 (:54-56)"""
+    s = S.rebomos_bulk_cell()
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    assert (d.nlocal, d.nself, d.nrecv) == (288, log["nghost"], 0)
+    assert sorted(d.tags_local.tolist()) == list(range(1, 289))
+    d.compute(1, 1)
+    rows = [d.thermo()]
+    for step in range(1, 21):
+        ev = 1 if step % 10 == 0 else 0
+        d.step(ev, ev)
+        if ev:
+            rows.append(d.thermo())
+    for got, ref in zip(rows, log["thermo"]):
+        assert got["pe"] == pytest.approx(ref["pe"], abs=5.1e-5)
+        assert got["ke"] == pytest.approx(ref["ke"], abs=5.1e-8)
+        assert got["press"] == pytest.approx(ref["press"], abs=5.1e-3)
+    assert not d.moved()                     # "Neighbor list builds = 0" (log.rebomos-bulk.1:83)
+    ctx.close()
+
+
+def test_device_ghosts_equal_the_host_planned_ghosts():
+    """same ghost SET (tag, position) as system.make_ghosts for a strained, jittered triclinic cell"""
+    s = S.jitter(S.scale(S.replicate(S.rebomos_bulk_cell(), (2, 1, 2)), 1.05), 0.1, seed=8)
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    owner, shift = S.make_ghosts(s.box, S.wrap(s.box, s.x), cutghost)
+    assert d.nself == len(owner)
+    want = np.round(S.wrap(s.box, s.x)[owner] + shift @ s.box.h.T, 6)
+    g = np.round(ctx.md_download_x_all(d.nlocal + d.nghost)[d.nlocal:], 6)
+    assert sorted(map(tuple, g)) == sorted(map(tuple, want))
+    ctx.close()
+
+
+def test_atoms_outside_the_box_are_remapped(oracle):
+    """input positions shifted by whole and fractional box vectors: the device wraps them (Domain::remap) and
+    the forces equal the oracle's for the wrapped system"""
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s = S.jitter(S.scale(S.rebomos_bulk_cell(), 1.08), 0.12, seed=21)
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    # push atoms out through every face, then reneighbor on the device
+    got = ctx.md_download(d.nlocal, want=("x",))
+    tags = d.tags_local
+    rng = np.random.default_rng(5)
+    kick = rng.integers(-1, 2, size=(d.nlocal, 3)).astype(float) @ s.box.h.T
+    ctx.md_upload_x(got["x"] + kick)
+    d.reneighbor()
+    assert d.nlocal == s.n and sorted(d.tags_local.tolist()) == list(range(1, s.n + 1))
+    d.compute(3, 1)
+    t = d.thermo()
+    tags, a = _by_tag(d, ("x", "f"))
+    order = np.argsort(tags)
+    xs = a["x"][order]
+    lam = s.box.x2lamda(xs)
+    assert lam.min() >= -1e-12 and lam.max() < 1.0 + 1e-12
+    o = mdref.RebomosCPU(oracle, P, S.System(s.box, xs, s.type, s.tag, s.mass)).compute(xs)
+    assert np.abs(a["f"][order] - o["f_owned"]).max() < 1e-9
+    assert t["pe"] == pytest.approx(o["eng"], rel=1e-10)
+    ctx.close()
+
+
+def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None):
+    """NVE run on `world` bricks (threads), forced reneighboring every `rebuild_every` steps; returns per-tag
+    x, v and the thermo of the last step, plus per-rank counts"""
+
+    def rank_fn(r, make_tr):
+        if style == capi.STYLE_REBOMOS:
+            ctx, cutghost = _rebo_ctx()
+            skin, map_ = 2.0, MAP
+        else:
+            ctx = capi.Context(0)
+            af = capi.AeamFile(POT_AEAM)
+            tabs = af.build()
+            ctx.aeam_set_tables(tabs)
+            skin, map_ = 1.0, None
+            cutghost = float(af.cut_table(tabs).max()) + skin
+            ctx._af = (af, tabs)
+        tr = make_tr(ctx) if world > 1 else None
+        d = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr)
+        counts0 = (d.nlocal, d.nself, d.nrecv)
+        d.compute(1, 1)
+        th0 = d.thermo()
+        left = 0
+        for step in range(1, steps + 1):
+            rb = rebuild_every and step % rebuild_every == 0
+            d.step(1 if step == steps else 0, 1 if step == steps else 0, rebuild=rb)
+            if rb:
+                left += ctx.dd_info()["left_last"]
+        th = d.thermo()
+        tags, a = _by_tag(d, ("x", "v", "f"))
+        ctx.close()
+        return dict(tags=tags, x=a["x"], v=a["v"], f=a["f"], th0=th0, th=th, counts0=counts0, left=left,
+                    builds=d.builds)
+
+    if world == 1:
+        res = [rank_fn(0, None)]
+    else:
+        res = resident.run_ranks(world, rank_fn)
+    n = s.n
+    x, v, f = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+    seen = np.zeros(n, dtype=int)
+    for r in res:
+        idx = r["tags"] - 1
+        x[idx], v[idx], f[idx] = r["x"], r["v"], r["f"]
+        seen[idx] += 1
+    assert np.all(seen == 1)                      # every atom owned exactly once
+    return dict(x=x, v=v, f=f, th0=res[0]["th0"], th=res[0]["th"], counts0=[r["counts0"] for r in res],
+                left=sum(r["left"] for r in res), builds=res[0]["builds"])
+
+
+def test_four_bricks_match_the_reference_4_rank_log(log):
+    """2 x 2 x 1 bricks of the 288-atom cell: Nlocal 72 each, Nghost 2768/2768/2775/2775
+    (log.rebomos-bulk.4:72-75), and the same thermo rows as one rank (log.rebomos-bulk.4:54-56 == .1:54-56)"""
+    s = S.rebomos_bulk_cell()
+    r = _run(4, s, None, 20, 0)
+    assert [c[0] for c in r["counts0"]] == [72, 72, 72, 72]
+    assert sorted(c[1] + c[2] for c in r["counts0"]) == [2768, 2768, 2775, 2775]
+    ref0, ref20 = log["thermo"][0], log["thermo"][2]
+    assert r["th0"]["pe"] == pytest.approx(ref0["pe"], abs=5.1e-5)
+    assert r["th0"]["press"] == pytest.approx(ref0["press"], abs=5.1e-3)
+    assert r["th"]["pe"] == pytest.approx(ref20["pe"], abs=5.1e-5)
+    assert r["th"]["ke"] == pytest.approx(ref20["ke"], abs=5.1e-8)
+    assert r["th"]["press"] == pytest.approx(ref20["press"], abs=5.1e-3)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bricks_with_migration_follow_the_one_rank_trajectory(world):
+    """3x3x2 replica (5184 atoms) at 300 K with a uniform drift of 60 A/ps on top: atoms stream through brick
+    and box faces (Galilean invariance: the physics is that of the run at rest).  Reneighboring is forced every
+    2 steps (0.16 A of drift, far inside the 1 A half skin).  1, 2 and 8 bricks must produce the same
+    trajectory, and atoms must really have changed owner."""
+    s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 2))
+    v0 = S.gaussian_velocities(s, 300.0, seed=11) + np.array([60.0, -45.0, 30.0])
+    steps, every = 40, 2
+    one = _run(1, s, v0, steps, every)
+    many = _run(world, s, v0, steps, every)
+    assert many["left"] > 20                       # atoms migrated between bricks
+    assert many["builds"] == one["builds"] == 1 + steps // every
+    dx = many["x"] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T      # same atom, possibly another periodic image
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(many["v"] - one["v"]).max() < 1e-7
+    assert np.abs(many["f"] - one["f"]).max() < 1e-7
+    assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+    assert many["th"]["ke"] == pytest.approx(one["th"]["ke"], rel=1e-9)
+    assert np.allclose(many["th"]["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
+    # and the drifting run is the run at rest, seen from a moving frame
+    rest = _run(1, s, v0 - np.array([60.0, -45.0, 30.0]), steps, 0)
+    assert many["th"]["pe"] == pytest.approx(rest["th"]["pe"], rel=1e-9)
+
+
+def test_aeam_bricks_with_halo_of_fp_and_ghost_forces(oracle):
+    """AEAM on 2 and 4 bricks: scalar forward exchange of fp and reverse exchange of the angular ghost forces
+    through the library's send list; forces equal the oracle's, trajectory equals the one-rank run"""
+    T = oracle.aeam_pot(POT_AEAM)
+    s = S.jitter(S.fcc_cell(4.045, 8, frac_type2=0.06, seed=3), 0.05, seed=4)
+    s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+    v0 = S.gaussian_velocities(s, 600.0, seed=2) + np.array([40.0, 25.0, -30.0])
+    r0 = _run(1, s, v0, 0, 0, style=capi.STYLE_AEAM)
+    o = mdref.AeamCPU(oracle, T, S.System(s.box, S.wrap(s.box, s.x), s.type, s.tag, s.mass)).compute(S.wrap(s.box, s.x))
+    assert np.abs(r0["f"] - o["f_owned"]).max() < 1e-9
+    one = _run(1, s, v0, 24, 3, style=capi.STYLE_AEAM)
+    for world in (2, 4):
+        st = _run(world, s, v0, 0, 0, style=capi.STYLE_AEAM)
+        assert np.abs(st["f"] - o["f_owned"]).max() < 1e-9
+        assert st["th0"]["pe"] == pytest.approx(o["eng"], rel=1e-11)
+        many = _run(world, s, v0, 24, 3, style=capi.STYLE_AEAM)
+        assert many["left"] > 5
+        dx = many["x"] - one["x"]
+        dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+        assert np.abs(dx).max() < 1e-8
+        assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+
+
+def test_deferred_displacement_trigger_fires_once_per_need():
+    """mdp_md_moved_async: silent while atoms stay inside skin/2 - margin, fires one call after they leave it,
+    and is reset by the reneighboring it asks for"""
+    s = S.replicate(S.rebomos_bulk_cell(), (2, 2, 1))
+    ctx, cutghost = _rebo_ctx()
+    v0 = np.tile(np.array([95.0, 0.0, 0.0]), (s.n, 1))           # 0.095 A per step
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP, v0=v0)
+    d.compute(0, 0)
+    fired = []
+    for step in range(1, 31):
+        ctx.md_initial_integrate()
+        m = d.moved()
+        if m:
+            d.reneighbor()
+            fired.append(step)
+        ctx.md_compute(0, 0)
+        ctx.md_final_integrate()
+    # trigger distance 0.9 A: exceeded at step 10 (0.95 A), reported one call later, then again 11 steps on
+    assert fired == [11, 22]
+    assert d.dangerous == 0
+    ctx.close()
