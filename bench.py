@@ -3,16 +3,20 @@
 3,981,312 atoms, BASELINE.json configs[3] / SURVEY.md 8d config #4) as a device-resident NVE run.
 
 One "step" = one velocity-Verlet step around one pass of the hot path (PairREBOMoS::compute:
-REBO centre kernels + LJ/gather kernel) over all atoms of the job; positions and the neighbor list
-are resident in HBM when the timed region starts.  `neigh_modify every 1 delay 0 check yes` is
-honoured with the displacement check every 10 steps (rebuild + repack inside the timed region
-when it fires).  N>1: atoms are spatially decomposed over N GPUs (strong scaling, fixed total
-size) with one ghost-position all_to_all per step on RCCL.
+REBO centre kernels + LJ/gather kernel; --workload aeam: PairAEAM::compute passes 1-3) over all atoms of
+the job; positions and lists are resident in HBM when the timed region starts.  As in the reference
+inputs the timed region tallies energy and virial every `thermo` steps (10, in.rebomos-bulk:31; 100,
+sample.in:28) and honours `neigh_modify every 1 check yes`: one GPU reads a deferred on-device
+displacement flag every step, several GPUs agree on it every --check-every steps; reneighboring
+(remap, migration between bricks, ghost derivation, list build) happens on the GPUs inside the timed
+region.  N>1: one brick of the box per GPU (strong scaling, fixed total size), one ghost-position
+all-to-all per step on RCCL, overlapped with the interior Lennard-Jones work.
 
 Prints ONE JSON line on rank 0 (contract in the task statement)."""
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,14 +29,17 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 graft.load_package()
-from lammps_plugins_amd.host import capi, decomp, resident, system as S  # noqa: E402
+from lammps_plugins_amd.host import capi, resident, system as S  # noqa: E402
 
 POT_REBOMOS = os.path.join(ROOT, "tests", "golden", "potentials", "MoS.REBO.set5b")
 POT_AEAM = os.path.join(ROOT, "tests", "golden", "potentials", "AlSi.aeam")
 
-# algorithmic HBM bytes per atom-step
+# algorithmic HBM bytes and FP64 flop-equivalents per atom-step
 B_ALG = {"rebomos": 2040.0, "aeam": 400.0}
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FLOP_ALG = {"rebomos": 25.0e3, "aeam": 7.0e3}
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector rate (public spec)
+THERMO_EVERY = {"rebomos": 10, "aeam": 100}
 
 
 def log(*a):
@@ -49,9 +56,9 @@ def build_system(args):
     return s, name
 
 
-def cpu_baseline(workload, seconds=12.0):
-    """the CPU oracle (port of the reference algorithm, oracle/) on a bounded sample of the same
-    workload, one core.  Only the pair computation is timed (99.7% of the reference's loop)."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_sample(workload):
+    """a bounded sample of the workload for the CPU oracle: (callable, atoms per call, description)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bindings as ob
     import mdref
@@ -60,16 +67,22 @@ def cpu_baseline(workload, seconds=12.0):
         P = orc.rebomos_params(POT_REBOMOS)
         s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 2))
         eng = mdref.RebomosCPU(orc, P, s)
-        sample = "in.rebomos-bulk cell replicated 3x3x2 = %d atoms, force-only compute() calls" % s.n
+        what = "in.rebomos-bulk cell replicated 3x3x2 = %d atoms, force-only compute() calls" % s.n
         call = lambda: eng.orc.rebomos_compute(P, eng.nlocal, eng.x_all, eng.elem, eng.tag_all, eng.nn, eng.off,
                                                eng.nb, eflag=0, vflag=0)
     else:
         T = orc.aeam_pot(POT_AEAM)
         s = S.fcc_cell(4.045, 14, frac_type2=0.0075, seed=7683797)
         eng = mdref.AeamCPU(orc, T, s)
-        sample = "fcc 14x14x14 cells = %d atoms (0.75%% Si), force-only compute() calls" % s.n
+        what = "fcc 14x14x14 cells = %d atoms (0.75%% Si), force-only compute() calls" % s.n
         call = lambda: eng.orc.aeam_compute(T, eng.nlocal, eng.x_all, eng.type_all, eng.nn, eng.off, eng.nb,
                                             eflag=0, vflag=0)
+    return call, s.n, what
+
+
+def _cpu_worker(arg):
+    workload, seconds = arg
+    call, natoms, what = _cpu_sample(workload)
     call()
     t0 = time.perf_counter()
     n = 0
@@ -78,9 +91,75 @@ def cpu_baseline(workload, seconds=12.0):
         n += 1
         if time.perf_counter() - t0 > seconds or n >= 400:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=s.n * n / dt / 1e6, unit="Matom-steps/s", cores=1, kind="port",
-                sample=sample + ", %d calls in %.1f s" % (n, dt))
+    return natoms * n, time.perf_counter() - t0, what, n
+
+
+def cpu_baseline(workload, seconds=8.0):
+    """the CPU oracle (port of the reference algorithm, oracle/) on a bounded sample of the same workload: one core
+    (mirrors `1 MPI task x 1 thread`, log.rebomos-bulk.1:59) and all cores of this box's CPU share, every core
+    working on its own replica of the sample (= ideal scaling of a spatial decomposition, log.rebomos-bulk.4:59).
+    Only the pair computation is timed (99.7 % of the reference's loop, log.rebomos-bulk.1:65)."""
+    work, dt, what, n = _cpu_worker((workload, seconds))
+    one = dict(value=work / dt / 1e6, unit="Matom-steps/s", cores=1, kind="port",
+               sample=what + ", %d calls in %.1f s" % (n, dt))
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or 1
+    ncore = max(1, min(ncore, 16))          # a one-GPU box's CPU share is 16 cores
+    allc = None
+    try:
+        with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
+            res = list(ex.map(_cpu_worker, [(workload, seconds)] * ncore))
+        allc = dict(value=sum(r[0] for r in res) / max(r[1] for r in res) / 1e6, unit="Matom-steps/s", cores=ncore,
+                    kind="port", sample=what + ", one replica per core, %d cores concurrently" % ncore)
+    except Exception as e:  # noqa: BLE001 -- the all-core figure is informational
+        log(f"[bench] all-core CPU baseline failed: {e}")
+    return one, allc
+
+
+# ------------------------------------------------------------------------------------------------ host mode
+def host_mode_rate(s, p, skin, cutghost, steps=5):
+    """PCIe-inclusive rate of the drop-in boundary (what a LAMMPS Pair::compute() sees): per step x of owned+ghost
+    atoms goes up (24 B/atom), forces of owned atoms come back (24 B/atom).  REBO-MoS only; never `value`."""
+    xw = S.wrap(s.box, s.x)
+    owner, shift = S.make_ghosts(s.box, xw, cutghost)
+    xa = np.ascontiguousarray(np.concatenate([xw, xw[owner] + shift @ s.box.h.T]))
+    type_all = np.concatenate([s.type, s.type[owner]]).astype(np.int32)
+    tag_all = np.concatenate([s.tag, s.tag[owner]]).astype(np.int32)
+    n = s.n
+    ctx = capi.Context(0)
+    ctx.rebomos_set_params(p)
+    ctx.set_atoms_host(n, xa, type_all, tag_all, 2, map_=[0, 0, 1])
+    ctx.set_skin(skin)
+    f = np.zeros((n, 3))
+    eng, vir = capi.C.c_double(0.0), np.zeros(6)
+
+    def compute():
+        ctx._ck(ctx.L.mdp_rebomos_compute_host(ctx.h, 0, 0, capi._dp(f), capi.C.byref(eng), capi._dp(vir), None, None))
+
+    compute()
+    for _ in range(2):
+        ctx.set_positions_host(xa)
+        compute()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.set_positions_host(xa)
+        compute()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.close()
+    return dt * 1e3
+
+
+def kernel_source_sha():
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "lammps-plugins_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -90,15 +169,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["rebomos", "aeam"], default="rebomos")
     ap.add_argument("--replicate", type=int, nargs=3, default=None)
-    ap.add_argument("--temp", type=float, default=0.0, help="initial temperature (in.rebomos-bulk: 0 K)")
-    ap.add_argument("--check-every", type=int, default=10)
+    ap.add_argument("--temp", type=float, default=0.0, help="initial temperature (in.rebomos-bulk: 0 K; sample.in: 863 K)")
+    ap.add_argument("--check-every", type=int, default=10,
+                    help="several GPUs: steps between the (collective) displacement checks; one GPU checks every step")
+    ap.add_argument("--thermo", type=int, default=None, help="steps between energy/virial tallies (default: the input deck's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-mode", action="store_true")
     ap.add_argument("--inner-skin", type=float, default=None,
                     help="skin of the style's own device-built lists in A (default: library default 1.0, capped by "
                          "the host skin); they are rebuilt on the device when an atom has moved half of it")
     args = ap.parse_args()
     if args.replicate is None:
         args.replicate = [24, 24, 24] if args.workload == "rebomos" else [63, 63, 63]
+    thermo_every = THERMO_EVERY[args.workload] if args.thermo is None else args.thermo
 
     if args.inner_skin is not None:
         os.environ["MDP_INNER_SKIN"] = str(args.inner_skin)
@@ -117,6 +200,7 @@ def main():
     if stage_host:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -124,13 +208,14 @@ def main():
         if stage_host:
             dist.init_process_group(backend, rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t_setup = time.perf_counter()
     s, wname = build_system(args)
     v0 = S.gaussian_velocities(s, args.temp, seed=1082337) if args.temp > 0 else None
     ctx = capi.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    p = None
     if args.workload == "rebomos":
         p = capi.read_rebomos_file(POT_REBOMOS)
         ctx.rebomos_set_params(p)
@@ -143,22 +228,15 @@ def main():
         style, skin, map_ = capi.STYLE_AEAM, 1.0, None
         cutghost = float(af.cut_table(tabs).max()) + skin
         s.mass[1:3] = af.mass[:2]
-    dev = torch.device("cuda", local_rank)
-    dom = resident.make_domain(ctx, style, s, cutghost, skin, map_, v0=v0, dist=dist, device=dev,
-                               stage_host=stage_host and dist is not None)
-    dom.build_neighbors()
-    dom.compute(eflag=1, vflag=1)
+    tr = resident.Transport(dist, dev, stage_host) if dist is not None else None
+    dom = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr)
+    dom.compute(1, 1)
     th = dom.thermo()
     pe0 = th["pe"]
-    rdev = "cpu" if stage_host else "cuda"   # device of the small reduction tensors
-    if dist is not None:
-        t = torch.tensor([th["pe"]], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t)
-        pe0 = float(t.item())
     stats = ctx.md_neighbor_stats()
     if rank == 0:
-        log(f"[bench] {wname}: {s.n} atoms, {world} GPU(s); rank0 nlocal={dom.nlocal} nghost={dom.nghost} "
-            f"master-list/atom={stats[0] / max(dom.nlocal, 1):.1f} PE/atom={pe0 / s.n:.6f} eV "
+        log(f"[bench] {wname}: {s.n} atoms, {world} GPU(s); rank0 nlocal={dom.nlocal} ghosts={dom.nself}+{dom.nrecv} "
+            f"list/atom={stats[0] / max(dom.nlocal, 1):.1f} PE/atom={pe0 / s.n:.6f} eV "
             f"setup {time.perf_counter() - t_setup:.1f}s")
 
     def sync_all():
@@ -166,25 +244,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # several GPUs check the displacement every --check-every steps: trigger early enough for that interval
+    margin = 0.03 * max(args.check_every, 1)
+
     def run(nsteps, step0):
-        """Verlet loop.  Every --check-every steps: `neigh_modify check yes` on the host's skin (max over
-        ranks); when it fires, atoms are re-wrapped / re-assigned and ghosts re-derived (Comm::exchange +
-        borders) before the step.  Multi-GPU REBO-MoS steps overlap the ghost exchange with the interior
-        Lennard-Jones work (RankDomain.step_overlapped)."""
-        nonlocal dom
+        """Verlet loop (Verlet::run): initial_integrate, [reneighbor when `check yes` fires], halo, force (energy /
+        virial every `thermo` steps), final_integrate.  Returns the reneighborings it did."""
         rebuilds = 0
         for k in range(1, nsteps + 1):
-            if args.check_every and (step0 + k) % args.check_every == 0:
-                need = dom.needs_rebuild()
-                if dist is not None:
-                    t = torch.tensor([1.0 if need else 0.0], device=rdev)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    need = bool(t.item() > 0)
-                if need:
-                    dom = resident.reneighbor(dom, s, cutghost, map_, dist=dist, device=dev)
-                    dom.compute(0, 0)      # forces of the current positions for the next half kick
-                    rebuilds += 1
-            dom.step(0, 0)
+            n = step0 + k
+            ev = 1 if thermo_every and n % thermo_every == 0 else 0
+            if dist is None:
+                rebuild = "auto"
+            else:
+                rebuild = bool(args.check_every and n % args.check_every == 0 and dom.needs_rebuild(margin))
+            b0 = dom.builds
+            dom.step(ev, ev, rebuild=rebuild)
+            rebuilds += dom.builds - b0
         return rebuilds
 
     run(args.warmup, 0)
@@ -196,11 +272,11 @@ def main():
     elapsed = time.perf_counter() - t0
     style_builds = ctx.md_neighbor_stats()[7] - style_builds0 if args.workload == "rebomos" else 0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if stage_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel time of the hot path, HIP events on the compute stream (separate pass) ----------
+    # ---- per-kernel time of the hot path: HIP events on the compute stream, force-only steps (separate pass) ----
     ctx.set_timing(True)
     kms = np.zeros(8)
     nmeas = 5
@@ -210,7 +286,7 @@ def main():
     kms /= nmeas
     ctx.set_timing(False)
 
-    dom.compute(eflag=1, vflag=1)
+    dom.compute(1, 1)
     th1 = dom.thermo()
 
     value = s.n * args.steps / elapsed / 1e6
@@ -223,21 +299,32 @@ def main():
         knames = ["aeam_tile_density_kernel+aeam_density_ang_kernel", "aeam_embed_kernel",
                   "aeam_tile_force_kernel+aeam_force_ang_kernel"]
     kdom = int(np.argmax(kms[:len(knames)]))
-    # algorithmic bytes of ONE launch of the dominant kernel: SURVEY 8(d) per-atom figure x atoms per launch
+    # algorithmic bytes of ONE pass of the path over this rank's atoms: SURVEY 8(d) per-atom figure x atoms.
+    # `achieved` / `frac` use the time of ALL kernels of the path (the contract figure is per atom-step of the
+    # whole compute(), not of its longest kernel); the dominant kernel alone is reported beside it.
     alg_bytes = B_ALG[args.workload] * dom.nlocal
-    achieved = alg_bytes / (kms[kdom] * 1e-3) / 1e9 if kms[kdom] > 0 else 0.0
-    # the same bytes over ALL kernels of the path (atom-steps/s x bytes) -- the stricter figure
     kall = float(kms[:len(knames)].sum())
     path_achieved = alg_bytes / (kall * 1e-3) / 1e9 if kall > 0 else 0.0
-    traffic = None
+    kernel_achieved = alg_bytes / (kms[kdom] * 1e-3) / 1e9 if kms[kdom] > 0 else 0.0
+    step_achieved = B_ALG[args.workload] * s.n / world / (ms_per_step * 1e-3) / 1e9
+    flops_path = FLOP_ALG[args.workload] * dom.nlocal / (kall * 1e-3) / 1e12 if kall > 0 else 0.0
+    flops_step = FLOP_ALG[args.workload] * s.n / world / (ms_per_step * 1e-3) / 1e12
+    # HBM traffic from the PMC counters: collected by profiles/pmc_passes.sh in separate rocprofv3 runs and stored
+    # with the hash of the kernel sources it was measured on; a stale entry is not reported
+    traffic, traffic_note = None, "no PMC entry for this configuration"
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
             tab = json.load(open(pmc_file))
             key = f"{args.workload}:{'x'.join(map(str, args.replicate))}:{world}"
-            traffic = tab.get(f"{key}:{knames[kdom]}", tab.get(key))
-        except Exception:
-            traffic = None
+            ent = tab.get(key)
+            if isinstance(ent, dict):
+                if ent.get("kernel_source_sha") == kernel_source_sha():
+                    traffic, traffic_note = ent.get("bytes_per_step"), ent.get("note", "FETCH_SIZE x2 + WRITE_SIZE, path kernels of one step")
+                else:
+                    traffic_note = "PMC entry is stale (kernel sources changed since it was measured)"
+        except Exception:  # noqa: BLE001
+            pass
     out = {
         "metric": "Matom-steps/sec",
         "value": round(value, 4),
@@ -252,31 +339,54 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "ns_per_day": round(args.steps / elapsed * 0.001 * 86.4, 4),
-        "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}", "transport": "rccl" if not stage_host else backend + "-staged (rehearsal)",
-                   "initial_temp_K": args.temp, "skin": skin, "neighbor_rebuilds_in_timed_region": rebuilds,
+        "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}",
+                   "transport": "rccl" if not stage_host else backend + "-staged (rehearsal)",
+                   "initial_temp_K": args.temp, "skin": skin, "thermo_every": thermo_every,
+                   "displacement_check": "every step, deferred on-device flag" if dist is None
+                   else f"every {args.check_every} steps, collective",
+                   "reneighborings_in_timed_region": rebuilds,
                    "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
                                   else "adaptive from 1.0") if args.workload == "rebomos" else None,
                    "style_list_builds_in_timed_region_rank0": int(style_builds),
-                   "pe_per_atom_start_eV": round(pe0 / s.n, 6)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel": knames[kdom],
-                     "kernel_ms": round(float(kms[kdom]), 4),
+                   "pe_per_atom_start_eV": round(pe0 / s.n, 6), "pe_per_atom_end_eV": round(th1["pe"] / s.n, 6),
+                   "temp_end_K": round(th1["temp"], 2)},
+        "roofline": {"bound": "hbm", "achieved": round(path_achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(path_achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
+                     "basis": "algorithmic bytes of one compute() pass / time of ALL kernels of the path "
+                              "(force-only step, HIP events on the compute stream)",
+                     "algorithmic_bytes_per_pass": alg_bytes, "path_ms": round(kall, 4),
                      "all_kernels_ms": {n: round(float(m), 4) for n, m in zip(knames, kms)},
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "path_ms": round(kall, 4), "path_achieved": round(path_achieved, 2),
-                     "path_frac": round(path_achieved / HBM_PEAK_GBPS, 5)},
+                     "dominant_kernel": {"name": knames[kdom], "ms": round(float(kms[kdom]), 4),
+                                         "achieved": round(kernel_achieved, 2),
+                                         "frac": round(kernel_achieved / HBM_PEAK_GBPS, 5)},
+                     "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBPS, 5)},
+                     "fp64": {"bound": "fp64-valu", "flop_per_atom_step": FLOP_ALG[args.workload],
+                              "achieved": round(flops_path, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(flops_path / FP64_PEAK_TFLOPS, 5),
+                              "whole_step_frac": round(flops_step / FP64_PEAK_TFLOPS, 5)}},
     }
+    ctx.close()
+    if rank == 0 and world == 1 and args.workload == "rebomos" and not args.no_host_mode:
+        try:
+            hm = host_mode_rate(s, p, skin, cutghost)
+            out["host_mode_ms_per_step"] = round(hm, 3)
+            out["host_mode_Matom_steps_per_s"] = round(s.n / hm / 1e3, 2)
+        except Exception as e:  # noqa: BLE001 -- informational figure
+            log(f"[bench] host-mode measurement failed: {e}")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(args.workload)
-        cb["value"] = round(cb["value"], 5)
-        out["cpu_baseline"] = cb
-        out["gpu_over_cpu_1core"] = round(value / cb["value"], 1)
+        one, allc = cpu_baseline(args.workload)
+        one["value"] = round(one["value"], 5)
+        out["cpu_baseline"] = one
+        out["gpu_over_cpu_1core"] = round(value / one["value"], 1)
+        if allc is not None:
+            allc["value"] = round(allc["value"], 5)
+            out["cpu_baseline_allcores"] = allc
+            out["gpu_over_cpu_allcores"] = round(value / allc["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -294,12 +294,14 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
 
 // pass 3, pair part (pair_aeam.cpp:309-393), force only: both visits that touch the cluster atom, as in
 // aeam_force_kernel.  LDS record of a union member: x y z q with q = Fptmp*F' of metal neighbours, 0 otherwise.
-template <int CL>
+// EV: also the pair energy (global and per atom) and the global virial of this rank's own visits, tallied exactly
+// as aeam_force_kernel<.., true> does (ev_tally of the visit i = a: pair_aeam.cpp:386-393).
+template <int CL, bool EV>
 __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const double *__restrict__ fp,
     const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
     const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16,
-    double *__restrict__ f)
+    double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag)
 {
   constexpr int L = 16, SK = 3;
   extern __shared__ double s_rec[]; // [capL][4]
@@ -348,13 +350,14 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
   if (tid == 0) s4[nU] = make_double4(1.0e30, 0.0, 0.0, 0.0);
   int ta[CL];
   bool real[CL];
-  double fx[CL], fy[CL], fz[CL];
+  double fx[CL], fy[CL], fz[CL], ea[CL];
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
 #pragma unroll
   for (int c = 0; c < CL; c++) {
     ta[c] = (int) xa[c].w;
     real[c] = have && kc * CL + c < nlocal;
     if (!(ta[c] < A.nnonangular)) qa[c] = 0.0; // (1 - deli): angular centres embed through the three-body kernel
-    fx[c] = fy[c] = fz[c] = 0.0;
+    fx[c] = fy[c] = fz[c] = ea[c] = 0.0;
   }
   __syncthreads();
   const int nm1 = A.nrmax + 1;
@@ -385,10 +388,12 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         if (in_a) {
           double pf;
           const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
-          const double4 *rec = A.pair_d8 + 2 * ((size_t) qA[c].pair * nm1 + m); // same row m for both (pair_aeam.cpp:367)
-          dfa = d4_der(rec[0], pf);
-          const double phip = d4_der(rec[1], pf);
+          const double2 *rec = A.pair_d6 + 3 * ((size_t) qA[c].pair * nm1 + m); // same row m for both (pair_aeam.cpp:367)
+          const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+          dfa = (r0.x * pf + r0.y) * pf + r1.x;
+          const double phip = (r1.y * pf + r2.x) * pf + r2.y;
           fpair_a = -qa[c] * dfa * recip + 0.5 * (-phip * recip);
+          if (EV) ea[c] += 0.5 * v4_val(A.z2r_v4[(size_t) qA[c].tz2r * nm1 + m], pf); // credited to i only
         }
         if (in_j) {
           const double qj = xj.w;
@@ -397,9 +402,10 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
           } else {
             double pf;
             const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
-            const double4 *rec = A.pair_d8 + 2 * ((size_t) qJ[c].pair * nm1 + m);
-            const double dfja = d4_der(rec[0], pf);
-            const double phip = d4_der(rec[1], pf);
+            const double2 *rec = A.pair_d6 + 3 * ((size_t) qJ[c].pair * nm1 + m);
+            const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const double dfja = (r0.x * pf + r0.y) * pf + r1.x;
+            const double phip = (r1.y * pf + r2.x) * pf + r2.y;
             fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
           }
         }
@@ -407,6 +413,14 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         fx[c] -= dx * ft;
         fy[c] -= dy * ft;
         fz[c] -= dz * ft;
+        if (EV) { // ev_tally(i = a, j, ..., fpair_a, d): every rank tallies its own visits
+          v0 += dx * dx * fpair_a;
+          v1 += dy * dy * fpair_a;
+          v2 += dz * dz * fpair_a;
+          v3 += dx * dy * fpair_a;
+          v4 += dx * dz * fpair_a;
+          v5 += dy * dz * fpair_a;
+        }
       }
     }
   };
@@ -418,6 +432,14 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     fy[c] = lane_sum<L>(fy[c]);
     fz[c] = lane_sum<L>(fz[c]);
   }
+  double ev_e = 0.0;
+  if (EV) {
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      ev_e += ea[c];
+      ea[c] = lane_sum<L>(ea[c]);
+    }
+  }
   if (s < CL) {
 #pragma unroll
     for (int c = 0; c < CL; c++)
@@ -426,7 +448,31 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         fo[0] += fx[c];
         fo[1] += fy[c];
         fo[2] += fz[c];
+        if (EV && (eflag & MDP_EFLAG_ATOM)) eatom[kc * CL + c] += ea[c];
       }
+  }
+  if (EV) {
+    double *slot = acc + MDP_ACC_STRIDE * (1 + (blockIdx.x & (MDP_ACC_SLOTS - 1)));
+    if (eflag & MDP_EFLAG_GLOBAL) {
+      ev_e = lane_sum<64>(ev_e);
+      if (lane == 0) atomicAdd(&slot[0], ev_e);
+    }
+    if (vflag & MDP_VFLAG_GLOBAL) {
+      v0 = lane_sum<64>(v0);
+      v1 = lane_sum<64>(v1);
+      v2 = lane_sum<64>(v2);
+      v3 = lane_sum<64>(v3);
+      v4 = lane_sum<64>(v4);
+      v5 = lane_sum<64>(v5);
+      if (lane == 0) {
+        atomicAdd(&slot[1], v0);
+        atomicAdd(&slot[2], v1);
+        atomicAdd(&slot[3], v2);
+        atomicAdd(&slot[4], v3);
+        atomicAdd(&slot[5], v4);
+        atomicAdd(&slot[6], v5);
+      }
+    }
   }
 }
 
@@ -866,26 +912,25 @@ __global__ void relay_kernel(const size_t nrows, const double *__restrict__ src,
   der4[i] = make_double4(c[0], c[1], c[2], 0.0);
 }
 
-// derivative coefficients of rho (c0..c2) and of phi (c0..c2) of ONE pair type side by side in a 64-byte
-// record: the pair-force visit needs both at the same row, and two 32-byte records from different arrays
-// cost two separate 128-byte L1 line fills
+// derivative coefficients of rho (c0..c2) and of phi (c0..c2) of ONE pair type side by side in a 48-byte
+// record: the pair-force visit needs both at the same row.  The tile kernels are bound by the vector L1's
+// lookup rate (~0.9 lookups per clock per CU measured, every lane a different row): a lookup moves at most 16
+// bytes per lane, so six doubles are three lookups -- a padded 64-byte record was four
 __global__ void pair_der_kernel(const int npair, const int nm1, const int *__restrict__ t2rhor,
                                 const int *__restrict__ t2z2r, const double *__restrict__ rhor,
-                                const double *__restrict__ z2r, double *__restrict__ out /* [npair][nm1][8] */)
+                                const double *__restrict__ z2r, double *__restrict__ out /* [npair][nm1][6] */)
 {
   const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t) npair * nm1) return;
   const int pt = (int) (i / nm1), m = (int) (i % nm1);
   const double *a = rhor + ((size_t) t2rhor[pt] * nm1 + m) * 7, *b = z2r + ((size_t) t2z2r[pt] * nm1 + m) * 7;
-  double *o = out + 8 * i;
+  double *o = out + 6 * i;
   o[0] = a[0];
   o[1] = a[1];
   o[2] = a[2];
-  o[3] = 0.0;
-  o[4] = b[0];
-  o[5] = b[1];
-  o[6] = b[2];
-  o[7] = 0.0;
+  o[3] = b[0];
+  o[4] = b[1];
+  o[5] = b[2];
 }
 
 __global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
@@ -932,6 +977,10 @@ int mdp_aeam_prepare(mdp_ctx *c)
     bool ok = false;
     MDP_TRY(mdp_tile_lists_build(c, cutsq, c->aeam_cl, &ok));
     c->aeam_tiled = ok;
+  }
+  if (!c->aeam_tiled && !c->csr_full) { // no tile lists after all (a union outgrew LDS): the CSR kernels need every row
+    c->csr_want_full = true;
+    MDP_TRY(mdp_md_build_master_list(c));
   }
   return MDP_OK;
 }
@@ -992,22 +1041,32 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, st));
   }
-  if (nlocal && c->aeam_tiled && !(eflag || vflag)) { // force-only step: tile lists
+  if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
     const int capL = (c->tile_maxu + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 4 * sizeof(double);
-#define MDP_ATF(CLV)                                                                                                 \
+    const bool ev = eflag || vflag;
+#define MDP_ATF(CLV, EVV)                                                                                            \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV>,                                      \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV, EVV>,                                 \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_force_kernel<CLV><<<c->ntile, 256, lds, st>>>(c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap,   \
-                                                            capL, c->tu.p, c->tile_nu.p, c->lj_off.p, c->lj_split.p,  \
-                                                            c->lj16.p, c->f.p);                                       \
+    aeam_tile_force_kernel<CLV, EVV><<<c->ntile, 256, lds, st>>>(                                                     \
+        c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,           \
+        c->lj_split.p, c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                                        \
   } while (0)
-    if (c->aeam_cl == 1) MDP_ATF(1);
-    else MDP_ATF(2);
+    if (c->aeam_cl == 1) {
+      if (ev) MDP_ATF(1, true);
+      else MDP_ATF(1, false);
+    } else {
+      if (ev) MDP_ATF(2, true);
+      else MDP_ATF(2, false);
+    }
 #undef MDP_ATF
   } else if (nlocal) {
+    if (!c->csr_full) { // first per-atom-virial step of a tiled run: build the rows of the metal atoms now (and from now on)
+      c->csr_want_full = true;
+      MDP_TRY(mdp_md_build_master_list(c));
+    }
     const int grid = nblk(nlocal, 256 / AE_L);
     const bool ev = eflag || vflag;
 #define MDP_AF(NTV, EVV)                                                                                              \
@@ -1088,7 +1147,7 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     A.z2r_d4 = c->aeam_z2r_d4.p;
     // per pair type: {rho' coefficients | phi' coefficients} in one 64-byte record (tile force kernel)
     const int npair = A.ntypes * A.ntypes, nm1 = A.nrmax + 1;
-    MDP_HIP(c, c->aeam_pair_d8.reserve((size_t) npair * nm1 * 8 + 8));
+    MDP_HIP(c, c->aeam_pair_d8.reserve((size_t) npair * nm1 * 6 + 8));
     MDP_HIP(c, c->aeam_maps.reserve(32));
     int h_map[32];
     for (int k = 0; k < 16; k++) {
@@ -1100,7 +1159,7 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
         npair, nm1, c->aeam_maps.p, c->aeam_maps.p + 16, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipStreamSynchronize(c->stream));
-    A.pair_d8 = reinterpret_cast<const double4 *>(c->aeam_pair_d8.p);
+    A.pair_d6 = reinterpret_cast<const double2 *>(c->aeam_pair_d8.p);
   }
   c->have_aeam = true;
   return MDP_OK;

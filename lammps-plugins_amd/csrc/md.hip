@@ -19,6 +19,7 @@ struct CutTables {
   double owned[16]; // cutneighsq[ei*4+ej]  element/type pair
   double ghost[16]; // 0 => no ghost lists
   int ne;           // table stride
+  int min_type;     // owned atoms of a lower type get an empty row (AEAM with tile lists: only angular centres read the CSR list)
 };
 
 using Grid = MdpGrid;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void nbuild_kernel(const Grid g, const CutTabl
   const double4 xi = xq[i];
   const int ti = (int) xi.w;
   const double *tab = (i < nlocal) ? ct.owned : ct.ghost;
-  if (i >= nlocal && ct.ghost[0] <= 0.0) {
+  if ((i >= nlocal && ct.ghost[0] <= 0.0) || (i < nlocal && ti < ct.min_type)) {
     if (!FILL) cnt[i] = 0;
     return;
   }
@@ -340,6 +341,14 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
     if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
     const int nt = c->aeam.ntypes;
     ct.ne = nt;
+    // With tile lists (resident mode, two types) the metal atoms never touch the CSR list: force-only AND energy /
+    // virial steps run the tile kernels.  Only the angular centres (0.75 % in sample.in) read it, so only their
+    // rows are built -- a quarter of the reneighboring time at 1 M atoms.  A per-atom-virial step (CSR kernels)
+    // asks for the full list (c->csr_want_full) and gets it rebuilt on the spot.
+    const char *e = getenv("MDP_AEAM_TILE");
+    const bool tiles = c->md && nt == 2 && !(e && atoi(e) == 0);
+    ct.min_type = (tiles && !c->csr_want_full) ? c->aeam.nnonangular : 0;
+    c->csr_full = ct.min_type == 0;
     for (int a = 0; a < nt; a++)
       for (int b = 0; b < nt; b++) {
         const double cc = c->aeam.cut[a * nt + b] + skin;         // pair_aeam.cpp:618-620 (+ skin)

@@ -94,7 +94,7 @@ struct AeamDev {
   int nrho[4], t2frho[4];
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
-  const double4 *pair_d8; // [ntypes*ntypes][nrmax+1][2]: {rho' c0..c2,0 | phi' c0..c2,0} of the pair type, 64 B per row
+  const double2 *pair_d6; // [ntypes*ntypes][nrmax+1][3]: {rho' c0 c1 | rho' c2, phi' c0 | phi' c1 c2} of the pair type, 48 B per row
 };
 
 // 30-bit key of a cell (10 bits per axis) along a 3-D Hilbert curve (Skilling, "Programming the Hilbert curve":
@@ -266,6 +266,8 @@ struct mdp_ctx {
   int h_ang_count = 0;
   int aeam_cl = 1;                // atoms per cluster of the AEAM tile lists
   bool aeam_tiled = false;        // resident mode, two types: tile lists (tu / lj16 ...) serve the force-only steps
+  bool csr_full = true;           // the CSR list holds rows for every owned atom (false: angular centres only)
+  bool csr_want_full = false;     // a per-atom-virial step ran: keep building the full list
 
   // ---- binning (shared by the master-list builder and the cluster-list builder)
   MdpGrid grid;

@@ -510,6 +510,10 @@ class DeviceDomain:
         final_integrate.  REBO-MoS on several GPUs hides the ghost exchange behind the interior Lennard-Jones work."""
         ctx = self.ctx
         ctx.md_initial_integrate()
+        if isinstance(rebuild, str):        # "auto": one GPU, deferred on-device flag read every step
+            if self.tr is not None:
+                raise ValueError("rebuild='auto' is for one-GPU runs; several ranks decide collectively (needs_rebuild)")
+            rebuild = self.moved()
         if rebuild:
             self.reneighbor()               # the border exchange carries the current positions
         fresh, self.fresh_ghosts = self.fresh_ghosts and rebuild, False
