@@ -179,9 +179,11 @@ typedef struct {
   int nghost_self;    /* ghosts [0,nghost_self) are periodic self-images (refreshed on the device), the rest are
                          remote atoms filled by mdp_md_unpack_x; lists that reach none of the latter need not
                          wait for the halo (mdp_md_compute_begin / _end)                                   */
-  int master_list;    /* rebomos only: 1 = also build the LAMMPS-style full list at 3*rcmax+skin
-                         (log.rebomos-bulk.1:43, for its statistics); the kernels never need it.
-                         aeam always builds its (86-entry) list: the kernels stream it.          */
+  int master_list;    /* 1 = also build the LAMMPS-style full list of every owned atom (rebomos: at 3*rcmax+skin,
+                         log.rebomos-bulk.1:43; aeam: per-type-pair cutoffs + skin, 86 entries/atom) for its
+                         statistics.  By default rebomos builds none (its kernels use the style's own lists) and
+                         aeam with tile lists builds the rows of the angular centres only; a per-atom-virial step
+                         (CSR kernels) switches the full aeam list on by itself.                              */
 } mdp_md_config;
 
 /* upload a sub-domain.  x/v/type/tag: owned atoms [nlocal]; ghosts: ghost_owner[g] = local index

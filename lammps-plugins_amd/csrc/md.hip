@@ -347,7 +347,7 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
     // asks for the full list (c->csr_want_full) and gets it rebuilt on the spot.
     const char *e = getenv("MDP_AEAM_TILE");
     const bool tiles = c->md && nt == 2 && !(e && atoi(e) == 0);
-    ct.min_type = (tiles && !c->csr_want_full) ? c->aeam.nnonangular : 0;
+    ct.min_type = (tiles && !c->csr_want_full && !c->cfg.master_list) ? c->aeam.nnonangular : 0;
     c->csr_full = ct.min_type == 0;
     for (int a = 0; a < nt; a++)
       for (int b = 0; b < nt; b++) {

@@ -47,19 +47,31 @@ def test_rebomos_4m_atoms_known_answers():
     ctx.close()
 
 
-@pytest.mark.timeout(900)
-def test_aeam_1m_atoms_properties():
+def _aeam_domain(ncell, frac, temp, master_list=False):
     af = capi.AeamFile(POT_AEAM)
     tabs = af.build()
     ctx = capi.Context(0)
     ctx.aeam_set_tables(tabs)
-    s = S.fcc_cell(4.045, (63, 63, 63), frac_type2=0.0075, seed=7683797)
-    assert s.n == 1000188
+    s = S.fcc_cell(4.045, (ncell, ncell, ncell), frac_type2=frac, seed=7683797)
     s.mass[1:3] = af.mass
-    v0 = S.gaussian_velocities(s, 863.0, seed=1082337)
+    v0 = S.gaussian_velocities(s, temp, seed=1082337) if temp > 0 else None
     cutghost = float(af.cut_table(tabs).max()) + 1.0
-    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0)
-    d.build_neighbors()
+    d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0, master_list=master_list)
+    d._keep_pot = (af, tabs)
+    return ctx, s, d
+
+
+def _nve(d, nsteps):
+    """Verlet loop with `neigh_modify every 1 check yes` through the deferred device flag (sample.in:17-18)"""
+    for _ in range(nsteps):
+        d.step(0, 0, rebuild="auto")
+
+
+@pytest.mark.timeout(900)
+def test_aeam_1m_atoms_properties():
+    """config #3: 63^3 x 4 = 1 000 188 atoms, 0.75 % Si, 863 K"""
+    ctx, s, d = _aeam_domain(63, 0.0075, 863.0, master_list=True)
+    assert s.n == 1000188
     assert ctx.md_neighbor_stats()[0] / s.n == pytest.approx(85.35, abs=0.3)   # 85.35 entries/atom
     d.compute(eflag=1, vflag=1)
     t0 = d.thermo()
@@ -68,14 +80,52 @@ def test_aeam_1m_atoms_properties():
     f = ctx.md_download(s.n, want=("f",))["f"]
     assert np.abs(f.sum(axis=0)).max() < 1e-7
     e0 = t0["pe"] + t0["ke"]
-    for step in range(1, 41):
-        d.ctx.md_initial_integrate()
-        if step % 10 == 0 and d.needs_rebuild():
-            d = resident.reneighbor(d, s, cutghost, None)
-        d.compute(0, 0)
-        d.ctx.md_final_integrate()
+    b0 = d.builds
+    _nve(d, 60)
+    assert d.builds > b0 and d.dangerous == 0        # hot start: the displacement trigger fired, in time
     d.compute(eflag=1, vflag=0)
     t1 = d.thermo()
     # velocity-Verlet at 863 K from a perfect lattice, dt = 1 fs: O((w dt)^2 KE) ~ 1e-4 eV/atom fluctuation
+    assert abs(t1["pe"] + t1["ke"] - e0) / s.n < 1.5e-4
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_aeam_pe_per_atom_does_not_depend_on_system_size():
+    """pure Al on the perfect lattice: every atom is equivalent, so PE/atom of 4 000 and 1 000 188 atoms must
+    agree to rounding (tile lists, ghost images and reductions scale correctly)"""
+    ctx1, s1, d1 = _aeam_domain(10, 0.0, 0.0)
+    d1.compute(1, 1)
+    e_small = d1.thermo()["pe"] / s1.n
+    ctx1.close()
+    ctx2, s2, d2 = _aeam_domain(63, 0.0, 0.0)
+    d2.compute(3, 1)
+    t = d2.thermo()
+    assert t["pe"] / s2.n == pytest.approx(e_small, rel=1e-11)
+    ea = ctx2.md_download(s2.n, want=("eatom",))["eatom"]
+    assert np.abs(ea - e_small).max() < 1e-10        # and per atom (north star: 1e-6 eV)
+    ctx2.close()
+
+
+@pytest.mark.timeout(1200)
+def test_aeam_16m_atoms_on_one_gpu():
+    """config #5 on ONE GPU: 159^3 x 4 = 16 078 716 atoms, 0.75 % Si, 863 K.  Known answers: the
+    list holds ~85.35 entries per atom, the net force vanishes, PE/atom is that of the 1 M-atom system up to the
+    different random Si placement, and NVE conserves energy across on-device reneighborings."""
+    ctx, s, d = _aeam_domain(159, 0.0075, 863.0, master_list=True)
+    assert s.n == 16078716
+    assert ctx.md_neighbor_stats()[0] / s.n == pytest.approx(85.35, abs=0.3)
+    d.compute(eflag=1, vflag=1)
+    t0 = d.thermo()
+    assert t0["pe"] / s.n == pytest.approx(-3.41225, abs=3e-5)     # 1 M atoms: -3.412263 (another Si placement)
+    assert t0["temp"] == pytest.approx(863.0, rel=1e-9)
+    f = ctx.md_download(s.n, want=("f",))["f"]
+    assert np.abs(f.sum(axis=0)).max() < 1e-6
+    e0 = t0["pe"] + t0["ke"]
+    b0 = d.builds
+    _nve(d, 40)
+    assert d.builds > b0 and d.dangerous == 0
+    d.compute(eflag=1, vflag=0)
+    t1 = d.thermo()
     assert abs(t1["pe"] + t1["ke"] - e0) / s.n < 1.5e-4
     ctx.close()

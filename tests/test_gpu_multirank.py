@@ -60,6 +60,86 @@ def _run(dom, nsteps, dist_mod=None):
     return rows
 
 
+def _worker_device(rank, world, port, style, q):
+    """the path bench.py runs: DeviceDomain + resident.Transport (here on a gloo group, staged through the host),
+    with a forced reneighboring in the middle so that atoms migrate through the torch.distributed all-to-all"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import conftest  # noqa: F401
+    from lammps_plugins_amd.host import resident
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        s, v0 = _build(style)
+        v0 = v0 + np.array([150.0, 40.0, -60.0])          # a drift that carries atoms across the brick faces
+        ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
+        tr = resident.Transport(dist, torch.device("cuda", 0), stage_host=True)
+        dom = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0, transport=tr)
+        dom.compute(1, 1)
+        rows = [dom.thermo()]
+        left = 0
+        for k in range(1, 25):
+            rb = k % 4 == 0
+            dom.step(0, 0, rebuild=rb)
+            if rb:
+                left += ctx.dd_info()["left_last"]
+        dom.compute(1, 1)
+        rows.append(dom.thermo())
+        got = ctx.md_download(dom.nlocal, want=("x", "f"))
+        q.put((rank, dom.tags_local, got["x"], got["f"], [[r["ke"], r["pe"], *r["virial"]] for r in rows], dom.nlocal, left))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_two_ranks_device_domain_over_torch_distributed(style):
+    from lammps_plugins_amd.host import resident, system as S
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker_device, args=(r, 2, port, style, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s, v0 = _build(style)
+    v0 = v0 + np.array([150.0, 40.0, -60.0])
+    ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
+    dom = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0)
+    dom.compute(1, 1)
+    rows = [dom.thermo()]
+    for k in range(1, 25):
+        dom.step(0, 0, rebuild=k % 4 == 0)
+    dom.compute(1, 1)
+    rows.append(dom.thermo())
+    got = ctx.md_download(dom.nlocal, want=("x", "f"))
+    tags = dom.tags_local
+    x1 = np.zeros((s.n, 3)); f1 = np.zeros((s.n, 3))
+    x1[tags - 1] = got["x"]; f1[tags - 1] = got["f"]
+    x2 = np.zeros((s.n, 3)); f2 = np.zeros((s.n, 3))
+    assert sum(r[5] for r in res) == s.n
+    assert sum(r[6] for r in res) > 10                    # atoms changed owner through the all-to-all
+    for rank, tg, x, f, tot, nloc, left in res:
+        x2[tg - 1] = x
+        f2[tg - 1] = f
+    tot = res[0][4]
+    for k in range(2):
+        assert tot[k][1] == pytest.approx(rows[k]["pe"], rel=1e-11)
+        assert tot[k][0] == pytest.approx(rows[k]["ke"], rel=1e-9, abs=1e-12)
+        assert np.allclose(tot[k][2:], rows[k]["virial"], rtol=1e-8, atol=1e-6)
+    dx = x2 - x1
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(f2 - f1).max() < 1e-7
+    ctx.close()
+
+
 def _worker(rank, world, port, style, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
