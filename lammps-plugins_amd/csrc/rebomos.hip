@@ -2660,7 +2660,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag)
   // count from the device and exits)
   int total = 0;
   for (int k = 0; k < MDP_NCLASS; k++) total += c->h_class_count[k];
-  const int grid = total > 0 ? (total / 8 + 1 < 512 ? total / 8 + 1 : 512) : 0;
+  const int grid = total > 0 ? (total / 8 + 1 < 64 ? total / 8 + 1 : 64) : 0; // grid-stride; normally nothing to do
   if (grid)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
                                                             c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,

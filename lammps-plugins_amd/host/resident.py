@@ -340,6 +340,7 @@ class Transport:
     def __init__(self, dist_module, device, stage_host: bool):
         import torch
         self.torch, self.dist, self.device, self.stage_host = torch, dist_module, device, stage_host
+        self.on_gpu = torch.device(device).type == "cuda"
         self.world = dist_module.get_world_size()
         self.rank = dist_module.get_rank()
 
@@ -364,11 +365,13 @@ class Transport:
         if not self.stage_host:
             w = self.dist.all_to_all_single(recv[:nrecv], send[:nsend], outs, ins, async_op=async_op)
             return recv, w
-        torch.cuda.synchronize()
+        if self.on_gpu:
+            torch.cuda.synchronize()
         o, i = recv[:nrecv].cpu(), send[:nsend].cpu()
         self.dist.all_to_all_single(o, i, outs, ins)
         recv[:nrecv].copy_(o)
-        torch.cuda.synchronize()
+        if self.on_gpu:
+            torch.cuda.synchronize()
         return recv, None
 
     def any(self, flag: bool) -> bool:

@@ -132,3 +132,44 @@ def test_plans_are_consistent_for_1_2_4_8_ranks():
             assert [len(p.owned) for p in plans] == [72] * 4  # log.rebomos-bulk.4:72
             # log.rebomos-bulk.4:74-75: "Nghost: 2771.5 ave 2775 max 2768 min", histogram 2 | 2
             assert sorted(len(p.ghost_global) for p in plans) == [2768, 2768, 2775, 2775]
+
+
+# ---- the transport bench.py uses between the bricks (resident.Transport), world_size 2, gloo, CPU tensors -------------
+def _transport_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from lammps_plugins_amd.host import resident
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr = resident.Transport(dist, torch.device("cpu"), stage_host=True)
+        # ragged all-to-all: rank r sends (r + 1) * (q + 2) records of width 3 to rank q (nothing to itself)
+        sc = np.array([(rank + 1) * (q_ + 2) if q_ != rank else 0 for q_ in range(world)], dtype=np.int64)
+        rc = tr.counts(sc)
+        send = torch.cat([torch.full((int(sc[q_]) * 3,), 100.0 * rank + q_, dtype=torch.float64) for q_ in range(world)])
+        recv, _ = tr.exchange(send, sc, rc, 3)
+        flag_any = tr.any(rank == 1)
+        tot = tr.sum([1.0 + rank, 10.0])
+        q.put((rank, rc.tolist(), recv[:int(rc.sum()) * 3].tolist(), flag_any, tot.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transport_ragged_all_to_all_world2():
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_transport_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # rank 0 receives what rank 1 addressed to it: (1 + 1) * (0 + 2) = 4 records of value 100
+    assert res[0][1] == [0, 4] and res[0][2] == [100.0] * 12
+    # rank 1 receives (0 + 1) * (1 + 2) = 3 records of value 1
+    assert res[1][1] == [3, 0] and res[1][2] == [1.0] * 9
+    assert res[0][3] is True and res[1][3] is True
+    assert res[0][4] == [3.0, 20.0] and res[1][4] == [3.0, 20.0]
