@@ -228,7 +228,20 @@ def main():
         style, skin, map_ = capi.STYLE_AEAM, 1.0, None
         cutghost = float(af.cut_table(tabs).max()) + skin
         s.mass[1:3] = af.mass[:2]
-    tr = resident.Transport(dist, dev, stage_host) if dist is not None else None
+    # transport of the bricks' exchanges: "torch" = all-to-all through torch.distributed (RCCL), the default;
+    # MDP_BENCH_TRANSPORT=native = grouped ncclSend/ncclRecv inside libmdpair_hip.so (csrc/comm_rccl.hip; the
+    # process group then only distributes the communicator id)
+    native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "torch") == "native" and not stage_host
+    if dist is None:
+        tr = None
+    elif native:
+        def bcast(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        tr = resident.NativeTransport(world, rank, bcast)
+    else:
+        tr = resident.Transport(dist, dev, stage_host)
     dom = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr)
     dom.compute(1, 1)
     th = dom.thermo()
@@ -340,7 +353,8 @@ def main():
         "data": "synthetic",
         "ns_per_day": round(args.steps / elapsed * 0.001 * 86.4, 4),
         "config": {"workload": wname, "atoms": s.n, "style": args.workload, "parallelism": f"spatial-dd{world}",
-                   "transport": "rccl" if not stage_host else backend + "-staged (rehearsal)",
+                   "transport": ("rccl (library, ncclSend/ncclRecv)" if native else "rccl (torch.distributed all_to_all)")
+                   if not stage_host else backend + "-staged (rehearsal)",
                    "initial_temp_K": args.temp, "skin": skin, "thermo_every": thermo_every,
                    "displacement_check": "every step, deferred on-device flag" if dist is None
                    else f"every {args.check_every} steps, collective",

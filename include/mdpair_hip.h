@@ -255,6 +255,8 @@ typedef struct {
   int procgrid[3];    /* bricks per dimension; rank = (ix*py + iy)*pz + iz */
   int rank;
   double cutghost;    /* ghost-shell width: the host's list cutoff, pair cutoff + skin (log.rebomos-bulk.1:43) */
+  int self_remote;    /* 0.  Testing aid: 1 = periodic self-images are treated as remote ghosts that travel through the
+                         transport to the rank itself (exercises every exchange with a single rank / GPU) */
 } mdp_dd_config;
 
 int mdp_dd_setup(mdp_ctx *ctx, const mdp_dd_config *cfg); /* after mdp_md_setup (owned atoms in any order, ghosts optional) */
@@ -274,6 +276,23 @@ int mdp_dd_forward_scalar_pack(mdp_ctx *ctx, double *d_buf);   /* AEAM fp (pair_
 int mdp_dd_forward_scalar_unpack(mdp_ctx *ctx, const double *d_buf);
 int mdp_dd_reverse_pack(mdp_ctx *ctx, double *d_buf);          /* forces on remote ghosts (AEAM angular terms) */
 int mdp_dd_reverse_unpack(mdp_ctx *ctx, const double *d_buf);  /* += onto the send-list atoms */
+/* ---- the same exchanges done by the library on RCCL (csrc/comm_rccl.hip): for C++ hosts ---------------------------
+ * What LAMMPS' Comm brick does over MPI for the reference (exchange / borders / forward_comm / reverse_comm; "Comm"
+ * is 5.67 % of log.rebomos-bulk.4:67) as grouped ncclSend/ncclRecv between the bricks' GPUs over xGMI.  RCCL is
+ * bound at run time (dlopen of librccl.so.1); MDP_ENOTIMPL if it cannot be loaded.  Rank 0 creates the id, the host
+ * distributes its 128 bytes (MPI_Bcast, a file, ...), every rank calls mdp_dd_comm_init after mdp_dd_setup.  All
+ * calls below are collective over the ranks and run on the context's stream; the per-step position exchange uses
+ * a stream of its own between _begin and _end, so that work launched in between (mdp_md_compute_begin) overlaps it. */
+int mdp_dd_comm_unique_id(void *id128);
+int mdp_dd_comm_init(mdp_ctx *ctx, const void *id128);
+int mdp_dd_comm_destroy(mdp_ctx *ctx);
+int mdp_dd_comm_reneighbor(mdp_ctx *ctx);       /* Comm::exchange + Comm::borders + Neighbor::build */
+int mdp_dd_comm_forward_begin(mdp_ctx *ctx);    /* Comm::forward_comm: x of the send list -> remote ghosts */
+int mdp_dd_comm_forward_end(mdp_ctx *ctx);
+int mdp_dd_comm_forward_scalar(mdp_ctx *ctx);   /* AEAM fp (pair_aeam.cpp:307) */
+int mdp_dd_comm_reverse(mdp_ctx *ctx);          /* Comm::reverse_comm of f (AEAM angular terms) */
+int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 max */);
+
 /* `neigh_modify every 1 delay 0 check yes` (sample.in:17-18, log.rebomos-bulk.1:46) without a host round trip per
  * step: *moved = outcome of the check launched by the PREVIOUS call (0 right after a reneighboring), then a check of
  * the current positions is launched.  Trigger: an owned atom moved more than skin/2 - 0.1 A since the last build

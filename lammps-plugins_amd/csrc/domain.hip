@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void dd_border_kernel(const DdGeom G, const in
             const double w = 1.0 / (double) G.g[d] + 2.0 * G.cutl[d];
             cc[d] = dd_cell10((ls[d] - ((double) bq[d] / (double) G.g[d] - G.cutl[d])) / w);
           }
-          const unsigned long long klass = q == G.rank ? 0ull : (unsigned long long) (q + 1);
+          const unsigned long long klass = (q == G.rank && !G.self_remote) ? 0ull : (unsigned long long) (q + 1);
           key[p] = (klass << 32) | mdp_hilbert30(cc[0], cc[1], cc[2]);
         }
         m++;
@@ -398,6 +398,33 @@ static int dd_require(mdp_ctx *c)
   return MDP_OK;
 }
 
+extern "C" int mdp_dd_comm_destroy(mdp_ctx *c);
+
+void mdp_dd_release(mdp_ctx *c)
+{
+  MdpDomain &D = c->dd;
+  (void) mdp_dd_comm_destroy(c);
+  D.dest.release();
+  D.counters.release();
+  D.idx_a.release();
+  D.idx_b.release();
+  D.ent_atom.release();
+  D.ent_code.release();
+  D.ent_cnt.release();
+  D.ent_off.release();
+  D.sendlist.release();
+  D.type_tmp.release();
+  D.tag_tmp.release();
+  D.key_a.release();
+  D.key_b.release();
+  D.sendshift.release();
+  D.v_tmp.release();
+  D.xq_tmp.release();
+  if (D.ev_moved) (void) hipEventDestroy(D.ev_moved);
+  D.ev_moved = nullptr;
+  D.on = false;
+}
+
 extern "C" {
 
 int mdp_dd_setup(mdp_ctx *c, const mdp_dd_config *cfg)
@@ -439,6 +466,7 @@ int mdp_dd_setup(mdp_ctx *c, const mdp_dd_config *cfg)
     if ((1.0 + 2.0 * G.cutl[d] * G.g[d]) + 1.0 > 12.0)
       return mdp_fail(c, MDP_EINVAL, "mdp_dd_setup: bricks are too thin for the ghost cutoff (dimension %d)", d);
   }
+  G.self_remote = cfg->self_remote ? 1 : 0;
   D.cutghost = cfg->cutghost;
   D.mig_send.assign(G.nranks, 0);
   D.bord_send.assign(G.nranks, 0);
@@ -606,7 +634,8 @@ int mdp_dd_borders_begin(mdp_ctx *c, int *send_counts)
   D.nself = cnt[0];
   D.nsend = nent - D.nself;
   for (int q = 0; q < G.nranks; q++) D.bord_send[q] = cnt[q + 1];
-  if (D.bord_send[G.rank] != 0) return mdp_fail(c, MDP_EINVAL, "dd: internal error (self entries in the send list)");
+  if (D.bord_send[G.rank] != 0 && !G.self_remote)
+    return mdp_fail(c, MDP_EINVAL, "dd: internal error (self entries in the send list)");
   MDP_HIP(c, c->ghost_owner.reserve((size_t) D.nself + 1));
   MDP_HIP(c, c->ghost_shift.reserve((size_t) 3 * D.nself + 3));
   MDP_HIP(c, D.sendlist.reserve((size_t) D.nsend + 1));
@@ -644,7 +673,8 @@ int mdp_dd_borders_end(mdp_ctx *c, const int *recv_counts, const double *d_buf)
   int nrecv = 0;
   for (int q = 0; q < G.nranks; q++) {
     const int r = recv_counts ? recv_counts[q] : 0;
-    if (r < 0 || (q == G.rank && r != 0)) return mdp_fail(c, MDP_EINVAL, "mdp_dd_borders_end: bad receive counts");
+    if (r < 0 || (q == G.rank && r != 0 && !G.self_remote))
+      return mdp_fail(c, MDP_EINVAL, "mdp_dd_borders_end: bad receive counts");
     D.bord_recv[q] = r;
     nrecv += r;
   }

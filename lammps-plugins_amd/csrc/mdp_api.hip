@@ -396,6 +396,7 @@ int mdp_destroy(mdp_ctx *c)
   if (!c) return MDP_OK;
   (void) hipSetDevice(c->device);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
+  mdp_dd_release(c);
   c->aeam_frho.release();
   c->aeam_rhor.release();
   c->aeam_z2r.release();

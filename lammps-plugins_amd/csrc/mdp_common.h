@@ -140,6 +140,7 @@ struct DdGeom {
   int me[3], rank, nranks;
   double cutl[3];       // ghost-shell width in lamda (fractional) units
   int ns[3];            // periodic image shifts tested per dimension: -ns .. ns
+  int self_remote;      // testing: periodic self-images travel through the transport (to the rank itself)
 };
 
 struct MdpDomain {
@@ -157,6 +158,12 @@ struct MdpDomain {
   // deferred displacement trigger of the host-level skin (neigh_modify check yes)
   hipEvent_t ev_moved = nullptr;
   bool moved_pending = false;
+  // RCCL transport inside the library (comm_rccl.hip)
+  void *nccl_comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  DevBuf<double> sbuf, rbuf;
+  DevBuf<int> cnt_dev;
 };
 
 struct mdp_ctx {
@@ -328,6 +335,7 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag);
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
 int mdp_md_build_neighbors_impl(mdp_ctx *c);
+void mdp_dd_release(mdp_ctx *c); // frees everything domain.hip / comm_rccl.hip hold
 int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)

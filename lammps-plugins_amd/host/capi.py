@@ -42,7 +42,7 @@ class MdConfig(C.Structure):
 class DdConfig(C.Structure):
     """mirror of mdp_dd_config"""
     _fields_ = [("boxlo", C.c_double * 3), ("h", C.c_double * 6), ("procgrid", C.c_int * 3), ("rank", C.c_int),
-                ("cutghost", C.c_double)]
+                ("cutghost", C.c_double), ("self_remote", C.c_int)]
 
 
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
@@ -61,6 +61,9 @@ EXPORTS = [
     "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
     "mdp_dd_forward_unpack", "mdp_dd_forward_scalar_pack", "mdp_dd_forward_scalar_unpack", "mdp_dd_reverse_pack",
     "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_download_int", "mdp_md_download_x_all",
+    "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
+    "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
+    "mdp_dd_comm_allreduce",
 ]
 
 
@@ -379,7 +382,7 @@ class Context:
         return list(out)
 
     # ---------------- domain decomposition on the device (csrc/domain.hip)
-    def dd_setup(self, box, procgrid, rank, cutghost):
+    def dd_setup(self, box, procgrid, rank, cutghost, self_remote=False):
         """box: host.system.Box (restricted triclinic); procgrid: bricks per dimension"""
         cfg = DdConfig()
         xy, xz, yz = (float(t) for t in box.tilt)
@@ -388,7 +391,7 @@ class Context:
             cfg.procgrid[d] = int(procgrid[d])
         for k, val in enumerate((box.prd[0], box.prd[1], box.prd[2], yz, xz, xy)):
             cfg.h[k] = float(val)
-        cfg.rank, cfg.cutghost = int(rank), float(cutghost)
+        cfg.rank, cfg.cutghost, cfg.self_remote = int(rank), float(cutghost), 1 if self_remote else 0
         self._ck(self.L.mdp_dd_setup(self.h, C.byref(cfg)))
         self._dd_nranks = int(procgrid[0]) * int(procgrid[1]) * int(procgrid[2])
 
@@ -444,6 +447,37 @@ class Context:
 
     def dd_reverse_unpack(self, d_buf):
         self._ck(self.L.mdp_dd_reverse_unpack(self.h, C.c_void_p(d_buf)))
+
+    # ---------------- RCCL transport inside the library (csrc/comm_rccl.hip)
+    def dd_comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.L.mdp_dd_comm_unique_id(buf)
+        if rc:
+            raise MdpError(rc, "mdp_dd_comm_unique_id failed (RCCL not loadable?)")
+        return buf.raw
+
+    def dd_comm_init(self, id128: bytes):
+        self._ck(self.L.mdp_dd_comm_init(self.h, C.c_char_p(id128)))
+
+    def dd_comm_reneighbor(self):
+        self._ck(self.L.mdp_dd_comm_reneighbor(self.h))
+
+    def dd_comm_forward_begin(self):
+        self._ck(self.L.mdp_dd_comm_forward_begin(self.h))
+
+    def dd_comm_forward_end(self):
+        self._ck(self.L.mdp_dd_comm_forward_end(self.h))
+
+    def dd_comm_forward_scalar(self):
+        self._ck(self.L.mdp_dd_comm_forward_scalar(self.h))
+
+    def dd_comm_reverse(self):
+        self._ck(self.L.mdp_dd_comm_reverse(self.h))
+
+    def dd_comm_allreduce(self, values, op=0):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._ck(self.L.mdp_dd_comm_allreduce(self.h, _dp(v), C.c_int(len(v)), C.c_int(op)))
+        return v
 
     def md_moved_async(self):
         """(moved, dangerous) of the check launched by the previous call; launches the next one"""

@@ -387,6 +387,30 @@ class Transport:
         return t.cpu().numpy()
 
 
+class NativeTransport:
+    """The exchanges done INSIDE the library on RCCL (csrc/comm_rccl.hip: grouped ncclSend/ncclRecv between the
+    bricks' GPUs) -- what a C++ host uses.  Python only bootstraps the communicator: rank 0 creates the 128-byte
+    id, `bcast` hands it to every rank (torch.distributed broadcast, MPI_Bcast, ...)."""
+    native = True
+    stage_host = False
+
+    def __init__(self, world: int, rank: int, bcast=None):
+        self.world, self.rank = world, rank
+        self.bcast = bcast if bcast is not None else (lambda b: b)
+        self.ctx = None
+
+    def attach(self, ctx: capi.Context):
+        uid = ctx.dd_comm_unique_id() if self.rank == 0 else bytes(128)
+        ctx.dd_comm_init(self.bcast(uid))
+        self.ctx = ctx
+
+    def any(self, flag: bool) -> bool:
+        return bool(self.ctx.dd_comm_allreduce([1.0 if flag else 0.0], op=1)[0] > 0)
+
+    def sum(self, values):
+        return self.ctx.dd_comm_allreduce(list(values), op=0)
+
+
 class DeviceDomain:
     """One brick of the periodic box per GPU, all bookkeeping on the device.
 
@@ -394,7 +418,8 @@ class DeviceDomain:
     setup only; nothing global exists afterwards).  transport=None: one GPU, no communication."""
 
     def __init__(self, ctx: capi.Context, style: int, s: S.System, cutghost: float, skin: float, map_, v0=None,
-                 dt: float = 0.001, transport: Transport | None = None, master_list: bool = False):
+                 dt: float = 0.001, transport: Transport | None = None, master_list: bool = False,
+                 self_remote: bool = False):
         from . import decomp
         self.ctx, self.style, self.box, self.skin, self.dt = ctx, style, s.box, skin, dt
         self.tr = transport
@@ -421,12 +446,15 @@ class DeviceDomain:
         for d in range(3):   # provisional: the library sets the bounds of the brick at every reneighboring
             cfg.bbox_lo[d], cfg.bbox_hi[d] = corners[:, d].min() - cutghost - 2.0, corners[:, d].max() + cutghost + 2.0
         e3, e1 = np.zeros((0, 3)), np.zeros(0, dtype=np.int32)
-        if transport is not None and not transport.stage_host:
+        if transport is not None and not transport.stage_host and not getattr(transport, "native", False):
             # pack -> all_to_all -> unpack are only ordered when the context launches on the stream the
             # collectives synchronise with (torch's current stream)
             ctx.set_stream(transport.torch.cuda.current_stream().cuda_stream)
         ctx.md_setup(cfg, x, v, s.type[mine], s.tag[mine], s.mass, map_, e1, e3, e1, e1)
-        ctx.dd_setup(s.box, self.grid, self.rank, cutghost)
+        ctx.dd_setup(s.box, self.grid, self.rank, cutghost, self_remote=self_remote)
+        self.native = bool(getattr(transport, "native", False))
+        if self.native:
+            transport.attach(ctx)
         self.send3 = self.recv3 = self.send1 = self.recv1 = None
         self.builds = 0
         self.dangerous = 0
@@ -438,6 +466,8 @@ class DeviceDomain:
         ctx, tr = self.ctx, self.tr
         if tr is None:
             ctx.dd_reneighbor()
+        elif self.native:
+            ctx.dd_comm_reneighbor()
         else:
             torch = tr.torch
             f64 = dict(dtype=torch.float64, device=tr.device)
@@ -478,6 +508,12 @@ class DeviceDomain:
         return self.tr is not None and (self.nsend or self.nrecv)
 
     def forward_positions(self, async_op=False):
+        if self.native:
+            self.ctx.dd_comm_forward_begin()      # exchange in flight on the library's communication stream
+            if async_op:
+                return "native"
+            self.ctx.dd_comm_forward_end()
+            return None
         self.ctx.dd_forward_pack(self.send3.data_ptr())
         _, w = self.tr.exchange(self.send3, self.send_counts, self.recv_counts, 3, recv=self.recv3, async_op=async_op)
         if async_op:
@@ -485,11 +521,17 @@ class DeviceDomain:
         self.ctx.dd_forward_unpack(self.recv3.data_ptr())
 
     def forward_fp(self):
+        if self.native:
+            self.ctx.dd_comm_forward_scalar()
+            return
         self.ctx.dd_forward_scalar_pack(self.send1.data_ptr())
         self.tr.exchange(self.send1, self.send_counts, self.recv_counts, 1, recv=self.recv1)
         self.ctx.dd_forward_scalar_unpack(self.recv1.data_ptr())
 
     def reverse_forces(self):
+        if self.native:
+            self.ctx.dd_comm_reverse()            # folds the self-images too
+            return
         self.ctx.md_fold_self_ghost_f()
         if not self._active():
             return
@@ -526,9 +568,12 @@ class DeviceDomain:
             work = None if fresh else self.forward_positions(async_op=True)   # pack + all-to-all in flight
             ctx.md_compute_begin(eflag, vflag)
             if not fresh:
-                if work is not None:
-                    work.wait()
-                ctx.dd_forward_unpack(self.recv3.data_ptr())
+                if self.native:
+                    ctx.dd_comm_forward_end()
+                else:
+                    if work is not None:
+                        work.wait()
+                    ctx.dd_forward_unpack(self.recv3.data_ptr())
             ctx.md_compute_end(eflag, vflag)
         else:
             if not fresh:

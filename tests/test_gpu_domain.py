@@ -232,3 +232,60 @@ def test_deferred_displacement_trigger_fires_once_per_need():
     assert fired == [11, 22]
     assert d.dangerous == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
+    """csrc/comm_rccl.hip with a one-rank communicator: `self_remote` sends every periodic self-image through the
+    transport to the rank itself, so border records, the per-step position exchange (on its own stream, overlapped
+    with the interior tiles), AEAM's fp forward and force reverse exchanges and the all-reduce all run through
+    ncclSend / ncclRecv / ncclAllGather / ncclAllReduce on this GPU.  Results must equal the plain one-GPU run."""
+    if style == "rebomos":
+        s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (2, 2, 1)), 0.05, seed=17)
+        v0 = S.gaussian_velocities(s, 300.0, seed=3) + np.array([80.0, -30.0, 20.0])
+        st = capi.STYLE_REBOMOS
+    else:
+        s = S.jitter(S.fcc_cell(4.045, 7, frac_type2=0.05, seed=9), 0.04, seed=10)
+        s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+        v0 = S.gaussian_velocities(s, 600.0, seed=4) + np.array([50.0, 35.0, -40.0])
+        st = capi.STYLE_AEAM
+
+    def run(native):
+        if st == capi.STYLE_REBOMOS:
+            ctx, cutghost = _rebo_ctx()
+            skin, map_ = 2.0, MAP
+        else:
+            ctx = capi.Context(0)
+            af = capi.AeamFile(POT_AEAM)
+            tabs = af.build()
+            ctx.aeam_set_tables(tabs)
+            ctx._af = (af, tabs)
+            skin, map_ = 1.0, None
+            cutghost = float(af.cut_table(tabs).max()) + skin
+        tr = resident.NativeTransport(1, 0) if native else None
+        d = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0, transport=tr, self_remote=native)
+        if native:
+            assert d.nself == 0 and d.nrecv > 0 and d.nsend == d.nrecv     # every ghost travels
+        d.compute(1, 1)
+        th0 = d.thermo()
+        for step in range(1, 21):
+            d.step(0, 0, rebuild=step % 5 == 0)
+        d.compute(1, 1)
+        th = d.thermo()
+        tags, a = _by_tag(d, ("x", "f"))
+        order = np.argsort(tags)
+        ghosts = d.nself + d.nrecv
+        ctx.close()
+        return th0, th, a["x"][order], a["f"][order], ghosts
+
+    p0, p1, px, pf, pg = run(False)
+    n0, n1, nx, nf, ng = run(True)
+    assert ng == pg
+    assert n0["pe"] == pytest.approx(p0["pe"], rel=1e-12)
+    assert np.allclose(n0["virial"], p0["virial"], rtol=1e-10, atol=1e-7)
+    assert n1["pe"] == pytest.approx(p1["pe"], rel=1e-10)
+    assert n1["ke"] == pytest.approx(p1["ke"], rel=1e-9)
+    dx = nx - px
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(nf - pf).max() < 1e-7
