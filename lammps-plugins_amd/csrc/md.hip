@@ -783,8 +783,11 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
   out[3] = c->cand_total;
   out[4] = 0;
   for (int k = 0; k < MDP_NCLASS; k++) out[4] += c->h_class_count[k];
-  out[5] = (long long) c->h_class_count[0] + c->h_class_count[1]; // 4-lane groups, both elements
-  out[6] = (long long) c->h_class_count[4] + c->h_class_count[5] + c->h_class_count[6] + c->h_class_count[7]; // 12/16
+  for (int part = 0; part < 2; part++) {
+    const int *h = c->h_class_count + part * MDP_NCLASS_HALF;
+    out[5] += (long long) h[0] + h[1];               // 4-lane groups, both elements
+    out[6] += (long long) h[4] + h[5] + h[6] + h[7]; // 12- and 16-lane groups
+  }
   out[7] = c->cfg.style == 1 ? c->style_builds : c->h_ang_count;
   return MDP_OK;
 }

@@ -19,8 +19,10 @@
 #define MDP_CLUSTER 2
 #define MDP_ACC_SLOTS 512
 #define MDP_ACC_STRIDE 16
-// REBO centre classes: lane-group size (4, 8, 12, 16, 32) x element
-#define MDP_NCLASS 10
+// REBO centre classes: lane-group size (4, 8, 12, 16, 32) x element, x {interior, boundary}: classes 10..19 hold the
+// centres whose candidate set reaches a REMOTE ghost (multi-GPU runs); the interior ones run while the halo is in flight
+#define MDP_NCLASS 20
+#define MDP_NCLASS_HALF 10
 
 // bytes of device memory currently held by the library's buffers in this process (memory_usage(), pair_rebomos.cpp:1113-1124)
 inline long long &mdp_device_bytes_counter()
@@ -226,7 +228,8 @@ struct mdp_ctx {
   int nclus = 0, cluster = MDP_CLUSTER;
   // halo overlap (multi-GPU): clusters whose lists reach no remote ghost come first in cl_order
   int remote_start = 1 << 30;
-  bool split_halo = false;
+  bool split_halo = false;        // Lennard-Jones tiles split interior / boundary (MDP_HALO_OVERLAP=lj)
+  bool centre_split = false;      // REBO centres split interior / boundary (default with remote ghosts)
   DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
   // Lennard-Jones tile lists (default): the MDP_TILE consecutive clusters one workgroup handles share

@@ -2072,7 +2072,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
                                                        const double4 *__restrict__ xq,
                                                        const int *__restrict__ cand_off, const int *__restrict__ cand,
                                                        const int *__restrict__ is_centre, int *__restrict__ class_list,
-                                                       int *__restrict__ class_count)
+                                                       int *__restrict__ class_count, const int remote_start)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -2081,14 +2081,18 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
     const double4 xi = xq[i];
     const int ti = (int) xi.w;
     int n = 0;
+    bool bnd = i >= remote_start; // the centre or one of its candidates is a remote ghost: needs this step's halo
     for (int q = cand_off[i]; q < cand_off[i + 1]; q++) {
-      const double4 xj = xq[cand[q]];
+      const int j = cand[q];
+      bnd = bnd || j >= remote_start;
+      const double4 xj = xq[j];
       const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
       n += (dx * dx + dy * dy + dz * dz) < P.rcmaxsq[ti * 2 + (int) xj.w];
     }
     // smallest lane group that holds the current coordination (one lane per neighbour, some to spare)
     k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 12) ? 2 : (n <= 14) ? 3 : 4; // groups of 4, 8, 12, 16, 32 lanes
     k = 2 * k + (ti != 0); // classes are per (lane-group size, element): the element is then uniform per launch
+    if (bnd) k += MDP_NCLASS_HALF;
   }
 #pragma unroll
   for (int kk = 0; kk < MDP_NCLASS; kk++) {
@@ -2241,7 +2245,13 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
-  MDP_HIP(c, c->class_list.reserve((size_t) MDP_NCLASS * nall + 8));
+  // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost (default) or, with
+  // MDP_HALO_OVERLAP=lj, behind the Lennard-Jones tiles that reach none (the round-1 scheme, kept for comparison)
+  const bool remote_any = c->md && c->remote_start < nall;
+  const char *eov = getenv("MDP_HALO_OVERLAP");
+  const bool centre_split = remote_any && !(eov && !strcmp(eov, "lj"));
+  c->centre_split = centre_split;
+  MDP_HIP(c, c->class_list.reserve((size_t) (centre_split ? MDP_NCLASS : MDP_NCLASS_HALF) * nall + 8));
   MDP_HIP(c, c->class_count.reserve(MDP_NCLASS));
   MDP_HIP(c, c->xhold_all.reserve((size_t) 3 * nall + 3));
   MDP_HIP(c, hipMemsetAsync(c->is_center.p, 0, sizeof(int) * nall, st));
@@ -2377,7 +2387,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
   if (const char *e = getenv("MDP_TILE_SMALL")) kSmallUnion = atoi(e) > 0 ? atoi(e) : kSmallUnion; // (tests)
   c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
-  const bool remote = c->md && c->remote_start < nall;
+  const bool remote = remote_any && !centre_split; // Lennard-Jones units classified interior / boundary
   if (nunit > 0 && (remote || (tiled && c->tile_maxu > kSmallUnion))) {
     MDP_HIP(c, c->cl_flag.reserve((size_t) 6 * (nunit + 1)));
     MDP_HIP(c, c->cl_pos.reserve((size_t) 4 * (nunit + 2)));
@@ -2410,7 +2420,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
   if (nall)
     classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
-                                                        c->is_center.p, c->class_list.p, c->class_count.p);
+                                                        c->is_center.p, c->class_list.p, c->class_count.p,
+                                                        centre_split ? c->remote_start : 0x7fffffff);
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
@@ -2429,13 +2440,14 @@ int mdp_rebomos_repack(mdp_ctx *c)
     size_t total = 0;
     for (int k = 0; k < MDP_NCLASS; k++) {
       c->pk_base[k] = total;
-      total += (size_t) c->h_class_count[k] * width[k / 2];
+      total += (size_t) c->h_class_count[k] * width[(k % MDP_NCLASS_HALF) / 2];
     }
     MDP_HIP(c, c->pk_cand.reserve(total + 1));
     for (int k = 0; k < MDP_NCLASS; k++) {
-      const long long n = (long long) c->h_class_count[k] * width[k / 2];
+      const int w = width[(k % MDP_NCLASS_HALF) / 2];
+      const long long n = (long long) c->h_class_count[k] * w;
       if (n > 0)
-        pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], width[k / 2],
+        pack_cand_kernel<<<(unsigned) ((n + 255) / 256), 256, 0, st>>>(c->h_class_count[k], w,
                                                                        c->class_list.p + (size_t) k * nall,
                                                                        c->cand_off.p, c->cand.p,
                                                                        c->pk_cand.p + c->pk_base[k]);
@@ -2573,10 +2585,10 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
 }
 
 template <int G>
-static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag)
+static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
 {
   for (int elem = 0; elem < 2; elem++) {
-    const int k = 2 * kg + elem;
+    const int k = 2 * kg + elem + part * MDP_NCLASS_HALF; // part 0: interior centres, 1: boundary centres
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
     constexpr int per_block = CentreCfg<G>::WPB * CentreCfg<G>::GPW;
@@ -2648,14 +2660,20 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
   return MDP_OK;
 }
 
-static int launch_centres(mdp_ctx *c, int eflag, int vflag)
+// parts: bit 0 = interior centres, bit 1 = boundary centres (+ the overflow pass, which must follow both)
+static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
 {
   hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
-  launch_centre<4>(c, 0, eflag, vflag);
-  launch_centre<8>(c, 1, eflag, vflag);
-  launch_centre<12>(c, 2, eflag, vflag);
-  launch_centre<16>(c, 3, eflag, vflag);
-  launch_centre<32>(c, 4, eflag, vflag);
+  for (int part = 0; part < 2; part++) {
+    if (!((parts >> part) & 1)) continue;
+    launch_centre<4>(c, 0, eflag, vflag, part);
+    launch_centre<8>(c, 1, eflag, vflag, part);
+    launch_centre<12>(c, 2, eflag, vflag, part);
+    launch_centre<16>(c, 3, eflag, vflag, part);
+    launch_centre<32>(c, 4, eflag, vflag, part);
+  }
+  MDP_HIP(c, hipGetLastError());
+  if (!(parts & 2)) return MDP_OK;
   // centres that outgrew their lane group since the last build (normally none: the kernel reads the
   // count from the device and exits)
   int total = 0;
@@ -2688,7 +2706,8 @@ static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
 }
 
 // First half of compute(): everything that does not need this step's REMOTE ghost positions -- the list
-// upkeep and the Lennard-Jones work of the interior clusters.  Runs while the halo exchange is in flight.
+// upkeep and the REBO centres whose candidate sets reach no remote ghost (or, MDP_HALO_OVERLAP=lj, the
+// Lennard-Jones work of the interior tiles).  Runs while the halo exchange is in flight.
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 {
   c->computes_since_build++;
@@ -2710,12 +2729,13 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
   }
   if (c->split_halo)
     for (int k = 0; k < 2; k++) MDP_TRY(launch_lj(c, k, /*gather=*/false, eflag, vflag, /*accumulate=*/false));
+  if (c->centre_split && !(vflag & MDP_VFLAG_ATOM)) MDP_TRY(launch_centres(c, eflag, vflag, /*interior*/ 1));
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
 
-// Second half: REBO centre kernels, boundary clusters, slot-force gather (or, without remote ghosts, the
-// fused Lennard-Jones + gather kernel over all clusters).
+// Second half: the remaining REBO centres, then the fused Lennard-Jones + slot-gather kernel over all tiles
+// (MDP_HALO_OVERLAP=lj: all centres, boundary tiles, and the slot gather as a kernel of its own).
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
@@ -2723,7 +2743,7 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
   if (va)
     MDP_TRY(launch_centres_vatom(c, eflag, vflag));
   else
-    MDP_TRY(launch_centres(c, eflag, vflag));
+    MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
   mdp_time_mark(c, 1);
   if (c->split_halo || va) {
     for (int k = c->split_halo ? 2 : 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));

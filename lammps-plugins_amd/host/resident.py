@@ -305,6 +305,11 @@ def make_domain(ctx, style, s: S.System, cutghost, skin, map_, v0=None, dt=0.001
         d.natoms_total = s.n
         return d
     from . import decomp
+    if not stage_host:
+        # pack -> all_to_all -> unpack are only ordered when the context launches on the stream the collectives
+        # synchronise with (torch's current stream)
+        import torch
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     xw = S.wrap(s.box, s.x)
     dec = decomp.Decomposition(s.box, xw, dist.get_world_size(), cutghost, type_=s.type)
     plan = dec.plan(dist.get_rank())

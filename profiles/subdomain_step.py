@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Device time of ONE step of ONE of the eight sub-domains of the 8-GPU headline run (REBO-MoS bulk, 24x24x24 replica
+= 3,981,312 atoms, 2x2x2 bricks), measured on one GPU: all eight bricks are set up as threads of this process
+(resident.ThreadTransport), then rank 0 alone steps -- pack, interior Lennard-Jones, unpack, centre kernels, boundary
+tiles, gather, integrator -- against the ghost positions of the last exchange while the other ranks wait.  What the
+timeline cannot show is the wire time of the all-to-all itself (5.1 MB per GPU and step), which the
+real run overlaps with the interior tiles.
+usage: rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/subdomain_step.py [nrep] [steps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+
+entry.load_package()
+from lammps_plugins_amd.host import capi, resident, system as S
+
+nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+pot = os.path.join(ROOT, "tests", "golden", "potentials", "MoS.REBO.set5b")
+s = S.replicate(S.rebomos_bulk_cell(), (nrep, nrep, nrep))
+out = {}
+
+
+def rank_fn(r, make_tr):
+    import torch
+    ctx = capi.Context(0)
+    p = capi.read_rebomos_file(pot)
+    ctx.rebomos_set_params(p)
+    cutghost = 3.0 * p.rcmax[0][0] + 2.0
+    tr = make_tr(ctx)
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, [0, 0, 1], transport=tr)
+    d.compute(1, 1)
+    th = d.thermo()
+    for _ in range(3):
+        d.step(0, 0)                      # real steps with exchanges: everything is warm
+    tr.sh.barrier.wait()
+    if r == 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):            # rank 0 alone; ghosts keep the positions of the last exchange
+            ctx.md_initial_integrate()
+            ctx.dd_forward_pack(d.send3.data_ptr())
+            ctx.md_compute_begin(0, 0)
+            ctx.dd_forward_unpack(d.recv3.data_ptr())
+            ctx.md_compute_end(0, 0)
+            ctx.md_final_integrate()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        out.update(atoms_total=s.n, nlocal=d.nlocal, self_ghosts=d.nself, remote_ghosts=d.nrecv, send_entries=d.nsend,
+                   halo_bytes_each_way=int(d.nsend * 24), pe_per_atom=th["pe"] / s.n, steps=steps,
+                   ms_per_step_rank0_alone=round(dt * 1e3, 4))
+    tr.sh.barrier.wait()
+    ctx.close()
+    return None
+
+
+resident.run_ranks(8, rank_fn)
+print(json.dumps(out))
