@@ -546,9 +546,10 @@ int mdp_md_initial_integrate(mdp_ctx *c)
   if (c->nlocal)
     nve_initial_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p,
                                                                c->xq.p);
-  if (c->nghost)
-    ghost_refresh_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
-                                                                 c->ghost_shift.p, c->xq.p);
+  // periodic self-images come first in the ghost range; remote ghosts are refreshed by the halo exchange
+  const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
+  if (nself)
+    ghost_refresh_kernel<<<nblk(nself), 256, 0, c->stream>>>(c->nlocal, nself, c->ghost_owner.p, c->ghost_shift.p, c->xq.p);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }

@@ -254,3 +254,43 @@ def test_device_bytes_are_reported():
     ctx.rebomos_compute_host(nloc)
     assert ctx.device_bytes() > before + 24.0 * len(xa)                # at least the coordinates
     ctx.close()
+
+
+@gpu
+@pytest.mark.parametrize("register", ["0", "1"])
+def test_host_reallocates_x_between_steps(register, monkeypatch):
+    """LAMMPS re-allocates atom->x when nmax grows (memory->grow at migration): every step here hands over a NEW
+    array -- sometimes at the address of one just freed -- in the default staged mode and with in-place
+    registration (MDP_HOST_REGISTER=1, arrays >= 8 MB, mdp_host_release before the free).  Forces must follow the
+    positions actually handed over (stale registrations keyed by pointer)."""
+    monkeypatch.setenv("MDP_HOST_REGISTER", register)
+    ctx = capi.Context(0)
+    ctx.rebomos_set_params(capi.read_rebomos_file(POT_REBOMOS))
+    s = S.replicate(S.rebomos_bulk_cell(), (11, 11, 11))            # 383 k atoms + ghosts: x is > 8 MB
+    xa, ta, ga, owner, shift, nloc, ngh = S.with_ghosts(s, 13.4)
+    ctx.set_atoms_host(nloc, xa, ta, ga, 2, map_=[0, 0, 1])
+    ctx.set_skin(2.0)
+    f0 = ctx.rebomos_compute_host(nloc, eflag=0, vflag=0)["f"]
+    L = capi.lib()
+    rng = np.random.default_rng(1)
+    disp = np.zeros_like(xa)
+    for step in range(3):
+        d_owned = 0.02 * rng.standard_normal((nloc, 3))
+        disp[:nloc] += d_owned
+        disp[nloc:] = disp[owner]
+        xnew = np.ascontiguousarray(xa + disp)                     # a fresh allocation every step
+        ctx.set_positions_host(xnew)
+        f = ctx.rebomos_compute_host(nloc, eflag=0, vflag=0)["f"]
+        if register == "1":
+            assert L.mdp_host_release(ctx.h, capi.C.c_void_p(xnew.ctypes.data)) == 0
+        del xnew
+    # reference: a fresh context given the final positions at once
+    ctx2 = capi.Context(0)
+    ctx2.rebomos_set_params(capi.read_rebomos_file(POT_REBOMOS))
+    ctx2.set_atoms_host(nloc, xa + disp, ta, ga, 2, map_=[0, 0, 1])
+    ctx2.set_skin(2.0)
+    fref = ctx2.rebomos_compute_host(nloc, eflag=0, vflag=0)["f"]
+    assert np.abs(f - fref).max() < 1e-9
+    assert np.abs(f - f0).max() > 1e-3                             # and they really changed
+    ctx.close()
+    ctx2.close()

@@ -162,7 +162,7 @@ def test_four_bricks_match_the_reference_4_rank_log(log):
     assert r["th"]["press"] == pytest.approx(ref20["press"], abs=5.1e-3)
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 3, 6, 8])
 def test_bricks_with_migration_follow_the_one_rank_trajectory(world):
     """3x3x2 replica (5184 atoms) at 300 K with a uniform drift of 60 A/ps on top: atoms stream through brick
     and box faces (Galilean invariance: the physics is that of the run at rest).  Reneighboring is forced every
