@@ -299,6 +299,13 @@ def main():
     kms /= nmeas
     ctx.set_timing(False)
 
+    # ---- one forced reneighboring (remap, migration, ghosts, lists; collective), wall time incl. its host syncs ----
+    sync_all()
+    t0 = time.perf_counter()
+    dom.reneighbor()
+    sync_all()
+    reneighbor_ms = (time.perf_counter() - t0) * 1e3
+
     dom.compute(1, 1)
     th1 = dom.thermo()
 
@@ -358,7 +365,7 @@ def main():
                    "initial_temp_K": args.temp, "skin": skin, "thermo_every": thermo_every,
                    "displacement_check": "every step, deferred on-device flag" if dist is None
                    else f"every {args.check_every} steps, collective",
-                   "reneighborings_in_timed_region": rebuilds,
+                   "reneighborings_in_timed_region": rebuilds, "reneighbor_wall_ms": round(reneighbor_ms, 3),
                    "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
                                   else "adaptive from 1.0") if args.workload == "rebomos" else None,
                    "style_list_builds_in_timed_region_rank0": int(style_builds),

@@ -196,6 +196,7 @@ struct mdp_ctx {
   std::vector<std::pair<const void *, size_t>> host_regs; // host arrays page-locked in place (large x arrays)
   char *h_up[2] = {nullptr, nullptr};          // pinned upload staging (double-buffered chunks)
   hipEvent_t ev_up[2] = {nullptr, nullptr};
+  hipEvent_t ev_down[8] = {};                  // chunked force download (host mode)
   double *h_down = nullptr;     // pinned download buffer
   size_t h_down_cap = 0;
   DevBuf<int> tag, type;

@@ -350,13 +350,17 @@ class Transport:
         self.rank = dist_module.get_rank()
 
     def counts(self, send_counts: np.ndarray) -> np.ndarray:
-        """recv[q] = what rank q sends to me"""
+        """recv[q] = what rank q sends to me.  Every rank gathers the whole count matrix (world^2 integers), so it
+        also knows whether ANY rank has something to send: an exchange that is empty everywhere is skipped by all
+        ranks alike (no collective is ever issued with empty tensors on every rank)."""
         torch = self.torch
         dev = "cpu" if self.stage_host else self.device
         s = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=dev)
-        r = torch.empty_like(s)
-        self.dist.all_to_all_single(r, s)
-        return r.cpu().numpy()
+        rows = [torch.empty_like(s) for _ in range(self.world)]
+        self.dist.all_gather(rows, s)
+        m = torch.stack(rows).cpu().numpy()          # m[q][r]: rank q -> rank r
+        self.last_total = int(m.sum())
+        return m[:, self.rank].copy()
 
     def exchange(self, send, send_counts, recv_counts, width: int, recv=None, async_op=False):
         """send: flat float64 device tensor of sum(send_counts)*width; returns (recv tensor, work or None)"""
@@ -367,6 +371,8 @@ class Transport:
         ins = [int(c) * width for c in send_counts]
         outs = [int(c) * width for c in recv_counts]
         nsend = sum(ins)
+        if getattr(self, "last_total", 1) == 0 and nsend == 0 and nrecv == 0:
+            return recv, None                    # nothing travels anywhere (decided from the gathered count matrix)
         if not self.stage_host:
             w = self.dist.all_to_all_single(recv[:nrecv], send[:nsend], outs, ins, async_op=async_op)
             return recv, w

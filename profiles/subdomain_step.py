@@ -39,8 +39,17 @@ def rank_fn(r, make_tr):
     th = d.thermo()
     for _ in range(3):
         d.step(0, 0)                      # real steps with exchanges: everything is warm
+    # one full reneighboring of all eight bricks (collective): wall time on this shared GPU, an upper bound
+    torch.cuda.synchronize()
+    tr.sh.barrier.wait()
+    tre = time.perf_counter()
+    d.reneighbor()
+    ctx.sync()
+    tre = time.perf_counter() - tre
+    d.compute(0, 0)
     tr.sh.barrier.wait()
     if r == 0:
+        out["reneighbor_wall_ms_8_bricks_sharing_one_gpu"] = round(tre * 1e3, 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):            # rank 0 alone; ghosts keep the positions of the last exchange
