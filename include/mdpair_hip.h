@@ -140,6 +140,17 @@ int mdp_set_skin(mdp_ctx *ctx, double skin);
  * any difference.  Call at every reneighboring after mdp_set_atoms_host.  MDP_SKIP_LIST_CHECK=1 disables it. */
 int mdp_rebomos_check_host_list(mdp_ctx *ctx, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
                                 double cutneigh);
+/* aeam, host mode: 1 = the style builds its lists on the device from the positions, exactly as rebomos does
+ * (bins, tile lists, CSR rows of the angular centres) and the host only reports its skin (mdp_set_skin) at every
+ * reneighboring; the device keeps its own Hilbert-sorted copy of the atoms and returns results in the host's order.
+ * The host's list is then not read -- flattening its 86 entries per atom on a host thread and uploading them cost
+ * more than ten steps per reneighboring at a million atoms -- so, as for rebomos, a list that is not the plain
+ * geometric one must be refused: mdp_aeam_check_host_list (per-type-pair cutoffs cut[ti][tj] + skin,
+ * pair_aeam.cpp:615-621).  Call before mdp_set_atoms_host.  0 (default) = stream the host's list
+ * (mdp_set_neighbors_host), the reference's own data flow (pair_aeam.cpp:150-153). */
+int mdp_aeam_device_lists(mdp_ctx *ctx, int on);
+int mdp_aeam_check_host_list(mdp_ctx *ctx, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
+                             double skin);
 /* same as mdp_set_neighbors_host, from a CSR copy (tests / hosts that already hold a flat list): offset[nall+1] */
 int mdp_set_neighbors_csr_host(mdp_ctx *ctx, int nall, const int *numneigh, const long long *offset,
                                const int *neigh, double skin);

@@ -964,7 +964,7 @@ int mdp_aeam_prepare(mdp_ctx *c)
   // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
   c->aeam_tiled = false;
   const char *e = getenv("MDP_AEAM_TILE");
-  if (c->md && c->aeam.ntypes == 2 && c->nlocal > 0 && !(e && atoi(e) == 0)) {
+  if ((c->md || c->aeam_device_lists) && c->aeam.ntypes == 2 && c->nlocal > 0 && !(e && atoi(e) == 0)) {
     double cutsq[4];
     for (int ti = 0; ti < 2; ti++)
       for (int tj = 0; tj < 2; tj++) { // either visit of the pair may need it
@@ -1183,7 +1183,9 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
 {
   if (!c) return MDP_EINVAL;
   if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
-  if (!c->atoms_set || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
+  const bool own_lists = c->aeam_device_lists && c->host_sort; // lists built here from the positions (as rebomos)
+  if (!c->atoms_set || (!own_lists && !c->neigh_set) || (own_lists && !c->skin_set))
+    return mdp_fail(c, MDP_ESTATE, "atoms / neighbor list not set");
   if (c->nlocal == 0) { // no owned atoms on this rank: nothing to tally, the host's arrays may be NULL
     c->rebo_packed = true;
     return MDP_OK;
@@ -1191,6 +1193,18 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
   if (!fp) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_density_host: fp missing for %d owned atoms", c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   if (!c->rebo_packed) { // reuse the flag: "style structures follow the current list"
+    if (own_lists) {
+      // the host's list is not read (the flattening of 86 M entries per million atoms on one host thread cost more
+      // than ten steps): bins, the CSR rows of the angular centres and the tile lists come from the positions
+      c->cfg.style = 2;
+      c->cfg.skin = c->skin;
+      c->cfg.master_list = 0;
+      for (int d = 0; d < 3; d++) {
+        c->cfg.bbox_lo[d] = c->bbox_lo[d];
+        c->cfg.bbox_hi[d] = c->bbox_hi[d];
+      }
+      MDP_TRY(mdp_md_build_master_list(c));
+    }
     MDP_TRY(mdp_aeam_prepare(c));
     c->rebo_packed = true;
   }
@@ -1201,9 +1215,20 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
   const int n = c->nlocal;
   MDP_TRY(mdp_host_pinned_reserve(c, (size_t) n + 16));
   double *he = c->h_down;
-  MDP_HIP(c, hipMemcpyAsync(fp, c->fp.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  if (rho) MDP_HIP(c, hipMemcpyAsync(rho, c->rho.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  const double *dfp = c->fp.p, *drho = c->rho.p, *dea = c->eatom.p;
+  if (c->host_sort) { // back to the host's atom order
+    MDP_HIP(c, c->host_stage.reserve((size_t) 10 * c->nall + 16));
+    double *s0 = c->host_stage.p, *s1 = s0 + n, *s2 = s1 + n;
+    MDP_TRY(mdp_to_host_order(c, n, 1, c->fp.p, s0));
+    MDP_TRY(mdp_to_host_order(c, n, 1, c->rho.p, s1));
+    if (eflag & MDP_EFLAG_ATOM) MDP_TRY(mdp_to_host_order(c, n, 1, c->eatom.p, s2));
+    dfp = s0;
+    drho = s1;
+    dea = s2;
+  }
+  MDP_HIP(c, hipMemcpyAsync(fp, dfp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (rho) MDP_HIP(c, hipMemcpyAsync(rho, drho, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, dea, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, nullptr));
   if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) n);
   return MDP_OK;
@@ -1223,7 +1248,11 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   hipStream_t st = c->stream;
   const int n = c->nlocal, nall = c->nall;
   // ghosts' fp come from the host's forward comm; owned values are already on the device
-  if (nall > n)
+  if (c->host_sort) { // the host's array is in its own atom order: whole array up, then into device order
+    MDP_HIP(c, c->host_stage.reserve((size_t) 10 * nall + 16));
+    MDP_HIP(c, hipMemcpyAsync(c->host_stage.p, fp_all, sizeof(double) * nall, hipMemcpyHostToDevice, st));
+    MDP_TRY(mdp_to_device_order(c, nall, 1, c->host_stage.p, c->fp.p));
+  } else if (nall > n)
     MDP_HIP(c, hipMemcpyAsync(c->fp.p + n, fp_all + n, sizeof(double) * (nall - n), hipMemcpyHostToDevice, st));
   MDP_TRY(mdp_acc_begin(c, true));
   MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * n, st));
@@ -1231,10 +1260,24 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   // results come back through the pinned buffer and are ADDED on the host (LAMMPS semantics; ghosts included)
   MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nall + 16));
   double *hf = c->h_down, *he = hf + (size_t) 3 * nall, *hv = he + nall;
-  MDP_HIP(c, hipMemcpyAsync(hf, c->f.p, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
-  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, c->eatom.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  const double *df = c->f.p, *de = c->eatom.p, *dv = c->vatom.p;
+  if (c->host_sort) {
+    double *s0 = c->host_stage.p, *s1 = s0 + (size_t) 3 * nall, *s2 = s1 + nall;
+    MDP_TRY(mdp_to_host_order(c, nall, 3, c->f.p, s0));
+    df = s0;
+    if (eflag & MDP_EFLAG_ATOM) {
+      MDP_TRY(mdp_to_host_order(c, n, 1, c->eatom.p, s1));
+      de = s1;
+    }
+    if (vflag & MDP_VFLAG_ATOM) {
+      MDP_TRY(mdp_to_host_order(c, nall, 6, c->vatom.p, s2));
+      dv = s2;
+    }
+  }
+  MDP_HIP(c, hipMemcpyAsync(hf, df, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
+  if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, de, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (vflag & MDP_VFLAG_ATOM)
-    MDP_HIP(c, hipMemcpyAsync(hv, c->vatom.p, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipMemcpyAsync(hv, dv, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
   if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nall);
   mdp_host_add(f, hf, (size_t) 3 * nall);

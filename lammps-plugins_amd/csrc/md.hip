@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void nbuild_kernel(const Grid g, const CutTabl
 // Number of (i owned, j != i) pairs with rsq <= cutsq, both atoms of a mapped (non-NULL) type: what a plain
 // geometric full list of the host holds for its owned rows.  rsq is formed exactly as LAMMPS' builders form it
 // (delx*delx + dely*dely + delz*delz, no fused multiply-add), so the count is comparable entry for entry.
-__global__ __launch_bounds__(256) void host_list_count_kernel(const Grid g, const double cutsq, const int nall,
+__global__ __launch_bounds__(256) void host_list_count_kernel(const Grid g, const CutTables ct, const int nall,
                                                               const int nlocal, const double4 *__restrict__ xq,
                                                               const int *__restrict__ perm,
                                                               const int *__restrict__ cell_start,
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void host_list_count_kernel(const Grid g, cons
             const double4 xj = xq[j];
             const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
             const double rsq = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-            n += (rsq <= cutsq && j != i && xj.w >= 0.0) ? 1u : 0u;
+            const int tj = xj.w >= 0.0 ? (int) xj.w : 0;
+            n += (rsq <= ct.owned[(int) xi.w * ct.ne + tj] && j != i && xj.w >= 0.0) ? 1u : 0u;
           }
         }
     }
@@ -346,7 +347,7 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
     // rows are built -- a quarter of the reneighboring time at 1 M atoms.  A per-atom-virial step (CSR kernels)
     // asks for the full list (c->csr_want_full) and gets it rebuilt on the spot.
     const char *e = getenv("MDP_AEAM_TILE");
-    const bool tiles = c->md && nt == 2 && !(e && atoi(e) == 0);
+    const bool tiles = (c->md || c->aeam_device_lists) && nt == 2 && !(e && atoi(e) == 0);
     ct.min_type = (tiles && !c->csr_want_full && !c->cfg.master_list) ? c->aeam.nnonangular : 0;
     c->csr_full = ct.min_type == 0;
     for (int a = 0; a < nt; a++)
@@ -698,6 +699,28 @@ int mdp_md_upload_x(mdp_ctx *c, const double *x)
   return MDP_OK;
 }
 
+static int host_list_compare(mdp_ctx *c, const CutTables &ct, double maxcut, unsigned long long host_total,
+                             const char *style)
+{
+  hipStream_t st = c->stream;
+  MDP_TRY(mdp_bin_atoms(c, maxcut, c->bbox_lo, c->bbox_hi));
+  MDP_HIP(c, c->scan_tmp.reserve(64));
+  unsigned long long *d_total = reinterpret_cast<unsigned long long *>(c->scan_tmp.p);
+  MDP_HIP(c, hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+  host_list_count_kernel<<<nblk(c->nall), 256, 0, st>>>(c->grid, ct, c->nall, c->nlocal, c->xq.p, c->cell_perm.p,
+                                                        c->cell_start.p, d_total);
+  MDP_HIP(c, hipGetLastError());
+  unsigned long long dev_total = 0;
+  MDP_HIP(c, hipMemcpyAsync(&dev_total, d_total, sizeof dev_total, hipMemcpyDeviceToHost, st));
+  MDP_HIP(c, hipStreamSynchronize(st));
+  if (dev_total != host_total)
+    return mdp_fail(c, MDP_EINVAL,
+                    "host neighbor list is not the plain geometric list (%llu entries, %llu pairs within the list cutoff "
+                    "%.6g): exclusions / skip lists are not supported by the MI355X %s style, which builds its own lists",
+                    host_total, dev_total, maxcut, style);
+  return MDP_OK;
+}
+
 // Guard for hosts whose list is not the plain geometric one.  The REBO-MoS device path derives its lists from
 // the positions (mdp_set_skin); the reference iterates the HOST's entries (pair_rebomos.cpp:304-307, 328-330,
 // 490-495), so `neigh_modify exclude`, special_bonds weights or a hybrid skip list would silently change the
@@ -729,23 +752,54 @@ int mdp_rebomos_check_host_list(mdp_ctx *c, int inum, const int *ilist, const in
                           "own lists from the positions and cannot honour special_bonds", i);
     }
   }
-  hipStream_t st = c->stream;
-  MDP_TRY(mdp_bin_atoms(c, cutneigh, c->bbox_lo, c->bbox_hi));
-  MDP_HIP(c, c->scan_tmp.reserve(64));
-  unsigned long long *d_total = reinterpret_cast<unsigned long long *>(c->scan_tmp.p);
-  MDP_HIP(c, hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
-  host_list_count_kernel<<<nblk(c->nall), 256, 0, st>>>(c->grid, cutneigh * cutneigh, c->nall, c->nlocal, c->xq.p,
-                                                        c->cell_perm.p, c->cell_start.p, d_total);
-  MDP_HIP(c, hipGetLastError());
-  unsigned long long dev_total = 0;
-  MDP_HIP(c, hipMemcpyAsync(&dev_total, d_total, sizeof dev_total, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
-  if (dev_total != host_total)
-    return mdp_fail(c, MDP_EINVAL,
-                    "host neighbor list is not the plain geometric list (%llu entries, %llu pairs within %.6g): exclusions / "
-                    "skip lists are not supported by the MI355X rebomos style, which builds its own lists",
-                    host_total, dev_total, cutneigh);
-  return MDP_OK;
+  CutTables ct;
+  memset(&ct, 0, sizeof ct);
+  ct.ne = 2;
+  for (int k = 0; k < 4; k++) ct.owned[k] = cutneigh * cutneigh;
+  return host_list_compare(c, ct, cutneigh, host_total, "rebomos");
+}
+
+// the same guard for aeam when it builds its lists on the device (mdp_aeam_device_lists): per-type-pair cutoffs
+// cut[ti][tj] + skin, as the host built its list (pair_aeam.cpp:615-621 + neighbor skin)
+int mdp_aeam_check_host_list(mdp_ctx *c, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
+                             double skin)
+{
+  if (!c || inum < 0 || !(skin >= 0.0)) return MDP_EINVAL;
+  if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
+  if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (const char *e = getenv("MDP_SKIP_LIST_CHECK"))
+    if (atoi(e) != 0) return MDP_OK;
+  if (inum != c->nlocal) return mdp_fail(c, MDP_EINVAL, "host neighbor list has %d owned rows, expected nlocal = %d", inum, c->nlocal);
+  if (inum == 0) return MDP_OK;
+  if (!ilist || !numneigh || !firstneigh) return mdp_fail(c, MDP_EINVAL, "host neighbor list arrays missing");
+  MDP_HIP(c, hipSetDevice(c->device));
+  unsigned long long host_total = 0;
+  const int stride = inum > 65536 ? inum / 65536 : 1;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = ilist[ii];
+    if (i < 0 || i >= c->nlocal) return mdp_fail(c, MDP_EINVAL, "host neighbor list: owned row %d names atom %d", ii, i);
+    host_total += (unsigned long long) numneigh[i];
+    if (ii % stride == 0) {
+      const int *row = firstneigh[i];
+      for (int k = 0; k < numneigh[i]; k++)
+        if (row[k] & ~MDP_NEIGHMASK)
+          return mdp_fail(c, MDP_EINVAL,
+                          "host neighbor list carries special-bond bits (atom %d): the MI355X aeam style builds its own "
+                          "lists from the positions and cannot honour special_bonds", i);
+    }
+  }
+  CutTables ct;
+  memset(&ct, 0, sizeof ct);
+  const int nt = c->aeam.ntypes;
+  ct.ne = nt;
+  double maxcut = 0.0;
+  for (int a = 0; a < nt; a++)
+    for (int b = 0; b < nt; b++) {
+      const double cc = c->aeam.cut[a * nt + b] + skin;
+      ct.owned[a * nt + b] = cc * cc;
+      maxcut = cc > maxcut ? cc : maxcut;
+    }
+  return host_list_compare(c, ct, maxcut, host_total, "aeam");
 }
 
 void *mdp_md_ptr(mdp_ctx *c, const char *name)

@@ -104,6 +104,16 @@ __global__ void unpermute_kernel(int n, int w, const int *__restrict__ perm, con
   dst[(size_t) perm[i] * w + q] = src[k];
 }
 
+// dst (device order) <- src (host order)
+__global__ void permute_kernel(int n, int w, const int *__restrict__ perm, const double *__restrict__ src,
+                               double *__restrict__ dst)
+{
+  const long long k = (long long) blockIdx.x * 256 + threadIdx.x;
+  if (k >= (long long) n * w) return;
+  const int i = (int) (k / w), q = (int) (k % w);
+  dst[k] = src[(size_t) perm[i] * w + q];
+}
+
 // start of every compute: energy/virial accumulators (+ their slots), the four flag words, the overflow counter.
 // flags[0] (overflow bits of the compute just finished) is folded into the STICKY word flags[4] first: force-only
 // steps of a resident run never read the flags, and a truncated neighbour set must still stop the run at the next
@@ -139,6 +149,23 @@ __global__ void acc_reduce_kernel(double *__restrict__ acc)
 }
 
 } // namespace
+
+// host order <-> device (Hilbert) order of per-atom arrays, `w` doubles per atom (host mode with host_sort)
+int mdp_to_host_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst)
+{
+  if (n <= 0) return MDP_OK;
+  unpermute_kernel<<<(unsigned) (((long long) n * w + 255) / 256), 256, 0, c->stream>>>(n, w, c->host_perm.p, d_src, d_dst);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst)
+{
+  if (n <= 0) return MDP_OK;
+  permute_kernel<<<(unsigned) (((long long) n * w + 255) / 256), 256, 0, c->stream>>>(n, w, c->host_perm.p, d_src, d_dst);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
 
 int mdp_acc_begin(mdp_ctx *c, bool any)
 {
@@ -309,7 +336,9 @@ static int host_sort_atoms(mdp_ctx *c)
 {
   const int nall = c->nall;
   const char *e = getenv("MDP_HOST_SORT");
-  c->host_sort = !c->md && c->have_rebomos && !c->have_aeam && c->nlocal > 0 && !(e && atoi(e) == 0);
+  // rebomos always builds its own lists; aeam does when the host asked for device lists (mdp_aeam_device_lists)
+  const bool own_lists = (c->have_rebomos && !c->have_aeam) || (c->have_aeam && c->aeam_device_lists);
+  c->host_sort = !c->md && own_lists && c->nlocal > 0 && !(e && atoi(e) == 0);
   if (!c->host_sort) return MDP_OK;
   hipStream_t st = c->stream;
   MDP_HIP(c, c->sort_keys_a.reserve(nall + 1));
@@ -655,6 +684,8 @@ int mdp_set_neighbors_host(mdp_ctx *c, int inum, int gnum, const int *ilist, con
   if (inum + gnum > 0 && (!ilist || !numneigh || !firstneigh))
     return mdp_fail(c, MDP_EINVAL, "mdp_set_neighbors_host: list arrays missing for %d rows", inum + gnum);
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (c->host_sort && c->have_aeam)
+    return mdp_fail(c, MDP_ESTATE, "aeam builds its lists on the device (mdp_aeam_device_lists): hand over the skin, not the list");
   if (inum != c->nlocal) return mdp_fail(c, MDP_EINVAL, "inum (%d) != nlocal (%d)", inum, c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   const int nall = c->nall;
@@ -685,6 +716,16 @@ int mdp_set_skin(mdp_ctx *c, double skin)
 {
   if (!c || !(skin >= 0.0)) return MDP_EINVAL;
   c->skin = skin;
+  c->skin_set = true;
+  c->rebo_packed = false;
+  return MDP_OK;
+}
+
+int mdp_aeam_device_lists(mdp_ctx *c, int on)
+{
+  if (!c) return MDP_EINVAL;
+  c->aeam_device_lists = on != 0;
+  c->neigh_set = false;
   c->rebo_packed = false;
   return MDP_OK;
 }
@@ -694,6 +735,8 @@ int mdp_set_neighbors_csr_host(mdp_ctx *c, int nall, const int *numneigh, const 
 {
   if (!c || !numneigh || !offset || (!neigh && offset[nall] > 0)) return MDP_EINVAL;
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (c->host_sort && c->have_aeam)
+    return mdp_fail(c, MDP_ESTATE, "aeam builds its lists on the device (mdp_aeam_device_lists): hand over the skin, not the list");
   if (nall != c->nall) return mdp_fail(c, MDP_EINVAL, "nall mismatch");
   MDP_HIP(c, hipSetDevice(c->device));
   c->h_off.assign(nall + 1, 0);

@@ -277,6 +277,8 @@ struct mdp_ctx {
   int h_ang_count = 0;
   int aeam_cl = 1;                // atoms per cluster of the AEAM tile lists
   bool aeam_tiled = false;        // resident mode, two types: tile lists (tu / lj16 ...) serve the force-only steps
+  bool aeam_device_lists = false; // host mode: lists built on the device from the positions (as rebomos), host list unused
+  bool skin_set = false;
   bool csr_full = true;           // the CSR list holds rows for every owned atom (false: angular centres only)
   bool csr_want_full = false;     // a per-atom-virial step ran: keep building the full list
 
@@ -344,6 +346,8 @@ int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi
 void mdp_time_mark(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
+int mdp_to_host_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst);   // per-atom arrays, device -> host order
+int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst); // host -> device order
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]
 int mdp_flags_check(mdp_ctx *c, const int *hflags5); // overflow bits (last compute | sticky) -> MDP_EOVERFLOW

@@ -63,7 +63,7 @@ EXPORTS = [
     "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_download_int", "mdp_md_download_x_all",
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
-    "mdp_dd_comm_allreduce",
+    "mdp_dd_comm_allreduce", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
 ]
 
 
@@ -254,6 +254,18 @@ class Context:
 
     def set_skin(self, skin):
         self._ck(self.L.mdp_set_skin(self.h, C.c_double(skin)))
+
+    def aeam_device_lists(self, on=True):
+        self._ck(self.L.mdp_aeam_device_lists(self.h, C.c_int(1 if on else 0)))
+
+    def aeam_check_host_list(self, ilist, numneigh, rows, skin):
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        ptrs = (C.POINTER(C.c_int) * len(rows))()
+        for i, r in enumerate(rows):
+            ptrs[i] = r.ctypes.data_as(C.POINTER(C.c_int))
+        self._ck(self.L.mdp_aeam_check_host_list(self.h, C.c_int(len(ilist)), _ip(ilist), _ip(numneigh), ptrs,
+                                                 C.c_double(skin)))
 
     def device_bytes(self) -> float:
         return float(self.L.mdp_device_bytes(self.h))

@@ -47,6 +47,7 @@ PairAEAM::PairAEAM(LAMMPS *lmp) : Pair(lmp)
   nelements = 0;
   cut_el = nullptr;
   nall_uploaded = -1;
+  device_lists = false;
   memset(&tables, 0, sizeof tables);
 }
 
@@ -175,6 +176,11 @@ void PairAEAM::init_style()
   cut_el = const_cast<double *>(tables.cut);
   open_device();
   if (mdp_aeam_set_tables(dev, &tables) != MDP_OK) fail_one(MDP_EINVAL, "table upload");
+  // two atom types (the alloy the style exists for): lists built on the device; MDP_AEAM_HOST_LIST=1 streams the
+  // host's list instead, as do systems with more types
+  const char *ehl = getenv("MDP_AEAM_HOST_LIST");
+  device_lists = atom->ntypes == 2 && !(ehl && atoi(ehl) != 0);
+  if (mdp_aeam_device_lists(dev, device_lists ? 1 : 0) != MDP_OK) fail_one(MDP_EINVAL, "list mode");
 
   neighbor->add_request(this, NeighConst::REQ_FULL);
   nall_uploaded = -1;
@@ -207,8 +213,17 @@ void PairAEAM::compute(int eflag, int vflag)
     rc = mdp_set_atoms_host(dev, nlocal, atom->nghost, nall ? atom->x[0] : nullptr, atom->type, atom->tag,
                             atom->ntypes, nullptr);
     if (rc != MDP_OK) fail_one(rc, "atom upload");
-    rc = mdp_set_neighbors_host(dev, list->inum, 0, list->ilist, list->numneigh, list->firstneigh, neighbor->skin);
-    if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
+    if (device_lists) {
+      // the device derives its lists from the positions (as the rebomos style does); the host's list is requested
+      // for the ghost shell it implies and must be the plain geometric one -- checked, not read
+      rc = mdp_set_skin(dev, neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "skin upload");
+      rc = mdp_aeam_check_host_list(dev, list->inum, list->ilist, list->numneigh, list->firstneigh, neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "neighbor list check");
+    } else {
+      rc = mdp_set_neighbors_host(dev, list->inum, 0, list->ilist, list->numneigh, list->firstneigh, neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
+    }
     nall_uploaded = nall;
   } else {
     rc = mdp_set_positions_host(dev, nall ? atom->x[0] : nullptr);

@@ -50,6 +50,7 @@ class PairAEAM : public Pair {
   double element_mass[4];
   double *cut_el;             // [nelements*nelements], points into potfile
   int nall_uploaded;
+  bool device_lists;          // lists built on the device from the positions; the host's list is checked, not read
 
   void allocate();
   void open_device();

@@ -71,6 +71,61 @@ def test_host_mode_matches_oracle(oracle, T, pot, ncell, frac, amp):
     ctx.close()
 
 
+def _host_mode_device_lists(ctx, eng, x, steps_of_motion=0):
+    """the drop-in path of the aeam plugin with two atom types: the host reports its skin, its list is only CHECKED
+    (mdp_aeam_check_host_list); bins, tile lists and the angular centres' rows are built on the device from the
+    positions, the device keeps a Hilbert-sorted copy of the atoms and returns everything in the host's order"""
+    xa = eng.all_positions(x)
+    nall, nloc = len(xa), eng.nlocal
+    ctx.aeam_device_lists(True)
+    ctx.set_atoms_host(nloc, xa, eng.type_all, eng.tag_all, 2, map_=None)
+    ctx.set_skin(1.0)
+    rows = [np.ascontiguousarray(eng.nb[eng.off[i]:eng.off[i] + eng.nn[i]], dtype=np.int32) for i in range(nall)]
+    ctx.aeam_check_host_list(np.arange(nloc, dtype=np.int32), eng.nn, rows, 1.0)
+    d = ctx.aeam_density_host(nloc, eflag=3)
+    fp_all = np.concatenate([d["fp"], d["fp"][eng.owner]])          # forward_comm on one periodic rank
+    r = ctx.aeam_force_host(nall, nloc, fp_all, eflag=3, vflag=5)
+    va = r["vatom"][:nloc].copy()
+    np.add.at(va, eng.owner, r["vatom"][nloc:])
+    return dict(f=ob.fold_ghost_forces(r["f"], eng.owner, nloc), eng=d["eng"] + r["eng"], virial=r["virial"],
+                eatom=d["eatom"] + r["eatom"], rho=d["rho"], vatom=va, rows=rows)
+
+
+@pytest.mark.parametrize("ncell,frac,amp", [(5, 0.08, 0.075), (6, 0.0075, 0.05), (4, 0.5, 0.1)])
+def test_host_mode_with_device_lists_matches_oracle(oracle, T, pot, ncell, frac, amp):
+    ctx = capi.Context(0)
+    ctx.aeam_set_tables(pot[1])
+    s = S.jitter(S.fcc_cell(4.045, ncell, frac_type2=frac, seed=99), amp, seed=100)
+    eng = mdref.AeamCPU(oracle, T, s)
+    g = _host_mode_device_lists(ctx, eng, s.x)
+    o = eng.compute(s.x)
+    assert np.abs(g["rho"] - o["rho"][:s.n]).max() < 1e-11
+    assert np.abs(g["f"] - o["f_owned"]).max() < 1e-9
+    assert g["eng"] == pytest.approx(o["eng"], rel=1e-11)
+    assert np.abs(g["eatom"] - o["eatom"][:s.n]).max() < 1e-9
+    assert np.allclose(g["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    vo = o["vatom"][:s.n].copy()
+    np.add.at(vo, eng.owner, o["vatom"][s.n:])
+    assert np.abs(g["vatom"] - vo).max() < 1e-9 * max(1.0, np.abs(vo).max())
+    # force-only call with moved positions (between two reneighborings of the host), again against the oracle
+    x2 = s.x + 0.02 * np.random.default_rng(3).standard_normal(s.x.shape)
+    xa2 = eng.all_positions(x2)
+    ctx.set_positions_host(xa2)
+    d = ctx.aeam_density_host(eng.nlocal, eflag=0)
+    r = ctx.aeam_force_host(len(xa2), eng.nlocal, np.concatenate([d["fp"], d["fp"][eng.owner]]), eflag=0, vflag=0)
+    o2 = eng.compute(x2)
+    assert np.abs(ob.fold_ghost_forces(r["f"], eng.owner, eng.nlocal) - o2["f_owned"]).max() < 1e-9
+    # a host list with an excluded pair is refused; so is handing the list over in this mode
+    nn2 = eng.nn.copy()
+    nn2[3] -= 1
+    with pytest.raises(capi.MdpError) as e:
+        ctx.aeam_check_host_list(np.arange(eng.nlocal, dtype=np.int32), nn2, g["rows"], 1.0)
+    assert "not the plain geometric list" in str(e.value)
+    with pytest.raises(capi.MdpError):
+        ctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, 1.0)
+    ctx.close()
+
+
 def test_resident_mode_matches_oracle_and_conserves_energy(oracle, T, pot):
     af, tabs = pot
     ctx = capi.Context(0)
