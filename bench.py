@@ -154,11 +154,11 @@ def host_mode_rate(s, p, skin, cutghost, steps=5):
 
 
 def kernel_source_sha():
+    """hash of the sources that decide what the path kernels read and write (kernels, list builders, atom order)"""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "lammps-plugins_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in ("aeam.hip", "domain.hip", "md.hip", "mdp_api.hip", "mdp_common.h", "rebomos.hip"):
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -1871,6 +1871,63 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   }
 }
 
+// Between the passes: the members of a union are sorted by atom index (each element segment by itself).  The
+// kernels that stage a union gather xq[member] with consecutive lanes taking consecutive members; atoms are stored
+// along a Hilbert curve, so after the sort neighbouring lanes mostly hit the same 128-byte line (four atoms) instead
+// of one line each -- the staging gathers were a quarter of the L1 lookups of the AEAM tile kernels.
+__global__ __launch_bounds__(256) void tile_sort_kernel(const int cap, const int *__restrict__ tile_nu,
+                                                        int *__restrict__ tu, unsigned short *__restrict__ tmask)
+{
+  extern __shared__ unsigned long long s_key[];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1];
+  int *mem = tu + (size_t) t * cap;
+  unsigned short *mm = tmask + (size_t) t * cap;
+  for (int seg = 0; seg < 2; seg++) {
+    const int b = seg ? N0 : 0, n = (seg ? nU : N0) - b;
+    if (n <= 1) continue; // (block-uniform)
+    int np = 2;
+    while (np < n) np <<= 1;
+    for (int i = tid; i < np; i += 256)
+      s_key[i] = i < n ? (((unsigned long long) (unsigned) mem[b + i]) << 16) | mm[b + i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np; i += 256) {
+          const int p = i ^ j;
+          if (p > i) {
+            const unsigned long long x = s_key[i], y = s_key[p];
+            if ((x > y) == ((i & k) == 0)) {
+              s_key[i] = y;
+              s_key[p] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < n; i += 256) {
+      const unsigned long long v = s_key[i];
+      mem[b + i] = (int) (v >> 16);
+      mm[b + i] = (unsigned short) (v & 0xFFFFull);
+    }
+    __syncthreads();
+  }
+}
+
+static int tile_sort_launch(mdp_ctx *c, int ntile)
+{
+  if (const char *e = getenv("MDP_TILE_SORT"))
+    if (atoi(e) == 0) return MDP_OK;
+  int np = 2;
+  while (np < c->tile_maxu) np <<= 1;
+  const size_t lds = (size_t) np * sizeof(unsigned long long);
+  if (lds > 48 * 1024)
+    MDP_HIP(c, hipFuncSetAttribute((const void *) tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  tile_sort_kernel<<<ntile, 256, lds, c->stream>>>(c->tile_cap, c->tile_nu.p, c->tu.p, c->tmask.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
 // Pass 2: each cluster (16 lanes) walks its tile's masks in union order and keeps the entries with its bit;
 // the Mo segment and the S segment are each padded to a whole 16-lane step with the dummy index nU
 __global__ __launch_bounds__(256) void tile_fill_kernel(const int nclus, const int cap,
@@ -2365,6 +2422,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p);
+  if (tiled) MDP_TRY(tile_sort_launch(c, ntile));
   if (tiled)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
                                             c->lj16.p);
@@ -2518,6 +2576,7 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   MDP_HIP(c, hipMemcpyAsync(&total, c->lj_off.p + nrow, sizeof(long long), hipMemcpyDeviceToHost, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   MDP_HIP(c, c->lj16.reserve((size_t) total + 256));
+  MDP_TRY(tile_sort_launch(c, ntile));
   tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
                                           c->lj16.p);
   MDP_HIP(c, hipGetLastError());
