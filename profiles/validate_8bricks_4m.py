@@ -21,18 +21,33 @@ from lammps_plugins_amd.host import capi, resident, system as S
 nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+style = sys.argv[4] if len(sys.argv) > 4 else "rebomos"      # or "aeam": fcc nrep^3 cells, 0.75 % Si, 863 K
 pot = os.path.join(ROOT, "tests", "golden", "potentials", "MoS.REBO.set5b")
-s = S.replicate(S.rebomos_bulk_cell(), (nrep, nrep, nrep))
-v0 = S.gaussian_velocities(s, 300.0, seed=11) + np.array([60.0, -45.0, 30.0])
+pot_aeam = os.path.join(ROOT, "tests", "golden", "potentials", "AlSi.aeam")
+if style == "rebomos":
+    s = S.replicate(S.rebomos_bulk_cell(), (nrep, nrep, nrep))
+    v0 = S.gaussian_velocities(s, 300.0, seed=11) + np.array([60.0, -45.0, 30.0])
+else:
+    s = S.fcc_cell(4.045, nrep, frac_type2=0.0075, seed=7683797)
+    s.mass[1:3] = capi.AeamFile(pot_aeam).mass[:2]
+    v0 = S.gaussian_velocities(s, 863.0, seed=11) + np.array([60.0, -45.0, 30.0])
 
 
 def run(world):
     def rank_fn(r, make_tr):
         ctx = capi.Context(0)
-        p = capi.read_rebomos_file(pot)
-        ctx.rebomos_set_params(p)
+        if style == "rebomos":
+            p = capi.read_rebomos_file(pot)
+            ctx.rebomos_set_params(p)
+            args = (capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1])
+        else:
+            af = capi.AeamFile(pot_aeam)
+            tabs = af.build()
+            ctx.aeam_set_tables(tabs)
+            ctx._keep = (af, tabs)
+            args = (capi.STYLE_AEAM, s, float(af.cut_table(tabs).max()) + 1.0, 1.0, None)
         tr = make_tr(ctx) if world > 1 else None
-        d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1], v0=v0, transport=tr)
+        d = resident.DeviceDomain(ctx, *args, v0=v0, transport=tr)
         d.compute(1, 1)
         th0 = d.thermo()
         left = 0
@@ -60,7 +75,7 @@ a, b = run(1), run(8)
 dx = b["x"] - a["x"]
 dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
 print(json.dumps({
-    "atoms": s.n, "steps": steps, "reneighbor_every": every, "atoms_that_changed_owner": int(b["left"]),
+    "style": style, "atoms": s.n, "steps": steps, "reneighbor_every": every, "atoms_that_changed_owner": int(b["left"]),
     "bricks_nlocal_nself_nremote": b["counts"],
     "max_dx_A": float(np.abs(dx).max()), "max_dv_A_per_ps": float(np.abs(b["v"] - a["v"]).max()),
     "pe_start_1_vs_8": [a["th0"]["pe"], b["th0"]["pe"]], "pe_end_1_vs_8": [a["th"]["pe"], b["th"]["pe"]],
