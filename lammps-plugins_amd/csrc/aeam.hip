@@ -1088,7 +1088,7 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
                                                                    c->acc.p, c->flags.p, vflag);
   MDP_HIP(c, hipGetLastError());
   mdp_time_mark(c, 3);
-  return mdp_acc_end(c, true);
+  return mdp_acc_end(c, eflag || vflag); // force-only steps tally nothing: no slots to fold
 }
 
 extern "C" {
