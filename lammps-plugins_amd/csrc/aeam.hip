@@ -165,6 +165,15 @@ __device__ __forceinline__ double rsqrt_nr(double x)
   return fma(0.5 * y, e, y);
 }
 
+// one Newton step: ~2e-15 relative (the seed is good to 2^-26).  Enough for the persistent kernels' row coordinate
+// (a spline is continuous across rows) and 1/r, five orders below the parity tolerance
+__device__ __forceinline__ double rsqrt_n1(double x)
+{
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+
 constexpr int kTile = 16; // clusters per tile (= MDP_TILE of rebomos.hip)
 
 __device__ __forceinline__ int xcd_contiguous(const int b, const int n)
@@ -473,6 +482,443 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         atomicAdd(&slot[6], v5);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Persistent tile kernels: the spline table of the majority pair type lives in LDS.
+//
+// The tile kernels above fetch one spline row per in-range pair from global memory, every lane a different row of
+// a 200-300 KB table: the vector L1 misses nearly always and its fill path (one 128-byte line per ~2.3 clocks
+// per CU, profiles/ubench/tcp_gather.hip) is what bounds them.  A row's four value coefficients are the cubic
+// Hermite expressions of the tabulated value Y and slope S at rows m and m+1 (pair_aeam.cpp:929-935), and the
+// derivative's three are those times 1/dr (:937-941) -- so 16 bytes per row hold everything, and the rows that
+// are ever addressed (r from ~2.3 A to the cutoff) of ONE function fit the 160 KB LDS of a CU next to the
+// staging buffers.  Hence one function per pass:
+//   PT_DENSITY  rho(r)            pass 1 of metal centres
+//   PT_FRHO     rho'(r) terms     pass 3, embedding part of both visits
+//   PT_FPHI     phi'(r) terms     pass 3, pair part of both visits (and the pair energy on tallying steps)
+// One workgroup per CU stays resident: NSUB sub-blocks of 256 threads each walk their share of the workgroup's
+// contiguous run of tiles.  A sub-block's next tile (union coordinates, rows, cluster heads) is requested into
+// registers BEFORE the current tile is computed and written to LDS after it; the compute phase itself reads LDS
+// only, so the loads in flight never sit in front of a wait.  Pairs of other type pairs (1.5 % in sample.in),
+// and rows below the window, read the same (Y,S) rows from global memory.
+// ------------------------------------------------------------------------------------------------------
+enum { PT_DENSITY = 0, PT_FRHO = 1, PT_FPHI = 2 };
+
+struct PTile {
+  int nlocal, nclus, ntile, cap, capL, rowcapB, per; // per = tiles per workgroup
+  int wlo, nw, lds_table;                           // LDS window: rows [wlo, wlo + nw) of table lds_table
+  double hot_rsqmax;                                // largest r^2 inside the (0,0) pair's cutoff
+  const double4 *xq;
+  const double *fp;
+  const int *tu, *tile_nu;
+  const long long *lj_off;
+  const int *lj_split;
+  const unsigned short *lj16;
+  const double2 *ys; // [table][nrmax+1] (value, slope) rows of the pass's function
+  double *rho, *f, *eatom, *acc;
+  int eflag, vflag;
+};
+
+struct YsRow {
+  double2 a, b; // rows m and m+1
+};
+// value and derivative (per unit of the row coordinate) of the row's cubic
+__device__ __forceinline__ double ys_val(const YsRow w, const double p)
+{
+  const double d = w.b.x - w.a.x;
+  const double c4 = 3.0 * d - 2.0 * w.a.y - w.b.y, c3 = w.a.y + w.b.y - 2.0 * d;
+  return ((c3 * p + c4) * p + w.a.y) * p + w.a.x;
+}
+__device__ __forceinline__ double ys_der(const YsRow w, const double p)
+{
+  const double d = w.b.x - w.a.x;
+  const double c4 = 3.0 * d - 2.0 * w.a.y - w.b.y, c3 = w.a.y + w.b.y - 2.0 * d;
+  return (3.0 * c3 * p + 2.0 * c4) * p + w.a.y;
+}
+
+// explicit address spaces for the two sources of a table row: left generic, the compiler folds "LDS or global"
+// into one flat load behind a pointer select, and a flat load waits for every load in flight
+// (scalars: copying a vector type goes through its copy constructor, which takes a generic reference)
+typedef __attribute__((address_space(3))) const double lds_double;
+typedef __attribute__((address_space(1))) const double glb_double;
+
+template <int MODE, int NSUB, int CL, bool EV>
+__global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A, const PTile P)
+{
+  constexpr int L = 16, SK = CL == 2 ? 3 : 2, RK = 2;
+  constexpr int REC = MODE == PT_FRHO ? 4 : 3; // doubles per union record: x y z (q)
+  extern __shared__ double2 s_dyn[];
+  double2 *__restrict__ s_tab = s_dyn; // [nw]
+  const int tid = threadIdx.x, sub = tid >> 8, t8 = tid & 255, lane = tid & 63, s = lane % L, gq = t8 / L;
+  char *sb = reinterpret_cast<char *>(s_tab + P.nw) + (size_t) sub * ((size_t) P.capL * REC * 8 + P.rowcapB);
+  double *__restrict__ s_rec = reinterpret_cast<double *>(sb);
+  unsigned short *__restrict__ s_row = reinterpret_cast<unsigned short *>(sb + (size_t) P.capL * REC * 8);
+  double2 *__restrict__ s_row2 = reinterpret_cast<double2 *>(s_row); // (16 bytes = 8 entries at a time)
+  const int nm1 = A.nrmax + 1;
+  {
+    const double2 *__restrict__ src = P.ys + (size_t) P.lds_table * nm1 + P.wlo;
+    for (int i = tid; i < P.nw; i += NSUB * 256) s_tab[i] = src[i];
+  }
+  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int t_first = wg * P.per;
+  const int t_last = t_first + P.per < P.ntile ? t_first + P.per : P.ntile; // exclusive
+  const int rounds = (P.per + NSUB - 1) / NSUB;
+
+  // Both stages only REQUEST: nothing loaded is touched (no select, no difference) before the next stage or
+  // the commit needs it -- a use right behind a load is a wait for everything in flight.
+  // ---- stage 1 of the prefetch: tile header + union member indices (two tiles ahead) ------------------
+  int m_t, m_idx[SK];
+  bool m_valid;
+  int2 m_nu;
+  long long m_rb;
+  int m_re; // (low word: only differences within a tile are taken.  A register of a load in flight that is dead
+            //  -- the high word of an offset that is only ever truncated -- gets reused at once, behind a wait)
+  const int *__restrict__ off_lo = reinterpret_cast<const int *>(P.lj_off);
+  auto load_meta = [&](const int tt) {
+    m_valid = tt < t_last;
+    m_t = m_valid ? tt : P.ntile - 1;
+    m_nu = reinterpret_cast<const int2 *>(P.tile_nu)[m_t];
+    m_rb = P.lj_off[(size_t) m_t * kTile];
+    m_re = off_lo[2 * ((size_t) m_t * kTile + kTile)];
+    const int *__restrict__ mem = P.tu + (size_t) m_t * P.cap;
+#pragma unroll
+    for (int k = 0; k < SK; k++) m_idx[k] = mem[t8 + 256 * k];
+  };
+  // ---- stage 2: the union's coordinates, the tile's rows, the cluster heads (one tile ahead) ----------
+  int n_t, n_nU, n_N0, n_rtot, n_split;
+  long long n_rb;
+  int n_b, n_b1;
+  double4 n_sv[SK], n_xa[CL];
+  double n_sq[SK], n_qa[CL];
+  double n_rv[RK][2];
+  auto gather = [&]() {
+    n_t = m_t;
+    n_nU = m_valid ? m_nu.x : 0;
+    n_N0 = m_valid ? m_nu.y : 0;
+    n_rtot = m_valid ? m_re - (int) m_rb : 0;
+    n_rb = m_rb;
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int j = t8 + 256 * k < n_nU ? m_idx[k] : 0;
+      n_sv[k] = P.xq[j];
+      n_sq[k] = MODE == PT_FRHO ? P.fp[j] : 0.0;
+    }
+    const double2 *__restrict__ rsrc = reinterpret_cast<const double2 *>(P.lj16 + m_rb);
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+      const double2 v = rsrc[(t8 + 256 * k) * 8 < n_rtot ? t8 + 256 * k : 0];
+      n_rv[k][0] = v.x;
+      n_rv[k][1] = v.y;
+    }
+    const int kc = m_t * kTile + gq;
+    n_b = off_lo[2 * kc];
+    n_b1 = off_lo[2 * kc + 2];
+    n_split = P.lj_split[kc];
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      const int ia = kc * CL + c < P.nlocal ? kc * CL + c : P.nlocal - 1;
+      n_xa[c] = P.xq[ia];
+      n_qa[c] = MODE == PT_FRHO ? P.fp[ia] : 0.0;
+    }
+  };
+  // registers -> LDS (between two barriers)
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int u = t8 + 256 * k;
+      if (u < n_nU) {
+        s_rec[REC * u] = n_sv[k].x;
+        s_rec[REC * u + 1] = n_sv[k].y;
+        s_rec[REC * u + 2] = n_sv[k].z;
+        if (MODE == PT_FRHO) s_rec[REC * u + 3] = (u < n_N0 ? 0 : 1) < A.nnonangular ? n_sq[k] : 0.0;
+      }
+    }
+    if (n_nU > 256 * SK) { // a union beyond the register stage: fetched here (not seen in practice)
+      const int *__restrict__ mem = P.tu + (size_t) n_t * P.cap;
+      for (int u = t8 + 256 * SK; u < n_nU; u += 256) {
+        const int j = mem[u];
+        const double4 v = P.xq[j];
+        s_rec[REC * u] = v.x;
+        s_rec[REC * u + 1] = v.y;
+        s_rec[REC * u + 2] = v.z;
+        if (MODE == PT_FRHO) s_rec[REC * u + 3] = (u < n_N0 ? 0 : 1) < A.nnonangular ? P.fp[j] : 0.0;
+      }
+    }
+    if (t8 == 0) { // the dummy member every padding entry points at: outside every cutoff
+      s_rec[REC * n_nU] = 1.0e30;
+      s_rec[REC * n_nU + 1] = 0.0;
+      s_rec[REC * n_nU + 2] = 0.0;
+      if (MODE == PT_FRHO) s_rec[REC * n_nU + 3] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+      const int e = t8 + 256 * k;
+      if (e * 8 < n_rtot) s_row2[e] = make_double2(n_rv[k][0], n_rv[k][1]);
+    }
+    if (n_rtot > 256 * RK * 8) {
+      const double2 *__restrict__ rsrc = reinterpret_cast<const double2 *>(P.lj16 + n_rb);
+      for (int e = t8 + 256 * RK; e * 8 < n_rtot; e += 256) s_row2[e] = rsrc[e];
+    }
+  };
+
+  load_meta(t_first + sub);
+  gather();
+  load_meta(t_first + NSUB + sub);
+  __syncthreads(); // (the table)
+  commit();
+  __syncthreads();
+
+  for (int rd = 0; rd < rounds; rd++) {
+    // ---- the tile to compute now: heads out of the stage registers ----
+    const int t = n_t, nU = n_nU;
+    const int cnt = __builtin_amdgcn_readfirstlane(nU ? n_b1 - n_b : 0);
+    const int split = __builtin_amdgcn_readfirstlane(nU ? n_split : 0);
+    const int roff = n_b - (int) n_rb;
+    const int kc = t * kTile + gq;
+    double4 xa[CL];
+    double qa[CL];
+    int ta[CL];
+    bool real[CL], metal[CL];
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      xa[c] = n_xa[c];
+      qa[c] = n_qa[c];
+      ta[c] = (int) xa[c].w;
+      real[c] = nU > 0 && kc < P.nclus && kc * CL + c < P.nlocal;
+      metal[c] = real[c] && ta[c] < A.nnonangular;
+      if (MODE == PT_FRHO && !(ta[c] < A.nnonangular)) qa[c] = 0.0; // (1 - deli): angular centres embed through the three-body kernel
+    }
+    // ---- request the next tile, and the header of the one after ----
+    // (vmcnt(0): nothing is in flight here -- the commit consumed it -- but only an explicit wait lets the compiler
+    //  see that on every path; otherwise its counter-based waits for "older" loads land behind the new requests)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    gather();
+    load_meta(t_first + (rd + 2) * NSUB + sub);
+
+    // ---- compute from LDS ----
+    double ac0[CL], ac1[CL], ac2[CL], ea[CL];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+#pragma unroll
+    for (int c = 0; c < CL; c++) ac0[c] = ac1[c] = ac2[c] = ea[c] = 0.0;
+    const unsigned short *__restrict__ row = s_row + roff;
+    // A table row comes from the LDS window (HOT pass) or from global memory (COLD pass: other type pairs, rows
+    // below the window).  The passes are separate loops because a loop that may read global memory waits for
+    // every load in flight -- the prefetch of the next tile -- in each trip; the cold loops run last and only in
+    // waves that met a cold pair.
+    auto lds_row = [&](const int m) {
+      YsRow w;
+      lds_double *src = (lds_double *) (s_tab + (m - P.wlo));
+      w.a.x = src[0];
+      w.a.y = src[1];
+      w.b.x = src[2];
+      w.b.y = src[3];
+      return w;
+    };
+    auto glb_row = [&](const int table, const int m) {
+      YsRow w;
+      glb_double *src = (glb_double *) (P.ys + (size_t) table * nm1 + m);
+      w.a.x = src[0];
+      w.a.y = src[1];
+      w.b.x = src[2];
+      w.b.y = src[3];
+      return w;
+    };
+    // HOT pass: pairs of the majority type pair (0,0) -- both visits read the LDS-resident table at the same row,
+    // and every parameter is a scalar (CutDec never applies to a metal centre, pair_aeam.cpp:187-190)
+    auto hot_pass = [&](bool &cold_seen) {
+      const int kb = 0, ke = split;
+      const double rdr = A.rdr[0];
+      const int nr = A.nr[0];
+      const double c2max = P.hot_rsqmax; // largest r^2 whose IEEE square root is <= cut (the reference tests r, pair_aeam.cpp:192)
+      bool hot[CL];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        const bool act = MODE == PT_DENSITY ? metal[c] : real[c];
+        hot[c] = act && ta[c] == 0;
+        if (act && ta[c] != 0) cold_seen = true;
+      }
+      bool anyhot = false;
+#pragma unroll
+      for (int c = 0; c < CL; c++) anyhot = anyhot || hot[c];
+      if (!__any(anyhot)) return; // (wave-uniform)
+      int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is read one trip ahead
+      for (int k = kb + s; k < ke; k += L) {
+        const double *__restrict__ pj = s_rec + REC * li_next;
+        const double xj = pj[0], yj = pj[1], zj = pj[2];
+        const double qj = MODE == PT_FRHO ? pj[REC - 1] : 0.0;
+        li_next = k + L < ke ? (int) row[k + L] : nU;
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          if (!(hot[c] && rsq > 0.0 && rsq <= c2max)) continue; // (the union holds the cluster's own atoms too)
+          const double recip = rsqrt_n1(rsq);
+          const double r = rsq * recip;
+          double pf;
+          const int m = spline_index(r, rdr, nr, pf);
+          if (m < P.wlo) { // below the window: the cold pass reads the row from global memory
+            cold_seen = true;
+            continue;
+          }
+          const YsRow w = lds_row(m);
+          if (MODE == PT_DENSITY) {
+            ac0[c] += ys_val(w, pf);
+          } else {
+            // the two visits' derivative terms: -q f'/r (pair_aeam.cpp:373) or -phi'/(2r) (:375-376)
+            const double der = ys_der(w, pf) * rdr * recip;
+            const double fpair_a = -(MODE == PT_FRHO ? qa[c] : 0.5) * der;
+            const double ft = fpair_a - (MODE == PT_FRHO ? qj : 0.5) * der;
+            if (EV && MODE == PT_FPHI) ea[c] += 0.5 * ys_val(w, pf); // credited to i only (pair_aeam.cpp:386-390)
+            ac0[c] -= dx * ft;
+            ac1[c] -= dy * ft;
+            ac2[c] -= dz * ft;
+            if (EV) { // ev_tally(i = a, j, ..., fpair_a, d): every rank tallies its own visits
+              v0 += dx * dx * fpair_a;
+              v1 += dy * dy * fpair_a;
+              v2 += dz * dz * fpair_a;
+              v3 += dx * dy * fpair_a;
+              v4 += dx * dz * fpair_a;
+              v5 += dy * dz * fpair_a;
+            }
+          }
+        }
+      }
+    };
+    // COLD pass: every other pair, rows from global memory, per-lane parameters
+    auto cold_pass = [&](auto tjc) {
+      constexpr int TJ = decltype(tjc)::value;
+      const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
+      TilePar qA[CL], qJ[CL];
+      double c2max[CL];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
+        qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
+        const double cm = MODE == PT_DENSITY || qA[c].cut > qJ[c].cut ? qA[c].cut : qJ[c].cut;
+        c2max[c] = cm * cm * (1.0 + 1.0e-12);
+      }
+      int li_next = kb + s < ke ? (int) row[kb + s] : nU;
+      for (int k = kb + s; k < ke; k += L) {
+        const double *__restrict__ pj = s_rec + REC * li_next;
+        const double xj = pj[0], yj = pj[1], zj = pj[2];
+        const double qj = MODE == PT_FRHO ? pj[REC - 1] : 0.0;
+        li_next = k + L < ke ? (int) row[k + L] : nU;
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          if (!((MODE == PT_DENSITY ? metal[c] : real[c]) && rsq > 0.0 && rsq <= c2max[c])) continue;
+          const double recip = rsqrt_nr(rsq);
+          const double r = rsq * recip;
+          const bool hotc = TJ == 0 && ta[c] == 0; // a pair the hot pass owns unless its row lies below the window
+          const bool in_a = r <= qA[c].cut, in_j = MODE != PT_DENSITY && r <= qJ[c].cut;
+          const int tabA = MODE == PT_FPHI ? qA[c].tz2r : qA[c].trho, tabJ = MODE == PT_FPHI ? qJ[c].tz2r : qJ[c].trho;
+          const double wa = MODE == PT_FRHO ? qa[c] : 0.5, wj = MODE == PT_FRHO ? qj : 0.5;
+          double fpair_a = 0.0, fpair_j = 0.0;
+          if (in_a) {
+            double pf;
+            const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
+            if (hotc && m >= P.wlo) continue;
+            const YsRow w = glb_row(tabA, m);
+            if (MODE == PT_DENSITY) {
+              ac0[c] += ys_val(w, pf);
+              continue;
+            }
+            fpair_a = -wa * ys_der(w, pf) * qA[c].rdr * recip;
+            if (EV && MODE == PT_FPHI) ea[c] += 0.5 * ys_val(w, pf);
+          }
+          if (MODE == PT_DENSITY) continue;
+          if (in_j) {
+            double pf;
+            const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
+            fpair_j = -wj * ys_der(glb_row(tabJ, m), pf) * qJ[c].rdr * recip;
+          }
+          const double ft = fpair_a + fpair_j;
+          ac0[c] -= dx * ft;
+          ac1[c] -= dy * ft;
+          ac2[c] -= dz * ft;
+          if (EV) {
+            v0 += dx * dx * fpair_a;
+            v1 += dy * dy * fpair_a;
+            v2 += dz * dz * fpair_a;
+            v3 += dx * dy * fpair_a;
+            v4 += dx * dz * fpair_a;
+            v5 += dy * dz * fpair_a;
+          }
+        }
+      }
+    };
+    {
+      bool cold0 = false;
+      hot_pass(cold0);
+      if (__any(cold0)) cold_pass(std::integral_constant<int, 0>{});
+      if (cnt > split) cold_pass(std::integral_constant<int, 1>{});
+    }
+    // ---- results of the tile ----
+    if (MODE == PT_DENSITY) {
+#pragma unroll
+      for (int c = 0; c < CL; c++) ac0[c] = lane_sum<L>(ac0[c]);
+      if (s < CL) {
+#pragma unroll
+        for (int c = 0; c < CL; c++)
+          if (c == s && metal[c]) P.rho[kc * CL + c] = ac0[c];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        ac0[c] = lane_sum<L>(ac0[c]);
+        ac1[c] = lane_sum<L>(ac1[c]);
+        ac2[c] = lane_sum<L>(ac2[c]);
+      }
+      double ev_e = 0.0;
+      if (EV && MODE == PT_FPHI) {
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          ev_e += ea[c];
+          ea[c] = lane_sum<L>(ea[c]);
+        }
+      }
+      if (s < CL) {
+#pragma unroll
+        for (int c = 0; c < CL; c++)
+          if (c == s && real[c]) { // plain += : only writer of owned f here (stream order); the angular kernel follows
+            double *fo = P.f + 3 * (size_t) (kc * CL + c);
+            fo[0] += ac0[c];
+            fo[1] += ac1[c];
+            fo[2] += ac2[c];
+            if (EV && MODE == PT_FPHI && (P.eflag & MDP_EFLAG_ATOM)) P.eatom[kc * CL + c] += ea[c];
+          }
+      }
+      if (EV) {
+        double *slot = P.acc + MDP_ACC_STRIDE * (1 + ((blockIdx.x * NSUB + sub) & (MDP_ACC_SLOTS - 1)));
+        if (MODE == PT_FPHI && (P.eflag & MDP_EFLAG_GLOBAL)) {
+          ev_e = lane_sum<64>(ev_e);
+          if (lane == 0) atomicAdd(&slot[0], ev_e);
+        }
+        if (P.vflag & MDP_VFLAG_GLOBAL) {
+          v0 = lane_sum<64>(v0);
+          v1 = lane_sum<64>(v1);
+          v2 = lane_sum<64>(v2);
+          v3 = lane_sum<64>(v3);
+          v4 = lane_sum<64>(v4);
+          v5 = lane_sum<64>(v5);
+          if (lane == 0) {
+            atomicAdd(&slot[1], v0);
+            atomicAdd(&slot[2], v1);
+            atomicAdd(&slot[3], v2);
+            atomicAdd(&slot[4], v3);
+            atomicAdd(&slot[5], v4);
+            atomicAdd(&slot[6], v5);
+          }
+        }
+      }
+    }
+    // ---- the next tile's data goes to LDS ----
+    __syncthreads();
+    commit();
+    __syncthreads();
   }
 }
 
@@ -912,6 +1358,14 @@ __global__ void relay_kernel(const size_t nrows, const double *__restrict__ src,
   der4[i] = make_double4(c[0], c[1], c[2], 0.0);
 }
 
+// (value, slope) of every row: all the persistent tile kernels need of a table (16 bytes per row)
+__global__ void ys_kernel(const size_t nrows, const double *__restrict__ src, double2 *__restrict__ ys)
+{
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= nrows) return;
+  ys[i] = make_double2(src[7 * i + 6], src[7 * i + 5]);
+}
+
 // derivative coefficients of rho (c0..c2) and of phi (c0..c2) of ONE pair type side by side in a 48-byte
 // record: the pair-force visit needs both at the same row.  The tile kernels are bound by the vector L1's
 // lookup rate (~0.9 lookups per clock per CU measured, every lane a different row): a lookup moves at most 16
@@ -987,6 +1441,121 @@ int mdp_aeam_prepare(mdp_ctx *c)
   return MDP_OK;
 }
 
+// Persistent tile kernels (above): geometry of the launch.  *done stays false when the window that fits LDS next to
+// the staging buffers would cover too little of the table -- the caller then runs the gather kernels.
+static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const int vflag, bool *done)
+{
+  *done = false;
+  if (const char *e = getenv("MDP_AEAM_PERSIST"))
+    if (atoi(e) == 0) return MDP_OK;
+  if (c->tile_rowmax <= 0) return MDP_OK;
+  if (!c->lds_max) {
+    int v = 0, n = 0;
+    MDP_HIP(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+    MDP_HIP(c, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device));
+    c->lds_max = v;
+    c->num_cu = n > 0 ? n : 256;
+  }
+  const AeamDev &A = c->aeam;
+  const int rec = mode == PT_FRHO ? 4 : 3;
+  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const int rowcapB = (2 * c->tile_rowmax + 15) & ~15;
+  const size_t sub_bytes = (size_t) capL * rec * 8 + rowcapB;
+  const int nr = A.nr[0]; // rows 1..nr of the (0,0) pair's table are addressed: m in [1, nr-1] and m+1
+  const char *ens = getenv("MDP_AEAM_PT_NSUB");
+  const int force_nsub = ens ? atoi(ens) : 0;
+  int nsub = 0, nw = 0;
+  for (int ns = 4; ns >= 2; ns--) {
+    if (force_nsub && ns != force_nsub) continue;
+    const long long room = (long long) c->lds_max - (long long) ns * (long long) sub_bytes - 64;
+    if (room <= 0) continue;
+    int w = (int) (room / 16);
+    if (w > nr) w = nr;
+    // the window has to reach down to ~0.36 of the cutoff (2.3 A of 6.5 A: below the first neighbour shell of a hot
+    // crystal), or -- with fewer waves -- at least to half of it
+    if (w >= (ns == 2 ? 0.5 : 0.64) * nr || force_nsub) {
+      nsub = ns;
+      nw = w;
+      break;
+    }
+  }
+  if (!nsub || nw < 2) return MDP_OK;
+  PTile P = {};
+  P.nlocal = c->nlocal;
+  P.nclus = c->nclus;
+  P.ntile = c->ntile;
+  P.cap = c->tile_cap;
+  P.capL = capL;
+  P.rowcapB = rowcapB;
+  int grid = (c->ntile + nsub - 1) / nsub;
+  if (grid > c->num_cu) grid = c->num_cu;
+  P.per = (c->ntile + grid - 1) / grid;
+  grid = (c->ntile + P.per - 1) / P.per;
+  P.nw = nw;
+  P.wlo = nr + 1 - nw;
+  P.lds_table = mode == PT_FPHI ? A.t2z2r[0] : A.t2rhor[0];
+  P.ys = mode == PT_FPHI ? A.z2r_ys : A.rhor_ys;
+  P.xq = c->xq.p;
+  P.fp = c->fp.p;
+  P.tu = c->tu.p;
+  P.tile_nu = c->tile_nu.p;
+  P.lj_off = c->lj_off.p;
+  P.lj_split = c->lj_split.p;
+  P.lj16 = c->lj16.p;
+  P.rho = c->rho.p;
+  P.f = c->f.p;
+  P.eatom = c->eatom.p;
+  P.acc = c->acc.p;
+  P.eflag = eflag;
+  P.vflag = vflag;
+  {
+    // the reference skips a pair when sqrt(rsq) > cut: the largest rsq that passes, found once on the host
+    const double cut = A.cut[0];
+    double t = cut * cut;
+    while (sqrt(t) > cut) t = nextafter(t, 0.0);
+    while (sqrt(nextafter(t, INFINITY)) <= cut) t = nextafter(t, INFINITY);
+    P.hot_rsqmax = t;
+  }
+  const size_t lds = (size_t) nw * 16 + (size_t) nsub * sub_bytes;
+  const bool ev = eflag || vflag;
+#define MDP_PT(MODEV, NS, EVV)                                                                                        \
+  do {                                                                                                                \
+    if (c->aeam_cl == 2) {                                                                                            \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<MODEV, NS, 2, EVV>,                             \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+      aeam_ptile_kernel<MODEV, NS, 2, EVV><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                           \
+    } else {                                                                                                          \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<MODEV, NS, 1, EVV>,                             \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+      aeam_ptile_kernel<MODEV, NS, 1, EVV><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                           \
+    }                                                                                                                 \
+  } while (0)
+#define MDP_PT_NS(MODEV, EVV)                                                                                         \
+  do {                                                                                                                \
+    if (nsub == 4) MDP_PT(MODEV, 4, EVV);                                                                             \
+    else if (nsub == 3) MDP_PT(MODEV, 3, EVV);                                                                        \
+    else MDP_PT(MODEV, 2, EVV);                                                                                       \
+  } while (0)
+  if (mode == PT_DENSITY) MDP_PT_NS(PT_DENSITY, false);
+  else if (mode == PT_FRHO) {
+    if (ev) MDP_PT_NS(PT_FRHO, true);
+    else MDP_PT_NS(PT_FRHO, false);
+  } else {
+    if (ev) MDP_PT_NS(PT_FPHI, true);
+    else MDP_PT_NS(PT_FPHI, false);
+  }
+#undef MDP_PT_NS
+#undef MDP_PT
+  MDP_HIP(c, hipGetLastError());
+  if (getenv("MDP_DEBUG") && !c->ptile_reported[mode]) {
+    c->ptile_reported[mode] = true;
+    fprintf(stderr, "[mdp] aeam persistent tile kernel mode %d: %d workgroups x %d sub-blocks, %d tiles each, window rows [%d, %d] of %d (%.1f KB), staging %zu B per sub-block\n",
+            mode, grid, nsub, P.per, P.wlo, nr, nr, nw * 16 / 1024.0, sub_bytes);
+  }
+  *done = true;
+  return MDP_OK;
+}
+
 // passes 1 + 2.  Leaves rho[], fp[] (= Fptmp*F') for owned atoms; embedding energy in the accumulators.
 int mdp_aeam_run_density(mdp_ctx *c, int eflag)
 {
@@ -995,7 +1564,10 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   const int nlocal = c->nlocal;
   MDP_TRY(mdp_acc_begin(c, true));
   mdp_time_mark(c, 0);
-  if (nlocal && c->aeam_tiled) {
+  bool persistent = false;
+  if (nlocal && c->aeam_tiled) MDP_TRY(aeam_ptile_launch(c, PT_DENSITY, 0, 0, &persistent));
+  if (persistent) {
+  } else if (nlocal && c->aeam_tiled) {
     const int capL = (c->tile_maxu + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 3 * sizeof(double);
 #define MDP_ATD(CLV)                                                                                                 \
@@ -1043,7 +1615,17 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, st));
   }
-  if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
+  bool persistent = false;
+  // (the force pass as two persistent passes -- rho' terms, phi' terms -- is correct and measured slower than the
+  //  gather kernel, which fetches both derivatives of a pair from one record: 1.4 ms against 0.65 ms; kept for tests)
+  const char *epf = getenv("MDP_AEAM_PERSIST_FORCE");
+  const bool persist_force = epf && atoi(epf) != 0;
+  if (persist_force && nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) {
+    MDP_TRY(aeam_ptile_launch(c, PT_FRHO, eflag, vflag, &persistent));
+    if (persistent) MDP_TRY(aeam_ptile_launch(c, PT_FPHI, eflag, vflag, &persistent));
+  }
+  if (persistent) {
+  } else if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
     const int capL = (c->tile_maxu + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 4 * sizeof(double);
     const bool ev = eflag || vflag;
@@ -1143,6 +1725,14 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     relay_kernel<<<(int) ((zr + 255) / 256), 256, 0, c->stream>>>(zr, c->aeam_z2r.p, c->aeam_z2r_v4.p, c->aeam_z2r_d4.p);
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipStreamSynchronize(c->stream));
+    MDP_HIP(c, c->aeam_rhor_ys.reserve(rr + 1));
+    MDP_HIP(c, c->aeam_z2r_ys.reserve(zr + 1));
+    ys_kernel<<<(int) ((rr + 255) / 256), 256, 0, c->stream>>>(rr, c->aeam_rhor.p, c->aeam_rhor_ys.p);
+    ys_kernel<<<(int) ((zr + 255) / 256), 256, 0, c->stream>>>(zr, c->aeam_z2r.p, c->aeam_z2r_ys.p);
+    MDP_HIP(c, hipGetLastError());
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    A.rhor_ys = c->aeam_rhor_ys.p;
+    A.z2r_ys = c->aeam_z2r_ys.p;
     A.rhor_v4 = c->aeam_rhor_v4.p;
     A.rhor_d4 = c->aeam_rhor_d4.p;
     A.z2r_v4 = c->aeam_z2r_v4.p;

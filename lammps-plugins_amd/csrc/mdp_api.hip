@@ -435,6 +435,8 @@ int mdp_destroy(mdp_ctx *c)
   c->aeam_z2r_v4.release();
   c->aeam_z2r_d4.release();
   c->aeam_pair_d8.release();
+  c->aeam_rhor_ys.release();
+  c->aeam_z2r_ys.release();
   c->aeam_maps.release();
   c->xq.release();
   c->xraw.release();

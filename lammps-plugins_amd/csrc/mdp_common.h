@@ -96,6 +96,7 @@ struct AeamDev {
   int nrho[4], t2frho[4];
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
+  const double2 *rhor_ys, *z2r_ys; // [table][nrmax+1] (value, slope) = columns 6 and 5 of a row: the persistent tile kernels' tables
   const double2 *pair_d6; // [ntypes*ntypes][nrmax+1][3]: {rho' c0 c1 | rho' c2, phi' c0 | phi' c1 c2} of the pair type, 48 B per row
 };
 
@@ -182,6 +183,9 @@ struct mdp_ctx {
   DevBuf<double> aeam_frho, aeam_rhor, aeam_z2r;
   DevBuf<double4> aeam_rhor_v4, aeam_rhor_d4, aeam_z2r_v4, aeam_z2r_d4;
   DevBuf<double> aeam_pair_d8;
+  DevBuf<double2> aeam_rhor_ys, aeam_z2r_ys;
+  int lds_max = 0, num_cu = 0; // device limits (queried once)
+  bool ptile_reported[3] = {false, false, false};
   DevBuf<int> aeam_maps;
 
   // ---- atoms
@@ -237,14 +241,14 @@ struct mdp_ctx {
   // the UNION of their neighbours; its coordinates are staged in LDS once per step and the cluster rows
   // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
   bool lj_tiled = false;
-  int ntile = 0, tile_cap = 0, tile_maxu = 0;
+  int ntile = 0, tile_cap = 0, tile_maxu = 0, tile_rowmax = 0; // (rowmax: most row entries of one tile, generic builder)
   int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: interior small/large, boundary small/large
   bool lj_ordered = false;        // cl_order in use (otherwise natural order, everything in class 0)
   int tile_small = 0;             // largest union of the "small" launch classes
   DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
   DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
   DevBuf<int> tile_nu;            // [ntile] members of each union
-  DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union
+  DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
   DevBuf<int> class_list;         // [MDP_NCLASS][nall]   class = 2 * (lane-group size index) + element

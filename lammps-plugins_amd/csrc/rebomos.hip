@@ -1714,13 +1714,13 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   unsigned short *s_fm = s_m + 4 * wcap;                                 // [cap] masks in final order
   __shared__ double4 s_xa[NA];
   __shared__ double s_cut[NA][2];
-  __shared__ int s_lo[3], s_hi[3], s_n0[4], s_n1[4], s_over;
+  __shared__ int s_lo[3], s_hi[3], s_n0[4], s_n1[4], s_over, s_rowsum;
   const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid < 3) {
     s_lo[tid] = 1 << 30;
     s_hi[tid] = -1;
   }
-  if (tid == 0) s_over = 0;
+  if (tid == 0) s_over = s_rowsum = 0;
   __syncthreads();
   if (tid < NA) {
     const int ia = t * NA + tid;
@@ -1863,11 +1863,14 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   if (sq == 0) {
     cnt[kc] = p0 + p1;
     split[kc] = p0;
+    atomicAdd(&s_rowsum, p0 + p1);
   }
+  __syncthreads();
   if (tid == 0) {
     tile_nu[2 * t] = nU;
     tile_nu[2 * t + 1] = N0;
     atomicMax(&tile_flag[1], nU);
+    atomicMax(&tile_flag[2], s_rowsum); // row entries of the whole tile (kernels that stage a tile's rows in LDS)
   }
 }
 
@@ -2349,7 +2352,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
     for (;;) {
       MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
       MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
-      MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 2, st));
+      MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 3, st));
       const size_t lds = (size_t) 14 * cap; // 4 wave segments of cap/2 (int + ushort) + cap ushort
       if (lds > 48 * 1024)
         MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2542,7 +2545,7 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   for (;;) {
     MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
     MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
-    MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 2, st));
+    MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 3, st));
     const size_t lds = (size_t) 14 * cap;
     if (cl == 1) {
       if (lds > 48 * 1024)
@@ -2560,12 +2563,13 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
                                                    c->tile_flag.p);
     }
     MDP_HIP(c, hipGetLastError());
-    int tf[2] = {0, 0};
-    MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+    int tf[3] = {0, 0, 0};
+    MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
     MDP_HIP(c, hipStreamSynchronize(st));
     if (!tf[0]) {
       c->tile_cap = cap;
       c->tile_maxu = tf[1];
+      c->tile_rowmax = tf[2];
       break;
     }
     cap *= 2;
