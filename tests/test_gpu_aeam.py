@@ -187,3 +187,47 @@ def test_resident_force_only_step_matches_oracle(oracle, T, pot, frac, amp):
     assert np.abs(f_tile - ref).max() < 1e-9
     assert np.abs(f_csr - ref).max() < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"MDP_AEAM_PERSIST": "0"},                                  # gather tile kernels (spline rows from global memory)
+    {},                                                         # persistent density kernel, table window in LDS
+    {"MDP_AEAM_PT_NSUB": "4"},                                  # narrower window, more sub-blocks
+    {"MDP_AEAM_PT_NSUB": "2", "MDP_AEAM_PERSIST_FORCE": "1"},   # the two persistent force passes as well
+])
+def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
+    """Every variant of the two-type tile kernels on a compressed, strongly jittered alloy: 8 % Si puts type-1
+    segments and different-element visits (global-memory rows) into every tile, the compression puts pairs
+    below the LDS window of the persistent kernels (rows read from global memory in their cold pass), and the
+    energy/virial step runs the tallying variants.  All against the CPU oracle."""
+    for k in ("MDP_AEAM_PERSIST", "MDP_AEAM_PT_NSUB", "MDP_AEAM_PERSIST_FORCE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    af, tabs = pot
+    ctx = capi.Context(0)
+    ctx.aeam_set_tables(tabs)
+    s = S.jitter(S.fcc_cell(3.55, 6, frac_type2=0.08, seed=21), 0.12, seed=22)   # nearest neighbours at 2.5 A +- 0.3
+    s.mass[1:3] = af.mass
+    cutghost = float(af.cut_table(tabs).max()) + 1.0
+    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
+    d.build_neighbors()
+    d.compute(eflag=0, vflag=0)
+    got = ctx.md_download(s.n, want=("x", "f"))
+    f_only = got["f"].copy()
+    d.compute(eflag=3, vflag=1)                       # tallying variants of the same kernels
+    t = d.thermo()
+    got_ev = ctx.md_download(s.n, want=("f", "eatom"))
+    x_tag = np.zeros_like(got["x"])
+    x_tag[d.tags_local - 1] = got["x"]
+    eng = mdref.AeamCPU(oracle, T, S.System(s.box, x_tag, s.type, s.tag, s.mass))
+    o = eng.compute(x_tag)
+    ref = o["f_owned"][d.tags_local - 1]
+    r_min = min(np.linalg.norm(x_tag[i] - x_tag[j]) for i in range(0, 40) for j in range(s.n) if i != j)
+    assert r_min < 2.6                                # the point of the compression (window of 4 sub-blocks: r >= 2.5 A)
+    assert np.abs(f_only - ref).max() < 2e-9
+    assert np.abs(got_ev["f"] - ref).max() < 2e-9
+    assert np.abs(got_ev["eatom"] - o["eatom"][:s.n][d.tags_local - 1]).max() < 1e-9
+    assert t["pe"] == pytest.approx(o["eng"], rel=1e-11)
+    assert np.allclose(t["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    ctx.close()
