@@ -1757,16 +1757,49 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   const unsigned long long below = (1ull << lane) - 1ull;
   int n0 = 0, n1 = 0;
   bool over = false;
-  for (int r = wave; r < nrows && !over; r += 4) {
-    const int y = ylo + r % ny, z = zlo + r / ny;
-    const int pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
-    const int pe = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1];
-    for (int p0 = pb; p0 < pe; p0 += 64) {
-      const int p = p0 + lane;
+  // The candidates of the (y,z) rows of cells are taken as ONE concatenated list, 64 per wave and trip: a row by
+  // itself holds 15-40 atoms, so a wave walking row after row had a quarter to a half of its lanes busy in front of
+  // two dependent round trips per row.  (The order in which members are found does not matter: tile_sort_kernel
+  // sorts every segment by atom index.)
+  constexpr int kRows = 256;
+  __shared__ int s_pb[kRows], s_off[kRows + 1], s_wsum[4];
+  for (int rbase = 0; rbase < nrows; rbase += kRows) {
+    const int nr = nrows - rbase < kRows ? nrows - rbase : kRows;
+    int pb = 0, len = 0;
+    if (tid < nr) {
+      const int r = rbase + tid;
+      const int y = ylo + r % ny, z = zlo + r / ny;
+      pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
+      len = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1] - pb;
+    }
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += s_wsum[w];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    s_pb[tid] = pb;
+    s_off[tid] = wbase + incl - len;
+    if (tid == 0) s_off[kRows] = total;
+    __syncthreads();
+    for (int g0 = wave * 64; g0 < total && !over; g0 += 256) {
+      const int gi = g0 + lane;
       unsigned m = 0;
       int j = 0, tj = 0;
-      if (p < pe) {
-        j = perm[p];
+      if (gi < total) {
+        int lo = 0, hi = kRows; // s_off[lo] <= gi < s_off[hi]  (rows past nr are empty: offset = total)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int mid = (lo + hi) >> 1;
+          if (s_off[mid] <= gi) lo = mid;
+          else hi = mid;
+        }
+        j = perm[s_pb[lo] + gi - s_off[lo]];
         const double4 xj = xq[j];
         tj = (int) xj.w;
         if (tj >= 0) {
@@ -1798,6 +1831,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
       n0 += c0;
       n1 += c1;
     }
+    __syncthreads(); // (s_pb / s_off are rewritten by the next block of rows)
   }
   if (lane == 0) {
     s_n0[wave] = n0;
