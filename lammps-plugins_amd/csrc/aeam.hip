@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         const double dx = xj.x - xa[c].x, dy = xj.y - xa[c].y, dz = xj.z - xa[c].z;
         const double rsq = dx * dx + dy * dy + dz * dz;
         const bool pair = real[c] && rsq > 0.0; // (the union holds the cluster's own atoms too)
-        const double recip = rsqrt_nr(pair ? rsq : 1.0);
+        const double recip = rsqrt_n1(pair ? rsq : 1.0); // one Newton step: 2e-15 relative, see rsqrt_n1
         const double r = rsq * recip;
         const bool in_a = pair && r <= qA[c].cut, in_j = pair && r <= qJ[c].cut;
         if (!(in_a || in_j)) continue;
