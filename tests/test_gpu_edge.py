@@ -125,3 +125,30 @@ def test_aeam_small_clusters(aeam, name):
     assert abs(g["eng"] - o["eng"]) < 1e-10 * max(1.0, abs(o["eng"]))
     assert np.abs(g["eatom"] - o["eatom"][:len(t)]).max() < 1e-10 * max(1.0, abs(o["eng"]))
     assert np.allclose(g["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-9 * scale)
+
+
+def test_rebomos_sparse_gas_in_a_large_box(rebo):
+    """64 atoms scattered over a 200 A box, some of them in bonded pairs and trimers: the one or two tiles they form
+    span the whole cell grid (about 30 x 30 rows of cells), so the tile-list builder goes through several blocks of
+    its row table and most candidate rows are empty."""
+    rng = np.random.default_rng(4242)
+    x = rng.random((40, 3)) * 180.0 - 90.0
+    extra, types = [], [int(t) for t in rng.integers(1, 3, size=40)]
+    for k in range(8):                                   # Mo-S dimers and S-Mo-S trimers next to some of the atoms
+        extra.append(x[k] + [2.41, 0.0, 0.0])
+        types[k] = 1
+        types.append(2)
+    for k in range(8, 16):
+        extra.append(x[k] + [0.0, 2.35, 0.4])
+        extra.append(x[k] + [0.3, -2.3, 0.5])
+        types[k] = 1
+        types += [2, 2]
+    x = np.vstack([x, np.array(extra)])
+    box = S.Box(np.zeros(3), np.array([200.0, 200.0, 200.0]), np.zeros(3))
+    s = S.System(box, x + 100.0, np.asarray(types, dtype=np.int32), np.arange(1, len(x) + 1, dtype=np.int32),
+                 np.array((0.0, 95.95, 32.065)))
+    g, o = _rebo_both(rebo, s)
+    assert np.abs(o["f_owned"]).max() > 0.1              # the bonded atoms do feel forces
+    assert np.abs(g["f"] - o["f_owned"]).max() < 1e-9
+    assert abs(g["eng"] - o["eng"]) < 1e-10 * max(1.0, abs(o["eng"]))
+    assert np.abs(g["eatom"] - o["eatom_owned"]).max() < 1e-10
