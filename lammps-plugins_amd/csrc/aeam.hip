@@ -379,56 +379,76 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
       qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
       qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
     }
-    // (plain loops: batching the loads of several entries was tried and lost to the occupancy it costs)
+    // Per trip: the geometry of all cluster atoms first, then the records of their visits (a -> j) requested
+    // together (each under its own predicate), then the arithmetic: the round trips of the cluster atoms overlap.
+    // (Batching several ENTRIES was tried and lost to the occupancy it costs.)
     int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is requested one trip ahead
     for (int k = kb + s; k < ke; k += L) {
       const double4 xj = s4[li_next];
       li_next = k + L < ke ? (int) row[k + L] : nU;
+      double dx[CL], dy[CL], dz[CL], recip[CL], r[CL], pfa[CL];
+      bool in_a[CL], in_j[CL];
+      int ma[CL];
+      double2 r0[CL], r1[CL], r2[CL];
 #pragma unroll
       for (int c = 0; c < CL; c++) {
-        const double dx = xj.x - xa[c].x, dy = xj.y - xa[c].y, dz = xj.z - xa[c].z;
-        const double rsq = dx * dx + dy * dy + dz * dz;
+        dx[c] = xj.x - xa[c].x;
+        dy[c] = xj.y - xa[c].y;
+        dz[c] = xj.z - xa[c].z;
+        const double rsq = dx[c] * dx[c] + dy[c] * dy[c] + dz[c] * dz[c];
         const bool pair = real[c] && rsq > 0.0; // (the union holds the cluster's own atoms too)
-        const double recip = rsqrt_n1(pair ? rsq : 1.0); // one Newton step: 2e-15 relative, see rsqrt_n1
-        const double r = rsq * recip;
-        const bool in_a = pair && r <= qA[c].cut, in_j = pair && r <= qJ[c].cut;
-        if (!(in_a || in_j)) continue;
-        double fpair_a = 0.0, fpair_j = 0.0, dfa = 0.0;
-        if (in_a) {
-          double pf;
-          const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
-          const double2 *rec = A.pair_d6 + 3 * ((size_t) qA[c].pair * nm1 + m); // same row m for both (pair_aeam.cpp:367)
-          const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-          dfa = (r0.x * pf + r0.y) * pf + r1.x;
-          const double phip = (r1.y * pf + r2.x) * pf + r2.y;
-          fpair_a = -qa[c] * dfa * recip + 0.5 * (-phip * recip);
-          if (EV) ea[c] += 0.5 * v4_val(A.z2r_v4[(size_t) qA[c].tz2r * nm1 + m], pf); // credited to i only
+        recip[c] = rsqrt_n1(pair ? rsq : 1.0);
+        r[c] = rsq * recip[c];
+        in_a[c] = pair && r[c] <= qA[c].cut;
+        in_j[c] = pair && r[c] <= qJ[c].cut;
+        ma[c] = spline_index(r[c], qA[c].rdr, qA[c].nr, pfa[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        r0[c] = r1[c] = r2[c] = make_double2(0.0, 0.0);
+        if (in_a[c]) {
+          const double2 *rec = A.pair_d6 + 3 * ((size_t) qA[c].pair * nm1 + ma[c]); // same row m for both (pair_aeam.cpp:367)
+          r0[c] = rec[0];
+          r1[c] = rec[1];
+          r2[c] = rec[2];
         }
-        if (in_j) {
+      }
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        if (!(in_a[c] || in_j[c])) continue;
+        double fpair_a = 0.0, fpair_j = 0.0, dfa = 0.0;
+        if (in_a[c]) {
+          const double pf = pfa[c];
+          dfa = (r0[c].x * pf + r0[c].y) * pf + r1[c].x;
+          const double phip = (r1[c].y * pf + r2[c].x) * pf + r2[c].y;
+          fpair_a = -qa[c] * dfa * recip[c] + 0.5 * (-phip * recip[c]);
+          if (EV) ea[c] += 0.5 * v4_val(A.z2r_v4[(size_t) qA[c].tz2r * nm1 + ma[c]], pf); // credited to i only
+        }
+        if (in_j[c]) {
           const double qj = xj.w;
-          if (TJ == ta[c] && in_a) { // same element: both visits read the same table rows
-            fpair_j = fpair_a + (qa[c] - qj) * dfa * recip;
+          if (TJ == ta[c] && in_a[c]) { // same element: both visits read the same table rows
+            fpair_j = fpair_a + (qa[c] - qj) * dfa * recip[c];
           } else {
             double pf;
-            const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
+            const int m = spline_index(r[c], qJ[c].rdr, qJ[c].nr, pf);
             const double2 *rec = A.pair_d6 + 3 * ((size_t) qJ[c].pair * nm1 + m);
-            const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            const double dfja = (r0.x * pf + r0.y) * pf + r1.x;
-            const double phip = (r1.y * pf + r2.x) * pf + r2.y;
-            fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
+            const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2];
+            const double dfja = (j0.x * pf + j0.y) * pf + j1.x;
+            const double phip = (j1.y * pf + j2.x) * pf + j2.y;
+            fpair_j = -qj * dfja * recip[c] + 0.5 * (-phip * recip[c]);
           }
         }
         const double ft = fpair_a + fpair_j;
-        fx[c] -= dx * ft;
-        fy[c] -= dy * ft;
-        fz[c] -= dz * ft;
+        fx[c] -= dx[c] * ft;
+        fy[c] -= dy[c] * ft;
+        fz[c] -= dz[c] * ft;
         if (EV) { // ev_tally(i = a, j, ..., fpair_a, d): every rank tallies its own visits
-          v0 += dx * dx * fpair_a;
-          v1 += dy * dy * fpair_a;
-          v2 += dz * dz * fpair_a;
-          v3 += dx * dy * fpair_a;
-          v4 += dx * dz * fpair_a;
-          v5 += dy * dz * fpair_a;
+          v0 += dx[c] * dx[c] * fpair_a;
+          v1 += dy[c] * dy[c] * fpair_a;
+          v2 += dz[c] * dz[c] * fpair_a;
+          v3 += dx[c] * dy[c] * fpair_a;
+          v4 += dx[c] * dz[c] * fpair_a;
+          v5 += dy[c] * dz[c] * fpair_a;
         }
       }
     }
