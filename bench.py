@@ -317,7 +317,7 @@ def main():
         knames = ["rebo_centre_kernel<4|8|12|16|32>", lj]
     else:
         # timed phases of the AEAM path (each is the named kernels back to back on the compute stream)
-        dens = "aeam_tile_density_kernel" if os.environ.get("MDP_AEAM_PERSIST", "1") == "0" else "aeam_ptile_kernel<density>"
+        dens = "aeam_tile_density_kernel" if os.environ.get("MDP_AEAM_PERSIST", "") == "0" else "aeam_ptile_kernel<density>"
         knames = [dens + "+aeam_density_ang_kernel", "aeam_embed_kernel",
                   "aeam_tile_force_kernel+aeam_force_ang_kernel"]
     kdom = int(np.argmax(kms[:len(knames)]))

@@ -1466,9 +1466,12 @@ int mdp_aeam_prepare(mdp_ctx *c)
 static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const int vflag, bool *done)
 {
   *done = false;
-  if (const char *e = getenv("MDP_AEAM_PERSIST"))
-    if (atoi(e) == 0) return MDP_OK;
+  const char *epers = getenv("MDP_AEAM_PERSIST"); // unset: decided here; 0: never; 1: whenever a window fits
+  if (epers && atoi(epers) == 0) return MDP_OK;
   if (c->tile_rowmax <= 0) return MDP_OK;
+  // the LDS-resident table is the (0,0) pair's: with many atoms of the other type most pairs would take the cold
+  // pass (rows from global memory, behind the hot pass) and the gather kernels are the better choice
+  if (!epers && (double) c->h_ang_count > 0.1 * (double) c->nlocal) return MDP_OK;
   if (!c->lds_max) {
     int v = 0, n = 0;
     MDP_HIP(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));

@@ -191,9 +191,10 @@ def test_resident_force_only_step_matches_oracle(oracle, T, pot, frac, amp):
 
 @pytest.mark.parametrize("env", [
     {"MDP_AEAM_PERSIST": "0"},                                  # gather tile kernels (spline rows from global memory)
-    {},                                                         # persistent density kernel, table window in LDS
-    {"MDP_AEAM_PT_NSUB": "4"},                                  # narrower window, more sub-blocks
-    {"MDP_AEAM_PT_NSUB": "2", "MDP_AEAM_PERSIST_FORCE": "1"},   # the two persistent force passes as well
+    {"MDP_AEAM_PERSIST": "1"},                                  # persistent density kernel, table window in LDS
+    {"MDP_AEAM_PERSIST": "1", "MDP_AEAM_PT_NSUB": "4"},         # narrower window, more sub-blocks
+    {"MDP_AEAM_PERSIST": "1", "MDP_AEAM_PT_NSUB": "2", "MDP_AEAM_PERSIST_FORCE": "1"},   # the two persistent force passes as well
+    {},                                                         # the library's own choice
 ])
 def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     """Every variant of the two-type tile kernels on a compressed, strongly jittered alloy: 8 % Si puts type-1
