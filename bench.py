@@ -280,11 +280,13 @@ def main():
     run(args.warmup, 0)
     sync_all()
     style_builds0 = ctx.md_neighbor_stats()[7]
+    prune0 = ctx.md_prune_stats()
     t0 = time.perf_counter()
     rebuilds = run(args.steps, args.warmup)
     sync_all()
     elapsed = time.perf_counter() - t0
     style_builds = ctx.md_neighbor_stats()[7] - style_builds0 if args.workload == "rebomos" else 0
+    prune1 = ctx.md_prune_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if stage_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +373,10 @@ def main():
                    "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
                                   else "adaptive from 1.0") if args.workload == "rebomos" else None,
                    "style_list_builds_in_timed_region_rank0": int(style_builds),
+                   "row_prunings_in_timed_region_rank0": prune1["prunings"] - prune0["prunings"],
+                   "row_prunings_late_rank0": prune1["late"] - prune0["late"],
+                   "row_pruning": (f"tile rows re-filtered to window + {prune1['buffer']:.2f} A from the current positions, "
+                                   "own displacement trigger") if prune1["active"] else "off",
                    "pe_per_atom_start_eV": round(pe0 / s.n, 6), "pe_per_atom_end_eV": round(th1["pe"] / s.n, 6),
                    "temp_end_K": round(th1["temp"], 2)},
         "roofline": {"bound": "hbm", "achieved": round(path_achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -240,6 +240,13 @@ void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
  * [5]=#centres in 4-lane groups, [6]=#centres in 12- and 16-lane groups, [7]=style-list builds so far (rebomos) /
  * #angular atoms (aeam) */
 int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
+/* dynamic pruning of the tile rows in resident runs (between list builds the rows are re-filtered from the current
+ * positions to the entries within window + buffer of a cluster atom; the reference walks its whole list every step,
+ * pair_rebomos.cpp:490-521 -- same pairs evaluated, fewer entries tested):
+ * out[0]=prunings so far, [1]=prunings that came late (an atom had moved more than half the buffer when the
+ * deferred trigger was read; the analogue of LAMMPS' "dangerous builds"), [2]=1 if the kernels currently walk pruned
+ * rows, [3]=buffer in units of 1e-6 Angstrom */
+int mdp_md_prune_stats(mdp_ctx *ctx, long long out[4]);
 /* shape of the rebomos style's own Lennard-Jones lists after the last build (host and resident mode):
  * out[0]=1 tile lists / 0 per-cluster lists (fallback), [1]=#tiles, [2]=union stride, [3]=largest union,
  * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,

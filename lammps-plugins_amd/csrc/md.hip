@@ -919,6 +919,16 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
   return MDP_OK;
 }
 
+int mdp_md_prune_stats(mdp_ctx *c, long long out[4])
+{
+  if (!c || !out) return MDP_EINVAL;
+  out[0] = c->prunes;
+  out[1] = c->dangerous_prunes;
+  out[2] = c->prune_valid ? 1 : 0;
+  out[3] = (long long) (c->prune_buf * 1.0e6 + 0.5);
+  return MDP_OK;
+}
+
 // ---- halo plumbing -----------------------------------------------------------------------------------
 int mdp_md_pack_x(mdp_ctx *c, int n, const int *d_sendlist, const double *d_shift, double *d_buf)
 {

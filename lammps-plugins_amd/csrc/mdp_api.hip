@@ -461,6 +461,10 @@ int mdp_destroy(mdp_ctx *c)
   c->lj.release();
   c->tu.release();
   c->tmask.release();
+  c->lj16_in.release();
+  c->lj_len_in.release();
+  c->lj_split_in.release();
+  c->xhold_prune.release();
   c->tile_nu.release();
   c->tile_flag.release();
   c->lj16.release();

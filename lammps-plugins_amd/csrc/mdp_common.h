@@ -247,6 +247,16 @@ struct mdp_ctx {
   int tile_small = 0;             // largest union of the "small" launch classes
   DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
   DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
+  // dynamic pruning of the tile rows (resident mode): between two list builds the rows are re-filtered, from the
+  // current positions, to the entries within window + prune_buf of a cluster atom; the kernels walk the pruned rows
+  // until an atom has moved prune_buf/2 since (second trigger of moved_kernel), then they are pruned again
+  DevBuf<unsigned short> lj16_in; // pruned rows, at the offsets of the rows as built
+  DevBuf<int> lj_len_in, lj_split_in; // their lengths and splits
+  DevBuf<double> xhold_prune;     // [nall][3] positions at the last pruning
+  bool prune_valid = false, prune_stale = false;
+  double prune_buf = 0.3;
+  int prune_epoch = 0, prune_check_epoch = -1, prune_copied_epoch = -1, prunes = 0, dangerous_prunes = 0;
+  int computes_since_prune = 0;
   DevBuf<int> tile_nu;            // [ntile] members of each union
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union

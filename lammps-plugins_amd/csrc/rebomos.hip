@@ -1180,6 +1180,7 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
     const double4 *__restrict__ xq, const int cap, const int capL, const int skip_above,
     const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
+    const int *__restrict__ lj_len /* row lengths of the pruned rows, or null: the rows as built */,
     const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, const int *__restrict__ cand_off,
     const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const int *__restrict__ rev16,
     const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
@@ -1213,7 +1214,7 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // rows are cap >= 2048 long: always in bounds
   const long long b = lj_off[kc];
   // segment lengths are equal for the four clusters of a wave by construction (tile_scan_kernel): scalars
-  const int cnt = __builtin_amdgcn_readfirstlane(live ? (int) (lj_off[kc + 1] - b) : 0);
+  const int cnt = __builtin_amdgcn_readfirstlane(live ? (lj_len ? lj_len[kc] : (int) (lj_off[kc + 1] - b)) : 0);
   const int split = __builtin_amdgcn_readfirstlane(live ? lj_split[kc] : 0);
   const unsigned short *__restrict__ row = lj16 + b;
   double4 xa[CL];
@@ -1999,6 +2000,96 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const int nclus, const i
   }
 }
 
+// Dynamic pruning of the rows (between list builds): every row entry is tested against the cluster's atoms at
+// the CURRENT positions and kept when it lies within (upper window bound + buffer) of one of them; the kept entries
+// are compacted into a second set of rows at the same offsets (segments padded as tile_scan_kernel pads them).
+// The list skin -- a third of the entries of a list built with 1 A of it -- then costs a pass of this kernel every
+// few tens of steps instead of an evaluation in every step; the rows as built stay, the buffer has its own
+// displacement trigger (moved_kernel), and an entry is never missed: it enters a window only after the two atoms
+// together moved the buffer, i.e. one of them half of it.
+struct PruneLimits {
+  double rsq[4]; // (window upper bound + buffer)^2 per pair type ti * 2 + tj
+};
+__global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, const int nlocal, const int nclus,
+                                                         const double4 *__restrict__ xq, const int cap,
+                                                         const int *__restrict__ tu, const int *__restrict__ tile_nu,
+                                                         const long long *__restrict__ lj_off,
+                                                         const int *__restrict__ lj_split,
+                                                         const unsigned short *__restrict__ lj16,
+                                                         unsigned short *__restrict__ lj16_in,
+                                                         int *__restrict__ len_in, int *__restrict__ split_in)
+{
+  constexpr int CL = 2, L = 16;
+  extern __shared__ double s_pos[]; // [nU][3]
+  const int tid = threadIdx.x, lane = tid & 63, s = lane % L, glane0 = lane - s;
+  const int t = blockIdx.x;
+  const int kc = t * MDP_TILE + tid / L;
+  const int nU = tile_nu[2 * t];
+  const int *__restrict__ mem = tu + (size_t) t * cap;
+  for (int u = tid; u < nU; u += 256) {
+    const double4 v = xq[mem[u]];
+    s_pos[3 * u] = v.x;
+    s_pos[3 * u + 1] = v.y;
+    s_pos[3 * u + 2] = v.z;
+  }
+  const long long b = lj_off[kc];
+  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
+  const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
+  const unsigned short *__restrict__ row = lj16 + b;
+  unsigned short *__restrict__ out = lj16_in + b;
+  double4 xa[CL];
+  bool real[CL];
+  int ta[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) {
+    const int ia = kc * CL + c;
+    real[c] = kc < nclus && ia < nlocal;
+    xa[c] = xq[real[c] ? ia : nlocal - 1];
+    ta[c] = (int) xa[c].w;
+    if (ta[c] < 0) { // type mapped to NULL: takes part in nothing
+      real[c] = false;
+      ta[c] = 0;
+    }
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << s) - 1ull;
+  int pseg[2];
+  int base = 0;
+#pragma unroll
+  for (int seg = 0; seg < 2; seg++) {
+    const int kb = seg ? split : 0, ke = seg ? cnt : split;
+    double lim_c[CL];
+#pragma unroll
+    for (int c = 0; c < CL; c++) lim_c[c] = lim.rsq[ta[c] * 2 + seg];
+    int n = 0;
+    for (int k = kb; k < ke; k += L) { // (segments are whole 16-lane steps, equally long for the rows of a wave)
+      const int li = (int) row[k + s];
+      bool keep = false;
+      if (li < nU) {
+        const double xj = s_pos[3 * li], yj = s_pos[3 * li + 1], zj = s_pos[3 * li + 2];
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dx = xa[c].x - xj, dy = xa[c].y - yj, dz = xa[c].z - zj;
+          keep = keep || (real[c] && dx * dx + dy * dy + dz * dz <= lim_c[c]);
+        }
+      }
+      const unsigned long long gb = (__ballot(keep) >> glane0) & 0xFFFFull;
+      if (keep) out[base + n + __popcll(gb & below)] = (unsigned short) li;
+      n += __popcll(gb);
+    }
+    int p = (n + 15) & ~15;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) p = max(p, __shfl_xor(p, o, 64));
+    for (int q = n + s; q < p; q += L) out[base + q] = (unsigned short) nU; // padding: the dummy slot
+    pseg[seg] = p;
+    base += p;
+  }
+  if (s == 0) {
+    split_in[kc] = pseg[0];
+    len_in[kc] = pseg[0] + pseg[1];
+  }
+}
+
 // does the tile's union reach a remote ghost?  Such tiles wait for the halo.
 __global__ __launch_bounds__(256) void tile_boundary_kernel(const int ntile, const int cap, const int remote_start,
                                                             const int *__restrict__ tile_nu,
@@ -2112,11 +2203,14 @@ __global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, 
 }
 
 // flag[0]: someone moved beyond the trigger; flag[1]: beyond the hard limit (half the inner skin)
+// flag[2], flag[3]: the same against the positions of the last pruning of the rows (xprune, may be null)
 __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double trigsq, const double hardsq,
                                                     const double4 *__restrict__ xq,
-                                                    const double *__restrict__ xhold, int *__restrict__ flag)
+                                                    const double *__restrict__ xhold, int *__restrict__ flag,
+                                                    const double *__restrict__ xprune, const double ptrigsq,
+                                                    const double phardsq)
 {
-  bool far = false, toofar = false;
+  bool far = false, toofar = false, pfar = false, ptoofar = false;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nall; i += gridDim.x * 256) {
     const double4 x = xq[i];
     const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1],
@@ -2124,6 +2218,17 @@ __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double
     const double d2 = dx * dx + dy * dy + dz * dz;
     far = far || d2 > trigsq;
     toofar = toofar || d2 > hardsq;
+    if (xprune) {
+      const double px = x.x - xprune[3 * (size_t) i], py = x.y - xprune[3 * (size_t) i + 1],
+                   pz = x.z - xprune[3 * (size_t) i + 2];
+      const double p2 = px * px + py * py + pz * pz;
+      pfar = pfar || p2 > ptrigsq;
+      ptoofar = ptoofar || p2 > phardsq;
+    }
+  }
+  if (xprune) {
+    if (__any(pfar) && (threadIdx.x & 63) == 0) flag[2] = 1;
+    if (__any(ptoofar) && (threadIdx.x & 63) == 0) flag[3] = 1;
   }
   // `flag` is pinned HOST memory (zeroed by the host before the launch): plain idempotent stores, visible when the
   // kernel has completed -- no memset and no copy engine in the per-step path
@@ -2463,6 +2568,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (tiled)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
                                             c->lj16.p);
+  c->prune_valid = false; // (new rows: the pruned copy is made at the next compute that wants it)
+  c->prune_stale = false;
+  c->prune_epoch++;
   if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
     if (cl == 1) MDP_CB(1, true, c->lj_off.p, c->lj.p);
@@ -2635,6 +2743,7 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
 //                   for the GPU inside the MD loop; the trigger is lowered by kStaleMargin to cover the one
 //                   step of extra motion, and a true violation is counted as a "dangerous build"
 constexpr double kStaleMargin = 0.1; // Angstrom
+constexpr double kPruneMargin = 0.05; // the same for the pruned rows' trigger (their buffer is a fraction of the skin)
 
 static int rebomos_check_launch(mdp_ctx *c, const double trig)
 {
@@ -2643,8 +2752,15 @@ static int rebomos_check_launch(mdp_ctx *c, const double trig)
   const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
   const double hard = 0.5 * c->skin_inner;
   int *h = (int *) (c->h_pinned + 24); // no check is in flight here: the caller has waited for the previous one
-  h[0] = h[1] = 0;
-  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, h);
+  h[0] = h[1] = h[2] = h[3] = 0;
+  // (pruned rows: their own, smaller trigger against the positions of the last pruning)
+  const bool pr = c->prune_valid;
+  double ptrig = 0.5 * c->prune_buf - kPruneMargin;
+  if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
+  const double phard = 0.5 * c->prune_buf;
+  c->prune_check_epoch = c->prune_epoch;
+  moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, h,
+                                     pr ? c->xhold_prune.p : nullptr, ptrig * ptrig, phard * phard);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -2669,6 +2785,10 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
     MDP_HIP(c, hipEventSynchronize(c->ev_stale)); // recorded a whole step ago
     stale = h[0] != 0;
     if (h[1]) c->dangerous_builds++;
+    if (c->prune_check_epoch == c->prune_epoch) { // (a check launched before the last pruning says nothing about it)
+      if (h[2]) c->prune_stale = true;
+      if (h[3]) c->dangerous_prunes++;
+    }
     c->stale_pending = false;
   }
   if (!stale) {
@@ -2697,6 +2817,41 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
   }
 }
 
+// (Re-)prune the Lennard-Jones rows from the current positions (tile_prune_kernel) and remember those positions.
+static int rebomos_prune(mdp_ctx *c)
+{
+  hipStream_t st = c->stream;
+  const int nrow = c->ntile * MDP_TILE;
+  MDP_HIP(c, c->lj_len_in.reserve(nrow + 1));
+  MDP_HIP(c, c->lj_split_in.reserve(nrow + 1));
+  MDP_HIP(c, c->xhold_prune.reserve((size_t) 3 * c->nall + 3));
+  if (c->prune_copied_epoch != c->prune_epoch) { // rows were rebuilt: start from a full copy (reads past a pruned
+    MDP_HIP(c, c->lj16_in.reserve((size_t) c->lj_total + 256)); // segment's end must find valid indices)
+    MDP_HIP(c, hipMemcpyAsync(c->lj16_in.p, c->lj16.p, sizeof(unsigned short) * ((size_t) c->lj_total + 256),
+                              hipMemcpyDeviceToDevice, st));
+    c->prune_copied_epoch = c->prune_epoch;
+  }
+  PruneLimits lim;
+  for (int k = 0; k < 4; k++) {
+    const double r = sqrt(c->rebomos.lj_rsq_hi[k]) + c->prune_buf;
+    lim.rsq[k] = r * r;
+  }
+  const size_t lds = (size_t) (c->tile_maxu + 1) * 3 * sizeof(double);
+  if (lds > 48 * 1024)
+    MDP_HIP(c, hipFuncSetAttribute((const void *) tile_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  tile_prune_kernel<<<c->ntile, 256, lds, st>>>(lim, c->nlocal, c->nclus, c->xq.p, c->tile_cap, c->tu.p, c->tile_nu.p,
+                                                c->lj_off.p, c->lj_split.p, c->lj16.p, c->lj16_in.p, c->lj_len_in.p,
+                                                c->lj_split_in.p);
+  if (c->nall) hold_all_kernel<<<(c->nall + 255) / 256, 256, 0, st>>>(c->nall, c->xq.p, c->xhold_prune.p);
+  MDP_HIP(c, hipGetLastError());
+  c->prune_valid = true;
+  c->prune_stale = false;
+  c->prune_epoch++; // (a displacement check launched before this says nothing about the new reference)
+  c->prune_copied_epoch = c->prune_epoch;
+  c->prunes++;
+  return MDP_OK;
+}
+
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
 // one launch class of the Lennard-Jones units (see unit_class_kernel): 0/1 interior, 2/3 boundary; odd = large unions
 static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, bool accumulate)
@@ -2714,6 +2869,7 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
   }
   const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
   if (c->lj_tiled) {
+    const bool pruned = c->prune_valid; // rows pruned to the pairs that can be inside a window right now
     const bool small = !(klass & 1);
     const int capL = ((small ? c->tile_small : c->tile_maxu) + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 3 * sizeof(double);
@@ -2724,7 +2880,8 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                       \
     rebo_lj_tile_kernel<EVV, GV, WV><<<count, 256, lds, st>>>(                                                      \
         c->rebomos, c->nlocal, order, first, c->nclus, c->xq.p, c->tile_cap, capL, skip_above, c->tu.p,            \
-        c->tile_nu.p, c->lj_off.p, c->lj_split.p, c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p,       \
+        c->tile_nu.p, c->lj_off.p, pruned ? c->lj_len_in.p : nullptr, pruned ? c->lj_split_in.p : c->lj_split.p,    \
+        pruned ? c->lj16_in.p : c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p,                         \
         c->fnbr.p,                                                                                                  \
         c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                \
   } while (0)
@@ -2843,6 +3000,7 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
     MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
   mdp_time_mark(c, 1);
   if (c->split_halo || va) {
+    c->prune_valid = false; // (these paths walk the rows as built)
     for (int k = c->split_halo ? 2 : 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
     if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
@@ -2857,6 +3015,29 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
       }
     }
   } else {
+    // resident runs walk pruned rows (see tile_prune_kernel); host mode re-uploads positions every step and is
+    // bound by that, a per-atom-virial step reads the rows as built
+    static const int prune_on = [] { const char *e = getenv("MDP_PRUNE"); return e ? atoi(e) : 1; }();
+    if (prune_on && c->md && c->lj_tiled && c->ntile > 0) {
+      static const double fixed_buf = [] { const char *e = getenv("MDP_PRUNE_BUFFER"); return e ? atof(e) : 0.0; }();
+      if (fixed_buf > 0.0) c->prune_buf = fixed_buf;
+      else if (c->prune_valid && c->prune_stale) {
+        // the buffer adapts like the inner skin: a pruning costs about a third of a Lennard-Jones pass, so a trigger
+        // that fires within a dozen computes (thermal vibration reaching half the buffer) widens it, one that stays
+        // quiet for long narrows it
+        if (c->computes_since_prune < 12 && c->prune_buf + 0.1 <= c->skin_inner - 0.2 + 1e-9) c->prune_buf += 0.1;
+        else if (c->computes_since_prune > 60 && c->prune_buf - 0.05 >= 0.2 - 1e-9) c->prune_buf -= 0.05;
+      }
+      if (c->prune_buf < c->skin_inner) { // (a buffer as wide as the skin prunes nothing)
+        if (!c->prune_valid || c->prune_stale) {
+          MDP_TRY(rebomos_prune(c));
+          c->computes_since_prune = 0;
+        }
+        c->computes_since_prune++;
+      } else
+        c->prune_valid = false;
+    } else
+      c->prune_valid = false;
     for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, /*gather=*/true, eflag, vflag, false));
   }
   MDP_HIP(c, hipGetLastError());
