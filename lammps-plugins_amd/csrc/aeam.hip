@@ -206,7 +206,8 @@ template <int CL>
 __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const int cap, const int capL,
     const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
-    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, double *__restrict__ rho)
+    const int *__restrict__ lj_len /* lengths of pruned rows, or null */, const int *__restrict__ lj_split,
+    const unsigned short *__restrict__ lj16, double *__restrict__ rho)
 {
   constexpr int L = 16, SK = 3;
   extern __shared__ double s_pos[]; // [capL][3]
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
 #pragma unroll
   for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k];
   const long long b = lj_off[kc];
-  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
+  const int cnt = __builtin_amdgcn_readfirstlane(lj_len ? lj_len[kc] : (int) (lj_off[kc + 1] - b));
   const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
   const unsigned short *__restrict__ row = lj16 + b;
   double4 xa[CL];
@@ -309,7 +310,8 @@ template <int CL, bool EV>
 __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const double *__restrict__ fp,
     const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
-    const long long *__restrict__ lj_off, const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16,
+    const long long *__restrict__ lj_off, const int *__restrict__ lj_len /* lengths of pruned rows, or null */,
+    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16,
     double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag)
 {
   constexpr int L = 16, SK = 3;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
 #pragma unroll
   for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k];
   const long long b = lj_off[kc];
-  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
+  const int cnt = __builtin_amdgcn_readfirstlane(lj_len ? lj_len[kc] : (int) (lj_off[kc + 1] - b));
   const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
   const unsigned short *__restrict__ row = lj16 + b;
   double4 xa[CL];
@@ -534,6 +536,7 @@ struct PTile {
   const double *fp;
   const int *tu, *tile_nu;
   const long long *lj_off;
+  const int *lj_len; // lengths of pruned rows (at the offsets of the rows as built), or null
   const int *lj_split;
   const unsigned short *lj16;
   const double2 *ys; // [table][nrmax+1] (value, slope) rows of the pass's function
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     }
     const int kc = m_t * kTile + gq;
     n_b = off_lo[2 * kc];
-    n_b1 = off_lo[2 * kc + 2];
+    n_b1 = P.lj_len ? P.lj_len[kc] : off_lo[2 * kc + 2]; // (pruned rows: the length itself)
     n_split = P.lj_split[kc];
 #pragma unroll
     for (int c = 0; c < CL; c++) {
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
   for (int rd = 0; rd < rounds; rd++) {
     // ---- the tile to compute now: heads out of the stage registers ----
     const int t = n_t, nU = n_nU;
-    const int cnt = __builtin_amdgcn_readfirstlane(nU ? n_b1 - n_b : 0);
+    const int cnt = __builtin_amdgcn_readfirstlane(nU ? (P.lj_len ? n_b1 : n_b1 - n_b) : 0);
     const int split = __builtin_amdgcn_readfirstlane(nU ? n_split : 0);
     const int roff = n_b - (int) n_rb;
     const int kc = t * kTile + gq;
@@ -1523,8 +1526,9 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
   P.tu = c->tu.p;
   P.tile_nu = c->tile_nu.p;
   P.lj_off = c->lj_off.p;
-  P.lj_split = c->lj_split.p;
-  P.lj16 = c->lj16.p;
+  P.lj_len = c->prune_valid ? c->lj_len_in.p : nullptr;
+  P.lj_split = c->prune_valid ? c->lj_split_in.p : c->lj_split.p;
+  P.lj16 = c->prune_valid ? c->lj16_in.p : c->lj16.p;
   P.rho = c->rho.p;
   P.f = c->f.p;
   P.eatom = c->eatom.p;
@@ -1586,6 +1590,18 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
   MDP_TRY(mdp_acc_begin(c, true));
+  if (c->aeam_tiled) {
+    // resident runs walk rows pruned to the pairs within reach right now (tile_prune_kernel in rebomos.hip): a third
+    // of the entries of a list built with 1 A of skin on a 6.5 A cutoff are skin
+    double cut[4];
+    for (int ti = 0; ti < 2; ti++)
+      for (int tj = 0; tj < 2; tj++) { // either visit of the pair may need the entry
+        const double a = c->aeam.cut[ti * 2 + tj], b = c->aeam.cut[tj * 2 + ti];
+        cut[ti * 2 + tj] = a > b ? a : b;
+      }
+    MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin));
+  } else
+    c->prune_valid = false;
   mdp_time_mark(c, 0);
   bool persistent = false;
   if (nlocal && c->aeam_tiled) MDP_TRY(aeam_ptile_launch(c, PT_DENSITY, 0, 0, &persistent));
@@ -1598,9 +1614,10 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
     if (lds > 48 * 1024)                                                                                              \
       MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_density_kernel<CLV>,                                    \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_density_kernel<CLV><<<c->ntile, 256, lds, st>>>(c->aeam, nlocal, c->nclus, c->xq.p, c->tile_cap, capL,    \
-                                                              c->tu.p, c->tile_nu.p, c->lj_off.p, c->lj_split.p,      \
-                                                              c->lj16.p, c->rho.p);                                   \
+    aeam_tile_density_kernel<CLV><<<c->ntile, 256, lds, st>>>(                                                        \
+        c->aeam, nlocal, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,                    \
+        c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
+        c->prune_valid ? c->lj16_in.p : c->lj16.p, c->rho.p);                                                         \
   } while (0)
     if (c->aeam_cl == 1) MDP_ATD(1);
     else MDP_ATD(2);
@@ -1659,7 +1676,8 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
     aeam_tile_force_kernel<CLV, EVV><<<c->ntile, 256, lds, st>>>(                                                     \
         c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,           \
-        c->lj_split.p, c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                                        \
+        c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
+        c->prune_valid ? c->lj16_in.p : c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                       \
   } while (0)
     if (c->aeam_cl == 1) {
       if (ev) MDP_ATF(1, true);

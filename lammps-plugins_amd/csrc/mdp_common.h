@@ -257,6 +257,9 @@ struct mdp_ctx {
   double prune_buf = 0.3;
   int prune_epoch = 0, prune_check_epoch = -1, prune_copied_epoch = -1, prunes = 0, dangerous_prunes = 0;
   int computes_since_prune = 0;
+  bool prune_check_pending = false; // (styles without a displacement check of their own: mdp_prune_upkeep)
+  hipEvent_t ev_prune = nullptr;
+  int tile_rows_cl = 2; // atoms per row of the current tile lists
   DevBuf<int> tile_nu;            // [ntile] members of each union
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
@@ -346,6 +349,9 @@ int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null); // x
 int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // d_out[n] = total (n+1 entries)
 int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n);
 int mdp_rebomos_repack(mdp_ctx *c);
+int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4]);                 // (re-)prune the tile rows from the current positions
+void mdp_prune_adapt(mdp_ctx *c, double buf_max, bool fired);
+int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], double skin);      // trigger + pruning for a style without its own displacement check
 int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok); // tile lists (cl atoms per cluster) for a two-type style; needs the bin grid
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag);

@@ -2729,6 +2729,10 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   c->nclus = nclus;
   c->ntile = ntile;
   c->lj_total = total;
+  c->tile_rows_cl = cl;
+  c->prune_valid = false; // (new rows)
+  c->prune_stale = false;
+  c->prune_epoch++;
   if (getenv("MDP_DEBUG"))
     fprintf(stderr, "[mdp] tile lists (generic): %d tiles, cap %d, largest union %d, %.1f row entries per cluster\n", ntile,
             c->tile_cap, c->tile_maxu, (double) total / nclus);
@@ -2817,8 +2821,9 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
   }
 }
 
-// (Re-)prune the Lennard-Jones rows from the current positions (tile_prune_kernel) and remember those positions.
-static int rebomos_prune(mdp_ctx *c)
+// (Re-)prune the tile rows from the current positions (tile_prune_kernel) and remember those positions.
+// lim_rsq[ti * 2 + tj]: (largest pair distance the kernels act on + buffer)^2.
+int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
 {
   hipStream_t st = c->stream;
   const int nrow = c->ntile * MDP_TILE;
@@ -2832,10 +2837,7 @@ static int rebomos_prune(mdp_ctx *c)
     c->prune_copied_epoch = c->prune_epoch;
   }
   PruneLimits lim;
-  for (int k = 0; k < 4; k++) {
-    const double r = sqrt(c->rebomos.lj_rsq_hi[k]) + c->prune_buf;
-    lim.rsq[k] = r * r;
-  }
+  for (int k = 0; k < 4; k++) lim.rsq[k] = lim_rsq[k];
   const size_t lds = (size_t) (c->tile_maxu + 1) * 3 * sizeof(double);
   if (lds > 48 * 1024)
     MDP_HIP(c, hipFuncSetAttribute((const void *) tile_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -2849,6 +2851,85 @@ static int rebomos_prune(mdp_ctx *c)
   c->prune_epoch++; // (a displacement check launched before this says nothing about the new reference)
   c->prune_copied_epoch = c->prune_epoch;
   c->prunes++;
+  c->computes_since_prune = 0;
+  return MDP_OK;
+}
+
+// the buffer adapts like the inner skin: a pruning costs about a third of a pass over the rows, so a trigger that
+// fires within a dozen computes (thermal vibration reaching half the buffer) widens it, one that stays quiet for
+// long narrows it.  fired: the trigger of the current pruning has fired (MDP_PRUNE_BUFFER fixes the buffer).
+void mdp_prune_adapt(mdp_ctx *c, const double buf_max, const bool fired)
+{
+  const char *eb = getenv("MDP_PRUNE_BUFFER");
+  const double fixed_buf = eb ? atof(eb) : 0.0;
+  if (fixed_buf > 0.0) {
+    c->prune_buf = fixed_buf;
+    return;
+  }
+  if (!fired) return;
+  if (c->computes_since_prune < 12 && c->prune_buf + 0.1 <= buf_max + 1e-9) c->prune_buf += 0.1;
+  else if (c->computes_since_prune > 60 && c->prune_buf - 0.05 >= 0.2 - 1e-9) c->prune_buf -= 0.05;
+}
+
+// A style without a displacement check of its own (aeam) keeps the pruned rows current with this: reads the
+// deferred flag of the previous compute's check, prunes (again) when needed, launches this compute's check.
+// Call before the first kernel that walks the rows; positions (ghosts included) must be current.
+__global__ __launch_bounds__(256) void moved_prune_kernel(const int nall, const double4 *__restrict__ xq,
+                                                          const double *__restrict__ xprune, const double ptrigsq,
+                                                          const double phardsq, int *__restrict__ flag)
+{
+  bool pfar = false, ptoofar = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nall; i += gridDim.x * 256) {
+    const double4 x = xq[i];
+    const double px = x.x - xprune[3 * (size_t) i], py = x.y - xprune[3 * (size_t) i + 1], pz = x.z - xprune[3 * (size_t) i + 2];
+    const double p2 = px * px + py * py + pz * pz;
+    pfar = pfar || p2 > ptrigsq;
+    ptoofar = ptoofar || p2 > phardsq;
+  }
+  if (__any(pfar) && (threadIdx.x & 63) == 0) flag[2] = 1; // (pinned host memory, zeroed by the host before the launch)
+  if (__any(ptoofar) && (threadIdx.x & 63) == 0) flag[3] = 1;
+}
+
+int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin)
+{
+  const char *ep = getenv("MDP_PRUNE");
+  const int prune_on = ep ? atoi(ep) : 1;
+  if (!prune_on || !c->md || c->ntile <= 0 || c->tile_rows_cl != 2) {
+    c->prune_valid = false;
+    return MDP_OK;
+  }
+  int *h = (int *) (c->h_pinned + 24);
+  if (c->prune_check_pending) {
+    MDP_HIP(c, hipEventSynchronize(c->ev_prune)); // recorded a whole compute ago
+    if (c->prune_check_epoch == c->prune_epoch) {
+      if (h[2]) c->prune_stale = true;
+      if (h[3]) c->dangerous_prunes++;
+    }
+    c->prune_check_pending = false;
+  }
+  mdp_prune_adapt(c, skin - 0.2, c->prune_valid && c->prune_stale);
+  if (!(c->prune_buf < skin)) {
+    c->prune_valid = false;
+    return MDP_OK;
+  }
+  if (!c->prune_valid || c->prune_stale) {
+    double lim[4];
+    for (int k = 0; k < 4; k++) lim[k] = (cut[k] + c->prune_buf) * (cut[k] + c->prune_buf);
+    MDP_TRY(mdp_tile_prune(c, lim));
+  }
+  c->computes_since_prune++;
+  if (!c->ev_prune) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_prune, hipEventDisableTiming));
+  double ptrig = 0.5 * c->prune_buf - kPruneMargin;
+  if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
+  const double phard = 0.5 * c->prune_buf;
+  h[2] = h[3] = 0;
+  const int nall = c->nall;
+  const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
+  moved_prune_kernel<<<grid, 256, 0, c->stream>>>(nall, c->xq.p, c->xhold_prune.p, ptrig * ptrig, phard * phard, h);
+  MDP_HIP(c, hipGetLastError());
+  MDP_HIP(c, hipEventRecord(c->ev_prune, c->stream));
+  c->prune_check_epoch = c->prune_epoch;
+  c->prune_check_pending = true;
   return MDP_OK;
 }
 
@@ -3017,21 +3098,18 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
   } else {
     // resident runs walk pruned rows (see tile_prune_kernel); host mode re-uploads positions every step and is
     // bound by that, a per-atom-virial step reads the rows as built
-    static const int prune_on = [] { const char *e = getenv("MDP_PRUNE"); return e ? atoi(e) : 1; }();
+    const char *ep = getenv("MDP_PRUNE");
+    const int prune_on = ep ? atoi(ep) : 1;
     if (prune_on && c->md && c->lj_tiled && c->ntile > 0) {
-      static const double fixed_buf = [] { const char *e = getenv("MDP_PRUNE_BUFFER"); return e ? atof(e) : 0.0; }();
-      if (fixed_buf > 0.0) c->prune_buf = fixed_buf;
-      else if (c->prune_valid && c->prune_stale) {
-        // the buffer adapts like the inner skin: a pruning costs about a third of a Lennard-Jones pass, so a trigger
-        // that fires within a dozen computes (thermal vibration reaching half the buffer) widens it, one that stays
-        // quiet for long narrows it
-        if (c->computes_since_prune < 12 && c->prune_buf + 0.1 <= c->skin_inner - 0.2 + 1e-9) c->prune_buf += 0.1;
-        else if (c->computes_since_prune > 60 && c->prune_buf - 0.05 >= 0.2 - 1e-9) c->prune_buf -= 0.05;
-      }
+      mdp_prune_adapt(c, c->skin_inner - 0.2, c->prune_valid && c->prune_stale);
       if (c->prune_buf < c->skin_inner) { // (a buffer as wide as the skin prunes nothing)
         if (!c->prune_valid || c->prune_stale) {
-          MDP_TRY(rebomos_prune(c));
-          c->computes_since_prune = 0;
+          double lim[4];
+          for (int k = 0; k < 4; k++) {
+            const double r = sqrt(c->rebomos.lj_rsq_hi[k]) + c->prune_buf;
+            lim[k] = r * r;
+          }
+          MDP_TRY(mdp_tile_prune(c, lim));
         }
         c->computes_since_prune++;
       } else

@@ -289,3 +289,49 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
     dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
     assert np.abs(dx).max() < 1e-9
     assert np.abs(nf - pf).max() < 1e-7
+
+
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch):
+    """Dynamic pruning of the tile rows (tile_prune_kernel): a hot run with a narrow buffer prunes every few steps;
+    positions and velocities after 60 steps must agree with the run that walks the rows as built to rounding (the
+    dropped entries contribute exactly zero; the kept ones land on other lanes, so partial sums differ in the last
+    bit), and no pruning may come late."""
+    if style == "rebomos":
+        s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 1))
+        temp, skin, map_ = 600.0, 2.0, MAP
+    else:
+        s = S.fcc_cell(4.045, 7, frac_type2=0.02, seed=3)
+        temp, skin, map_ = 863.0, 1.0, None
+    out = {}
+    for tag, env in (("pruned", {"MDP_PRUNE": "1", "MDP_PRUNE_BUFFER": "0.25"}), ("as built", {"MDP_PRUNE": "0"})):
+        for k in ("MDP_PRUNE", "MDP_PRUNE_BUFFER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if style == "rebomos":
+            ctx, cutghost = _rebo_ctx()
+            st = capi.STYLE_REBOMOS
+        else:
+            af = capi.AeamFile(POT_AEAM)
+            tabs = af.build()
+            ctx = capi.Context(0)
+            ctx.aeam_set_tables(tabs)
+            s.mass[1:3] = af.mass
+            cutghost = float(af.cut_table(tabs).max()) + 1.0
+            st = capi.STYLE_AEAM
+        v0 = S.gaussian_velocities(s, temp, seed=77)
+        d = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0)
+        d.compute(0, 0)
+        for step in range(60):
+            d.step(0, 0, rebuild="auto")
+        got = ctx.md_download(d.nlocal, want=("x", "v"))
+        order = np.argsort(d.tags_local)
+        stats = ctx.md_prune_stats()
+        out[tag] = (got["x"][order], got["v"][order], stats, d.builds)
+        ctx.close()
+    xp, vp, sp, bp = out["pruned"]
+    xb, vb, sb, bb = out["as built"]
+    assert sp["prunings"] >= 4 and sp["late"] == 0 and sb["prunings"] == 0
+    assert bp == bb
+    assert np.abs(xp - xb).max() < 1e-9 and np.abs(vp - vb).max() < 1e-7
