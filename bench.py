@@ -295,7 +295,7 @@ def main():
     # ---- per-kernel time of the hot path: HIP events on the compute stream, force-only steps (separate pass) ----
     ctx.set_timing(True)
     kms = np.zeros(8)
-    nmeas = 5
+    nmeas = 20  # (long enough for a row pruning to weigh what it weighs in the run)
     for _ in range(nmeas):
         dom.step(0, 0)
         kms += np.array(ctx.get_timing())

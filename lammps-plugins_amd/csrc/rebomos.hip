@@ -2011,7 +2011,7 @@ struct PruneLimits {
   double rsq[4]; // (window upper bound + buffer)^2 per pair type ti * 2 + tj
 };
 __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, const int nlocal, const int nclus,
-                                                         const double4 *__restrict__ xq, const int cap,
+                                                         const double4 *__restrict__ xq, const int cap, const int capL,
                                                          const int *__restrict__ tu, const int *__restrict__ tile_nu,
                                                          const long long *__restrict__ lj_off,
                                                          const int *__restrict__ lj_split,
@@ -2019,24 +2019,50 @@ __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, 
                                                          unsigned short *__restrict__ lj16_in,
                                                          int *__restrict__ len_in, int *__restrict__ split_in)
 {
-  constexpr int CL = 2, L = 16;
-  extern __shared__ double s_pos[]; // [nU][3]
+  // The tile's rows (contiguous in memory) are staged in LDS with 16-byte loads, compacted there in place -- a
+  // row's kept entries never outrun its read position, and a row belongs to one 16-lane group of one wave -- and
+  // written back whole with 16-byte stores: no 2-byte global traffic, no global load inside the loop.  What lies
+  // behind a row's new length stays what it was (valid indices: the kernels read a few entries past a segment).
+  constexpr int CL = 2, L = 16, SK = 3;
+  extern __shared__ double s_pos[]; // [capL][3], then the rows
+  unsigned short *__restrict__ s_rows = reinterpret_cast<unsigned short *>(s_pos + 3 * (size_t) capL);
   const int tid = threadIdx.x, lane = tid & 63, s = lane % L, glane0 = lane - s;
   const int t = blockIdx.x;
   const int kc = t * MDP_TILE + tid / L;
   const int nU = tile_nu[2 * t];
   const int *__restrict__ mem = tu + (size_t) t * cap;
-  for (int u = tid; u < nU; u += 256) {
-    const double4 v = xq[mem[u]];
-    s_pos[3 * u] = v.x;
-    s_pos[3 * u + 1] = v.y;
-    s_pos[3 * u + 2] = v.z;
+  const long long rb = lj_off[(size_t) t * MDP_TILE];
+  const int rtot = (int) (lj_off[(size_t) t * MDP_TILE + MDP_TILE] - rb); // entries of the whole tile (multiple of 16)
+  {
+    int sidx[SK];
+#pragma unroll
+    for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // (rows are cap >= 2048 long: always in bounds)
+    double4 sv[SK];
+#pragma unroll
+    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(lj16 + rb);
+    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(s_rows);
+    for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
+#pragma unroll
+    for (int k = 0; k < SK; k++) {
+      const int u = tid + 256 * k;
+      if (u < nU) {
+        s_pos[3 * u] = sv[k].x;
+        s_pos[3 * u + 1] = sv[k].y;
+        s_pos[3 * u + 2] = sv[k].z;
+      }
+    }
+    for (int u = tid + 256 * SK; u < nU; u += 256) {
+      const double4 v = xq[mem[u]];
+      s_pos[3 * u] = v.x;
+      s_pos[3 * u + 1] = v.y;
+      s_pos[3 * u + 2] = v.z;
+    }
   }
   const long long b = lj_off[kc];
   const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
   const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
-  const unsigned short *__restrict__ row = lj16 + b;
-  unsigned short *__restrict__ out = lj16_in + b;
+  unsigned short *__restrict__ row = s_rows + (int) (b - rb);
   double4 xa[CL];
   bool real[CL];
   int ta[CL];
@@ -2074,19 +2100,26 @@ __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, 
         }
       }
       const unsigned long long gb = (__ballot(keep) >> glane0) & 0xFFFFull;
-      if (keep) out[base + n + __popcll(gb & below)] = (unsigned short) li;
+      // (the read of this trip is complete for the whole wave before any lane writes: same instruction stream)
+      if (keep) row[base + n + __popcll(gb & below)] = (unsigned short) li;
       n += __popcll(gb);
     }
     int p = (n + 15) & ~15;
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) p = max(p, __shfl_xor(p, o, 64));
-    for (int q = n + s; q < p; q += L) out[base + q] = (unsigned short) nU; // padding: the dummy slot
+    for (int q = n + s; q < p; q += L) row[base + q] = (unsigned short) nU; // padding: the dummy slot
     pseg[seg] = p;
     base += p;
   }
   if (s == 0) {
     split_in[kc] = pseg[0];
     len_in[kc] = pseg[0] + pseg[1];
+  }
+  __syncthreads();
+  {
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(s_rows);
+    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(lj16_in + rb);
+    for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
   }
 }
 
@@ -2500,12 +2533,13 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                                    c->cell_start.p, cap, c->tu.p, c->tmask.p, c->tile_nu.p,
                                                    c->lj_cnt.p, c->lj_split.p, c->tile_flag.p);
       MDP_HIP(c, hipGetLastError());
-      int tf[2] = {0, 0};
-      MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+      int tf[3] = {0, 0, 0};
+      MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
       MDP_HIP(c, hipStreamSynchronize(st));
       if (!tf[0]) {
         c->tile_cap = cap;
         c->tile_maxu = tf[1];
+        c->tile_rowmax = tf[2];
         break;
       }
       cap *= 2; // a union outgrew the segment: retry larger, give up beyond what LDS can stage
@@ -2747,7 +2781,9 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
 //                   for the GPU inside the MD loop; the trigger is lowered by kStaleMargin to cover the one
 //                   step of extra motion, and a true violation is counted as a "dangerous build"
 constexpr double kStaleMargin = 0.1; // Angstrom
-constexpr double kPruneMargin = 0.05; // the same for the pruned rows' trigger (their buffer is a fraction of the skin)
+constexpr double kPruneMargin = 0.07; // the same for the pruned rows' trigger (their buffer is a fraction of the skin):
+                                      // two steps of motion -- the flag is read one compute later, and in a multi-GPU
+                                      // run the check sees remote ghosts where the previous step left them
 
 static int rebomos_check_launch(mdp_ctx *c, const double trig)
 {
@@ -2830,18 +2866,23 @@ int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
   MDP_HIP(c, c->lj_len_in.reserve(nrow + 1));
   MDP_HIP(c, c->lj_split_in.reserve(nrow + 1));
   MDP_HIP(c, c->xhold_prune.reserve((size_t) 3 * c->nall + 3));
-  if (c->prune_copied_epoch != c->prune_epoch) { // rows were rebuilt: start from a full copy (reads past a pruned
-    MDP_HIP(c, c->lj16_in.reserve((size_t) c->lj_total + 256)); // segment's end must find valid indices)
-    MDP_HIP(c, hipMemcpyAsync(c->lj16_in.p, c->lj16.p, sizeof(unsigned short) * ((size_t) c->lj_total + 256),
+  if (c->prune_copied_epoch != c->prune_epoch) { // rows were rebuilt: the slack behind the last row as well
+    MDP_HIP(c, c->lj16_in.reserve((size_t) c->lj_total + 256)); // (reads past a segment's end must find valid indices)
+    MDP_HIP(c, hipMemcpyAsync(c->lj16_in.p + c->lj_total, c->lj16.p + c->lj_total, sizeof(unsigned short) * 256,
                               hipMemcpyDeviceToDevice, st));
     c->prune_copied_epoch = c->prune_epoch;
   }
   PruneLimits lim;
   for (int k = 0; k < 4; k++) lim.rsq[k] = lim_rsq[k];
-  const size_t lds = (size_t) (c->tile_maxu + 1) * 3 * sizeof(double);
+  const int capL = (c->tile_maxu + 1 + 1) & ~1; // (the rows behind it start 16-byte aligned)
+  const size_t lds = (size_t) capL * 3 * sizeof(double) + (size_t) 2 * c->tile_rowmax + 32;
+  if (c->tile_rowmax <= 0 || lds > 160 * 1024) { // (rows of a tile do not fit LDS next to its union: no pruning)
+    c->prune_valid = false;
+    return MDP_OK;
+  }
   if (lds > 48 * 1024)
     MDP_HIP(c, hipFuncSetAttribute((const void *) tile_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-  tile_prune_kernel<<<c->ntile, 256, lds, st>>>(lim, c->nlocal, c->nclus, c->xq.p, c->tile_cap, c->tu.p, c->tile_nu.p,
+  tile_prune_kernel<<<c->ntile, 256, lds, st>>>(lim, c->nlocal, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p,
                                                 c->lj_off.p, c->lj_split.p, c->lj16.p, c->lj16_in.p, c->lj_len_in.p,
                                                 c->lj_split_in.p);
   if (c->nall) hold_all_kernel<<<(c->nall + 255) / 256, 256, 0, st>>>(c->nall, c->xq.p, c->xhold_prune.p);
