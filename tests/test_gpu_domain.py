@@ -304,7 +304,8 @@ def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch
         s = S.fcc_cell(4.045, 7, frac_type2=0.02, seed=3)
         temp, skin, map_ = 863.0, 1.0, None
     out = {}
-    for tag, env in (("pruned", {"MDP_PRUNE": "1", "MDP_PRUNE_BUFFER": "0.25"}), ("as built", {"MDP_PRUNE": "0"})):
+    for tag, env in (("pruned", {"MDP_PRUNE": "1", "MDP_PRUNE_BUFFER": "0.25"}), ("adaptive", {"MDP_PRUNE": "1"}),
+                     ("as built", {"MDP_PRUNE": "0"})):
         for k in ("MDP_PRUNE", "MDP_PRUNE_BUFFER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -335,3 +336,6 @@ def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch
     assert sp["prunings"] >= 4 and sp["late"] == 0 and sb["prunings"] == 0
     assert bp == bb
     assert np.abs(xp - xb).max() < 1e-9 and np.abs(vp - vb).max() < 1e-7
+    xa_, va_, sa, ba = out["adaptive"]          # the buffer widens by itself when the trigger fires within a dozen computes
+    assert sa["late"] == 0 and sa["buffer"] > 0.3 + 1e-9 and sa["prunings"] < sp["prunings"] and ba == bb
+    assert np.abs(xa_ - xb).max() < 1e-9 and np.abs(va_ - vb).max() < 1e-7
