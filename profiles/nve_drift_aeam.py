@@ -14,8 +14,9 @@ s.mass[1:3] = af.mass
 v0 = S.gaussian_velocities(s, 863.0, seed=4928459)
 cutghost = float(af.cut_table(tabs).max()) + 1.0
 res = {}
-for tag, env in (("persistent density kernel", "1"), ("gather kernels", "0")):
+for tag, env, prune in (("persistent density kernel", "1", "1"), ("gather kernels", "0", "1"), ("persistent density kernel, rows as built", "1", "0")):
     os.environ["MDP_AEAM_PERSIST"] = env
+    os.environ["MDP_PRUNE"] = prune
     ctx = capi.Context(0)
     ctx.aeam_set_tables(tabs)
     d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0)
@@ -26,7 +27,7 @@ for tag, env in (("persistent density kernel", "1"), ("gather kernels", "0")):
         d.step(1 if step % 500 == 0 else 0, 0, rebuild="auto")
         if step % 500 == 0:
             t = d.thermo(); out.append(round((t["pe"] + t["ke"] - e0) / s.n, 9))
-    res[tag] = dict(atoms=s.n, builds=d.builds, e0_per_atom=round(e0 / s.n, 9), drift_eV_per_atom=out,
+    res[tag] = dict(atoms=s.n, builds=d.builds, prune=ctx.md_prune_stats(), e0_per_atom=round(e0 / s.n, 9), drift_eV_per_atom=out,
                     temp_end=round(S.temperature(t["ke"], s.n), 2))
     ctx.close()
 print(json.dumps(res))
