@@ -320,7 +320,9 @@ int mdp_md_moved_async(mdp_ctx *ctx, int *moved, int *dangerous);
 int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):
- * rebomos: [0]=REBO centre kernels, [1]=LJ+gather kernel; aeam: [0]=density, [1]=embed, [2]=force.
+ * rebomos: [0]=REBO centre kernels, [1]=row pruning (0 unless one was due), [2]=LJ+gather kernel;
+ * aeam: [0]=density of the metal centres (tile kernel), [1]=density of the angular centres, [2]=embedding,
+ * [3]=force tile kernel (incl. force_clear), [4]=angular three-body forces.
  * Enabled by mdp_set_timing(ctx,1). */
 int mdp_set_timing(mdp_ctx *ctx, int on);
 int mdp_get_timing(mdp_ctx *ctx, double ms[8]);

@@ -1435,8 +1435,7 @@ int mdp_aeam_prepare(mdp_ctx *c)
   if (c->nlocal)
     ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p);
   MDP_HIP(c, hipGetLastError());
-  MDP_HIP(c, hipMemcpyAsync(&c->h_ang_count, c->ang_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof(int), &c->h_ang_count));
   // resident mode, two atom types: tile lists next to the CSR list (which the angular kernels and the steps
   // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
   c->aeam_tiled = false;
@@ -1631,16 +1630,17 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
       default: aeam_density_kernel<AE_L, 4><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
     }
   }
+  mdp_time_mark(c, 1);
   if (c->h_ang_count)
     aeam_density_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
                                                                      c->nb_off.p, c->nb.p, c->rho.p, c->flags.p);
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 1);
+  mdp_time_mark(c, 2);
   if (nlocal)
     aeam_embed_kernel<<<nblk(nlocal, 256), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->rho.p, c->fp.p, c->eatom.p,
                                                          c->acc.p, eflag, /*accumulate=*/0);
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 2);
+  mdp_time_mark(c, 3);
   return MDP_OK;
 }
 
@@ -1705,12 +1705,13 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
     }
 #undef MDP_AF
   }
+  mdp_time_mark(c, 4);
   if (c->h_ang_count)
     aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
                                                                    c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->vatom.p,
                                                                    c->acc.p, c->flags.p, vflag);
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 3);
+  mdp_time_mark(c, 5);
   return mdp_acc_end(c, eflag || vflag); // force-only steps tally nothing: no slots to fold
 }
 

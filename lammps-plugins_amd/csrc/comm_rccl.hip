@@ -14,6 +14,8 @@
 #include "mdp_common.h"
 
 #include <dlfcn.h>
+
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace {
@@ -35,31 +37,31 @@ struct RcclApi {
 RcclApi *rccl()
 {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.ok ? &api : nullptr;
-  tried = true;
-  void *h = nullptr;
-  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (h) break;
-  }
-  if (!h) return nullptr;
+  static std::once_flag once; // several contexts may come up on several host threads at the same time
+  std::call_once(once, [] {
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return;
 #define MDP_SYM(field, sym)                                        \
   api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym)); \
-  if (!api.field) return nullptr
-  MDP_SYM(GetUniqueId, "ncclGetUniqueId");
-  MDP_SYM(CommInitRank, "ncclCommInitRank");
-  MDP_SYM(CommDestroy, "ncclCommDestroy");
-  MDP_SYM(GetErrorString, "ncclGetErrorString");
-  MDP_SYM(GroupStart, "ncclGroupStart");
-  MDP_SYM(GroupEnd, "ncclGroupEnd");
-  MDP_SYM(Send, "ncclSend");
-  MDP_SYM(Recv, "ncclRecv");
-  MDP_SYM(AllGather, "ncclAllGather");
-  MDP_SYM(AllReduce, "ncclAllReduce");
+  if (!api.field) return
+    MDP_SYM(GetUniqueId, "ncclGetUniqueId");
+    MDP_SYM(CommInitRank, "ncclCommInitRank");
+    MDP_SYM(CommDestroy, "ncclCommDestroy");
+    MDP_SYM(GetErrorString, "ncclGetErrorString");
+    MDP_SYM(GroupStart, "ncclGroupStart");
+    MDP_SYM(GroupEnd, "ncclGroupEnd");
+    MDP_SYM(Send, "ncclSend");
+    MDP_SYM(Recv, "ncclRecv");
+    MDP_SYM(AllGather, "ncclAllGather");
+    MDP_SYM(AllReduce, "ncclAllReduce");
 #undef MDP_SYM
-  api.ok = true;
-  return &api;
+    api.ok = true;
+  });
+  return api.ok ? &api : nullptr;
 }
 
 #define MDP_NCCL(c, call)                                                                                      \
@@ -85,11 +87,10 @@ int exchange_counts(mdp_ctx *c, const std::vector<int> &send, std::vector<int> &
   const int n = D.G.nranks;
   hipStream_t st = c->stream;
   MDP_HIP(c, D.cnt_dev.reserve((size_t) n * (n + 1) + 8));
-  MDP_HIP(c, hipMemcpyAsync(D.cnt_dev.p, send.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+  MDP_TRY(mdp_write_small(c, D.cnt_dev.p, send.data(), sizeof(int) * n));
   MDP_NCCL(c, rccl()->AllGather(D.cnt_dev.p, D.cnt_dev.p + n, (size_t) n, ncclInt, (ncclComm_t) D.nccl_comm, st));
   std::vector<int> all((size_t) n * n);
-  MDP_HIP(c, hipMemcpyAsync(all.data(), D.cnt_dev.p + n, sizeof(int) * n * n, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_TRY(mdp_read_one(c, D.cnt_dev.p + n, sizeof(int) * n * n, all.data()));
   recv.assign(n, 0);
   for (int q = 0; q < n; q++) recv[q] = all[(size_t) q * n + D.G.rank];
   return MDP_OK;
@@ -106,13 +107,19 @@ int exchange(mdp_ctx *c, const double *sbuf, const int *scnt, double *rbuf, cons
   for (int q = 0; q < n; q++) any = any || scnt[q] || rcnt[q];
   if (!any) return MDP_OK;
   MDP_NCCL(c, R->GroupStart());
-  for (int q = 0; q < n; q++) {
-    if (scnt[q]) MDP_NCCL(c, R->Send(sbuf + so, (size_t) scnt[q] * width, ncclDouble, q, (ncclComm_t) D.nccl_comm, st));
-    if (rcnt[q]) MDP_NCCL(c, R->Recv(rbuf + ro, (size_t) rcnt[q] * width, ncclDouble, q, (ncclComm_t) D.nccl_comm, st));
+  // a failing Send/Recv must not leave the thread inside an open group (every later RCCL call of the thread, torch's
+  // included, would queue into it): remember the first error, always close the group, report afterwards
+  ncclResult_t first = ncclSuccess;
+  for (int q = 0; q < n && first == ncclSuccess; q++) {
+    if (scnt[q]) first = R->Send(sbuf + so, (size_t) scnt[q] * width, ncclDouble, q, (ncclComm_t) D.nccl_comm, st);
+    if (rcnt[q] && first == ncclSuccess)
+      first = R->Recv(rbuf + ro, (size_t) rcnt[q] * width, ncclDouble, q, (ncclComm_t) D.nccl_comm, st);
     so += (size_t) scnt[q] * width;
     ro += (size_t) rcnt[q] * width;
   }
-  MDP_NCCL(c, R->GroupEnd());
+  const ncclResult_t end = R->GroupEnd();
+  if (first != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclSend/ncclRecv -> %s", R->GetErrorString(first));
+  if (end != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclGroupEnd -> %s", R->GetErrorString(end));
   return MDP_OK;
 }
 
@@ -169,6 +176,7 @@ int mdp_dd_comm_destroy(mdp_ctx *c)
   D.sbuf.release();
   D.rbuf.release();
   D.cnt_dev.release();
+  D.abuf.release();
   return MDP_OK;
 }
 
@@ -206,7 +214,9 @@ int mdp_dd_comm_reneighbor(mdp_ctx *c)
   MDP_TRY(mdp_dd_borders_pack(c, D.sbuf.p));
   MDP_TRY(exchange(c, D.sbuf.p, sc.data(), D.rbuf.p, rc.data(), 6, st));
   MDP_TRY(mdp_dd_borders_end(c, rc.data(), D.rbuf.p));
-  // per-step buffers (3 doubles per entry either way) -- the border buffers are at least that large
+  // the per-step exchanges (3 doubles per entry either way) reuse the border buffers (6 per entry): nothing is
+  // (re-)allocated -- a hipFree would wait for the whole device -- between two reneighborings
+  D.fwd_pending = false;
   return mdp_md_build_neighbors_impl(c);
 }
 
@@ -225,6 +235,7 @@ int mdp_dd_comm_forward_begin(mdp_ctx *c)
   MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
   MDP_TRY(exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream));
   MDP_HIP(c, hipEventRecord(D.ev_arrived, D.comm_stream));
+  D.fwd_pending = true;
   return MDP_OK;
 }
 
@@ -234,6 +245,7 @@ int mdp_dd_comm_forward_end(mdp_ctx *c)
   MdpDomain &D = c->dd;
   if (!D.nsend && !D.nrecv) return MDP_OK;
   MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_arrived, 0));
+  D.fwd_pending = false;
   return mdp_dd_forward_unpack(c, D.rbuf.p);
 }
 
@@ -271,13 +283,13 @@ int mdp_dd_comm_allreduce(mdp_ctx *c, double *vals, int n, int op)
   if (!vals || n < 1 || n > 64) return MDP_EINVAL;
   MdpDomain &D = c->dd;
   hipStream_t st = c->stream;
-  MDP_HIP(c, D.sbuf.reserve(128));
-  MDP_HIP(c, hipMemcpyAsync(D.sbuf.p, vals, sizeof(double) * n, hipMemcpyHostToDevice, st));
-  MDP_NCCL(c, rccl()->AllReduce(D.sbuf.p, D.sbuf.p + 64, (size_t) n, ncclDouble, op ? ncclMax : ncclSum,
+  // own buffer: sbuf may hold the position exchange that is in flight on the communication stream
+  if (D.fwd_pending) return mdp_fail(c, MDP_ESTATE, "mdp_dd_comm_allreduce between mdp_dd_comm_forward_begin and _end");
+  MDP_HIP(c, D.abuf.reserve(128));
+  MDP_TRY(mdp_write_small(c, D.abuf.p, vals, sizeof(double) * n));
+  MDP_NCCL(c, rccl()->AllReduce(D.abuf.p, D.abuf.p + 64, (size_t) n, ncclDouble, op ? ncclMax : ncclSum,
                                 (ncclComm_t) D.nccl_comm, st));
-  MDP_HIP(c, hipMemcpyAsync(vals, D.sbuf.p + 64, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
-  return MDP_OK;
+  return mdp_read_one(c, D.abuf.p + 64, sizeof(double) * n, vals);
 }
 
 } // extern "C"

@@ -493,8 +493,7 @@ int mdp_dd_migrate_begin(mdp_ctx *c, int *send_counts)
   MDP_HIP(c, hipMemsetAsync(D.counters.p, 0, sizeof(int) * (4 * G.nranks + 16), st));
   if (n) dd_remap_kernel<<<nblk(n), 256, 0, st>>>(G, n, c->xq.p, D.dest.p, D.counters.p);
   MDP_HIP(c, hipGetLastError());
-  MDP_HIP(c, hipMemcpyAsync(D.mig_send.data(), D.counters.p, sizeof(int) * G.nranks, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_TRY(mdp_read_one(c, D.counters.p, sizeof(int) * G.nranks, D.mig_send.data()));
   D.mig_send[G.rank] = 0;
   D.mig_total = 0;
   for (int q = 0; q < G.nranks; q++) D.mig_total += D.mig_send[q];
@@ -515,7 +514,7 @@ int mdp_dd_migrate_pack(mdp_ctx *c, double *d_buf)
   std::vector<int> off(2 * (size_t) G.nranks, 0);
   for (int q = 1; q < G.nranks; q++) off[q] = off[q - 1] + D.mig_send[q - 1];
   int *seg = D.counters.p + G.nranks, *cur = D.counters.p + 2 * G.nranks;
-  MDP_HIP(c, hipMemcpyAsync(seg, off.data(), sizeof(int) * 2 * G.nranks, hipMemcpyHostToDevice, st)); // cursors = 0
+  MDP_TRY(mdp_write_small(c, seg, off.data(), sizeof(int) * 2 * G.nranks)); // cursors = 0
   dd_pack_leavers_kernel<<<nblk(D.nlocal_old), 256, 0, st>>>(D.nlocal_old, G.rank, D.dest.p, seg, cur, c->xq.p, c->v.p,
                                                              c->type.p, c->tag.p, d_buf);
   MDP_HIP(c, hipGetLastError());
@@ -595,8 +594,7 @@ int mdp_dd_borders_begin(mdp_ctx *c, int *send_counts)
     dd_border_kernel<false><<<nblk(n), 256, 0, st>>>(G, n, c->xq.p, D.ent_cnt.p, nullptr, nullptr, nullptr, nullptr);
     MDP_HIP(c, hipGetLastError());
     MDP_TRY(mdp_scan_exclusive_int(c, D.ent_cnt.p, D.ent_off.p, n));
-    MDP_HIP(c, hipMemcpyAsync(&nent, D.ent_off.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    MDP_HIP(c, hipStreamSynchronize(st));
+    MDP_TRY(mdp_read_one(c, D.ent_off.p + n, sizeof(int), &nent));
   }
   D.nent = nent;
   const int ncls = G.nranks + 1;
@@ -621,8 +619,7 @@ int mdp_dd_borders_begin(mdp_ctx *c, int *send_counts)
     MDP_HIP(c, hipMemsetAsync(d_start, 0xFF, sizeof(int) * ncls, st));
     dd_class_start_kernel<<<nblk(nent), 256, 0, st>>>(nent, D.key_b.p, d_start);
     MDP_HIP(c, hipGetLastError());
-    MDP_HIP(c, hipMemcpyAsync(start.data(), d_start, sizeof(int) * ncls, hipMemcpyDeviceToHost, st));
-    MDP_HIP(c, hipStreamSynchronize(st));
+    MDP_TRY(mdp_read_one(c, d_start, sizeof(int) * ncls, start.data()));
   }
   std::vector<int> cnt(ncls, 0);
   int next = nent;

@@ -486,8 +486,7 @@ int mdp_md_build_master_list(mdp_ctx *c)
     MDP_HIP(c, hipMemsetAsync(c->ang_count.p, 0, sizeof(int), st));
     MDP_HIP(c, hipMemsetAsync(c->nb_cnt.p, 0, sizeof(int) * (nall + 1), st));
     if (nlocal) ang_select_kernel<<<nblk(nlocal), 256, 0, st>>>(nlocal, ct.min_type, c->xq.p, c->ang_list.p, c->ang_count.p);
-    MDP_HIP(c, hipMemcpyAsync(&nsel, c->ang_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    MDP_HIP(c, hipStreamSynchronize(st));
+    MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof(int), &nsel));
     if (nsel)
       nbuild_list_kernel<false><<<(nsel + 3) / 4, 256, 0, st>>>(g, ct, nsel, c->ang_list.p, c->xq.p, c->cell_perm.p,
                                                                 c->cell_start.p, c->nb_cnt.p, nullptr, nullptr);
@@ -497,9 +496,10 @@ int mdp_md_build_master_list(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_i64(c, c->nb_cnt.p, c->nb_off.p, nall));
   long long tot[2] = {0, 0};
-  MDP_HIP(c, hipMemcpyAsync(&tot[0], c->nb_off.p + nall, sizeof(long long), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipMemcpyAsync(&tot[1], c->nb_off.p + nlocal, sizeof(long long), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  {
+    const MdpRead rd[2] = {{c->nb_off.p + nall, sizeof(long long), &tot[0]}, {c->nb_off.p + nlocal, sizeof(long long), &tot[1]}};
+    MDP_TRY(mdp_read_small(c, rd, 2));
+  }
   c->nb_total = tot[0];
   c->nb_owned_total = tot[1];
   MDP_HIP(c, c->nb.reserve((size_t) tot[0] + 1));
@@ -768,6 +768,14 @@ int mdp_md_upload_x(mdp_ctx *c, const double *x)
                                                           c->xq.p);
   MDP_HIP(c, hipGetLastError());
   MDP_HIP(c, hipStreamSynchronize(st));
+  // Positions were rewritten outside the integrator: rows pruned for the old positions (buffer 0.2-0.6 A) may miss
+  // pairs now, and the deferred displacement checks in flight looked at the old positions.  The next compute
+  // prunes afresh and checks the style's own lists BEFORE it walks them (blocking, once).
+  c->prune_valid = false;
+  c->prune_stale = false;
+  c->prune_epoch++;
+  c->prune_check_pending = false;
+  c->check_now = true;
   return MDP_OK;
 }
 
@@ -783,8 +791,7 @@ static int host_list_compare(mdp_ctx *c, const CutTables &ct, double maxcut, uns
                                                         c->cell_start.p, d_total);
   MDP_HIP(c, hipGetLastError());
   unsigned long long dev_total = 0;
-  MDP_HIP(c, hipMemcpyAsync(&dev_total, d_total, sizeof dev_total, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_TRY(mdp_read_one(c, d_total, sizeof dev_total, &dev_total));
   if (dev_total != host_total)
     return mdp_fail(c, MDP_EINVAL,
                     "host neighbor list is not the plain geometric list (%llu entries, %llu pairs within the list cutoff "

@@ -21,6 +21,54 @@ int mdp_fail(mdp_ctx *c, int code, const char *fmt, ...)
   return code;
 }
 
+static int small_reserve(mdp_ctx *c, size_t bytes)
+{
+  if (bytes <= c->h_small_cap) return MDP_OK;
+  if (c->h_small) (void) hipHostFree(c->h_small);
+  c->h_small = nullptr;
+  c->h_small_cap = 0;
+  const size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 2;
+  MDP_HIP(c, hipHostMalloc((void **) &c->h_small, cap, hipHostMallocDefault));
+  c->h_small_cap = cap;
+  return MDP_OK;
+}
+
+int mdp_read_small(mdp_ctx *c, const MdpRead *r, int n)
+{
+  size_t total = 0;
+  for (int k = 0; k < n; k++) total += (r[k].bytes + 15) & ~(size_t) 15;
+  MDP_TRY(small_reserve(c, total));
+  size_t at = 0;
+  for (int k = 0; k < n; k++) {
+    if (r[k].bytes) MDP_HIP(c, hipMemcpyAsync(c->h_small + at, r[k].d_src, r[k].bytes, hipMemcpyDeviceToHost, c->stream));
+    at += (r[k].bytes + 15) & ~(size_t) 15;
+  }
+  MDP_HIP(c, hipStreamSynchronize(c->stream));
+  at = 0;
+  for (int k = 0; k < n; k++) {
+    if (r[k].bytes) memcpy(r[k].h_dst, c->h_small + at, r[k].bytes);
+    at += (r[k].bytes + 15) & ~(size_t) 15;
+  }
+  return MDP_OK;
+}
+
+int mdp_read_one(mdp_ctx *c, const void *d_src, size_t bytes, void *h_dst)
+{
+  const MdpRead r = {d_src, bytes, h_dst};
+  return mdp_read_small(c, &r, 1);
+}
+
+int mdp_write_small(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+{
+  if (!bytes) return MDP_OK;
+  MDP_HIP(c, hipStreamSynchronize(c->stream)); // (a read or write staged earlier has left the scratch buffer)
+  MDP_TRY(small_reserve(c, bytes));
+  memcpy(c->h_small, h_src, bytes);
+  MDP_HIP(c, hipMemcpyAsync(d_dst, c->h_small, bytes, hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipStreamSynchronize(c->stream));
+  return MDP_OK;
+}
+
 void mdp_time_mark(mdp_ctx *c, int k)
 {
   if (!c->timing) return;
@@ -516,6 +564,8 @@ int mdp_destroy(mdp_ctx *c)
   c->nb_cnt.release();
   if (c->ev_stale_made) (void) hipEventDestroy(c->ev_stale);
   if (c->h_pinned) (void) hipHostFree(c->h_pinned);
+  if (c->h_small) (void) hipHostFree(c->h_small);
+  c->h_small = nullptr;
   if (c->ev_made)
     for (int i = 0; i < 8; i++) (void) hipEventDestroy(c->ev[i]);
   if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +26,9 @@
 #define MDP_NCLASS_HALF 10
 
 // bytes of device memory currently held by the library's buffers in this process (memory_usage(), pair_rebomos.cpp:1113-1124)
-inline long long &mdp_device_bytes_counter()
+inline std::atomic<long long> &mdp_device_bytes_counter()
 {
-  static long long bytes = 0;
+  static std::atomic<long long> bytes{0}; // several contexts (threads) allocate concurrently
   return bytes;
 }
 
@@ -165,7 +166,8 @@ struct MdpDomain {
   void *nccl_comm = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
-  DevBuf<double> sbuf, rbuf;
+  DevBuf<double> sbuf, rbuf, abuf; // abuf: the all-reduce's own words
+  bool fwd_pending = false;        // a position exchange is in flight between _forward_begin and _forward_end
   DevBuf<int> cnt_dev;
 };
 
@@ -210,6 +212,8 @@ struct mdp_ctx {
   DevBuf<double> acc;   // [16] eng, virial[6], flags...
   DevBuf<int> flags;    // [4] overflow etc.
   double *h_pinned = nullptr; // pinned staging for small results (32 doubles)
+  char *h_small = nullptr;    // pinned scratch of mdp_read_small / mdp_write_small (counts, totals, flag words)
+  size_t h_small_cap = 0;
 
   // ---- master neighbor list (CSR over nall atoms)
   bool neigh_set = false;
@@ -282,6 +286,7 @@ struct mdp_ctx {
   long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
   hipEvent_t ev_stale = nullptr;
   bool ev_stale_made = false, stale_pending = false;
+  bool check_now = false;         // positions were rewritten by the host (mdp_md_upload_x): check the lists before use
   DevBuf<double> fnbr;            // [cand_total][4] force on the slot's neighbour + its share of the pair energy
   DevBuf<double> fown;            // [nall][4] the centre's own share: -(sum of its slot forces), energy
   DevBuf<double> vslot;           // [cand_total][6] per-atom virial shares (allocated on first use)
@@ -330,6 +335,19 @@ struct mdp_ctx {
 };
 
 int mdp_fail(mdp_ctx *c, int code, const char *fmt, ...);
+
+// Small device <-> host transfers (counts, totals, flag words) go through a pinned scratch buffer of the CONTEXT and
+// are complete on return: no asynchronous copy ever targets a stack variable or a std::vector (pageable memory goes
+// through the runtime's shared staging path, and a host that drives several contexts from several threads must not
+// depend on how that path behaves under concurrency).
+struct MdpRead {
+  const void *d_src;
+  size_t bytes;
+  void *h_dst;
+};
+int mdp_read_small(mdp_ctx *c, const MdpRead *r, int n);                       // waits for the stream
+int mdp_read_one(mdp_ctx *c, const void *d_src, size_t bytes, void *h_dst);    // waits for the stream
+int mdp_write_small(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes); // waits for the stream
 
 #define MDP_HIP(c, call)                                                                             \
   do {                                                                                               \

@@ -2437,6 +2437,56 @@ void mdp_rebomos_fill_dev(mdp_ctx *c, double skin)
 //   * Lennard-Jones cluster pair lists (r <= rcLJmax + s_in)
 // s_in ("inner skin") <= the host's skin: the lists stay valid until some atom has moved s_in/2, which
 // the device checks itself every compute (moved_kernel); the host's list only defines the ghost shell.
+// MDP_DIAG=1: what the list builder saw when a candidate row outgrew the 64-bit active mask (small systems only:
+// everything is copied to the host).  Answers "which input was wrong" for a spurious overflow.
+static void repack_diag(mdp_ctx *c)
+{
+  const int nall = c->nall, nlocal = c->nlocal;
+  if (nall <= 0 || nall > (1 << 22)) return;
+  std::vector<double> x(4 * (size_t) nall);
+  std::vector<int> off(nall + 2), cs;
+  (void) hipMemcpy(x.data(), c->xq.p, sizeof(double) * 4 * nall, hipMemcpyDeviceToHost);
+  (void) hipMemcpy(off.data(), c->cand_off.p, sizeof(int) * (nall + 1), hipMemcpyDeviceToHost);
+  const long long ncell = (long long) c->grid.n[0] * c->grid.n[1] * c->grid.n[2];
+  cs.resize((size_t) ncell + 2);
+  (void) hipMemcpy(cs.data(), c->cell_start.p, sizeof(int) * (ncell + 1), hipMemcpyDeviceToHost);
+  int worst = 0, wi = -1, nbad = 0, nzero = 0, nout = 0, nonmono = 0;
+  for (int i = 0; i < nall; i++) {
+    const int n = off[i + 1] - off[i];
+    if (n > worst) worst = n, wi = i;
+    const double *p = &x[4 * (size_t) i];
+    if (!(p[0] == p[0]) || !(p[1] == p[1]) || !(p[2] == p[2])) nbad++;
+    if (p[0] == 0.0 && p[1] == 0.0 && p[2] == 0.0) nzero++;
+    for (int d = 0; d < 3; d++)
+      if (p[d] < c->bbox_lo[d] || p[d] > c->bbox_hi[d]) {
+        nout++;
+        break;
+      }
+  }
+  for (long long k = 0; k < ncell; k++)
+    if (cs[k + 1] < cs[k]) nonmono++;
+  fprintf(stderr,
+          "[mdp diag] ctx %p rank %d: nlocal %d nall %d (self %d, remote from %d) grid %dx%dx%d cells; longest row %d at atom %d "
+          "(%s) x=(%.3f %.3f %.3f) elem %.0f; NaN positions %d, all-zero positions %d, outside the bin box %d; "
+          "cell_start[ncell]=%d non-monotonic cells %d; cand_total %d\n",
+          (void *) c, c->dd.on ? c->dd.G.rank : -1, nlocal, nall, c->remote_start - nlocal, c->remote_start, c->grid.n[0],
+          c->grid.n[1], c->grid.n[2], worst, wi, wi < nlocal ? "owned" : (wi < c->remote_start ? "self image" : "remote ghost"),
+          wi >= 0 ? x[4 * (size_t) wi] : 0.0, wi >= 0 ? x[4 * (size_t) wi + 1] : 0.0, wi >= 0 ? x[4 * (size_t) wi + 2] : 0.0,
+          wi >= 0 ? x[4 * (size_t) wi + 3] : 0.0, nbad, nzero, nout, cs[(size_t) ncell], nonmono, off[nall]);
+  if (wi >= 0) { // how many atoms really sit within 5 A of the worst one, and how many of them are coincident
+    int near = 0, same = 0;
+    for (int j = 0; j < nall; j++) {
+      if (j == wi) continue;
+      const double dx = x[4 * (size_t) j] - x[4 * (size_t) wi], dy = x[4 * (size_t) j + 1] - x[4 * (size_t) wi + 1],
+                   dz = x[4 * (size_t) j + 2] - x[4 * (size_t) wi + 2];
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      near += r2 < 25.0;
+      same += r2 < 1e-6;
+    }
+    fprintf(stderr, "[mdp diag]   atoms within 5 A of it: %d, coincident with it: %d\n", near, same);
+  }
+}
+
 int mdp_rebomos_repack(mdp_ctx *c)
 {
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
@@ -2534,8 +2584,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                                    c->lj_cnt.p, c->lj_split.p, c->tile_flag.p);
       MDP_HIP(c, hipGetLastError());
       int tf[3] = {0, 0, 0};
-      MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-      MDP_HIP(c, hipStreamSynchronize(st));
+      MDP_TRY(mdp_read_one(c, c->tile_flag.p, sizeof(int) * 3, tf));
       if (!tf[0]) {
         c->tile_cap = cap;
         c->tile_maxu = tf[1];
@@ -2577,9 +2626,10 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nrow));
   int cand_total = 0;
   long long lj_total = 0;
-  MDP_HIP(c, hipMemcpyAsync(&cand_total, c->cand_off.p + nall, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipMemcpyAsync(&lj_total, c->lj_off.p + nrow, sizeof(long long), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  {
+    const MdpRead rd[2] = {{c->cand_off.p + nall, sizeof(int), &cand_total}, {c->lj_off.p + nrow, sizeof(long long), &lj_total}};
+    MDP_TRY(mdp_read_small(c, rd, 2));
+  }
   c->cand_total = cand_total;
   c->lj_total = lj_total;
   if (tiled && getenv("MDP_DEBUG"))
@@ -2642,12 +2692,13 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                                            tiled ? c->tile_nu.p : nullptr, kSmallUnion, flag4);
     MDP_HIP(c, hipGetLastError());
     int total[4] = {0, 0, 0, 0};
+    MdpRead rd[4];
     for (int q = 0; q < 4; q++) {
       int *pos = c->cl_pos.p + (size_t) q * (nunit + 2);
       MDP_TRY(mdp_scan_exclusive_int(c, flag4 + (size_t) q * (nunit + 1), pos, nunit));
-      MDP_HIP(c, hipMemcpyAsync(&total[q], pos + nunit, sizeof(int), hipMemcpyDeviceToHost, st));
+      rd[q] = {pos + nunit, sizeof(int), &total[q]};
     }
-    MDP_HIP(c, hipStreamSynchronize(st));
+    MDP_TRY(mdp_read_small(c, rd, 4));
     for (int q = 0; q < 4; q++) c->lj_class_base[q + 1] = c->lj_class_base[q] + total[q];
     unit_order_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, flag4, c->cl_pos.p, c->lj_class_base[1],
                                                            c->lj_class_base[2], c->lj_class_base[3], c->cl_order.p);
@@ -2666,11 +2717,14 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
-  MDP_HIP(c, hipMemcpyAsync(c->h_class_count, c->class_count.p, sizeof(int) * MDP_NCLASS, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipMemcpyAsync(hflags, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
-  if (hflags[1])
+  {
+    const MdpRead rd[2] = {{c->class_count.p, sizeof(int) * MDP_NCLASS, c->h_class_count}, {c->flags.p, sizeof(int) * 4, hflags}};
+    MDP_TRY(mdp_read_small(c, rd, 2));
+  }
+  if (hflags[1]) {
+    if (getenv("MDP_DIAG")) repack_diag(c);
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
+  }
   { // packed candidate heads of the lane-group classes (widths = UA*G of rebo_centre_kernel<G>), per element
     const int width[5] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<12>::UA * 12, CentreCfg<16>::UA * 16,
                           CentreCfg<32>::UA * 32};
@@ -2740,8 +2794,7 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
     }
     MDP_HIP(c, hipGetLastError());
     int tf[3] = {0, 0, 0};
-    MDP_HIP(c, hipMemcpyAsync(tf, c->tile_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-    MDP_HIP(c, hipStreamSynchronize(st));
+    MDP_TRY(mdp_read_one(c, c->tile_flag.p, sizeof(int) * 3, tf));
     if (!tf[0]) {
       c->tile_cap = cap;
       c->tile_maxu = tf[1];
@@ -2753,8 +2806,7 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   }
   MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nrow));
   long long total = 0;
-  MDP_HIP(c, hipMemcpyAsync(&total, c->lj_off.p + nrow, sizeof(long long), hipMemcpyDeviceToHost, st));
-  MDP_HIP(c, hipStreamSynchronize(st));
+  MDP_TRY(mdp_read_one(c, c->lj_off.p + nrow, sizeof(long long), &total));
   MDP_HIP(c, c->lj16.reserve((size_t) total + 256));
   MDP_TRY(tile_sort_launch(c, ntile));
   tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
@@ -2810,10 +2862,14 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
   stale = false;
   if (!c->nall) return MDP_OK;
   int *h = (int *) (c->h_pinned + 24);
-  if (!c->md) { // immediate
+  if (!c->md || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
+    if (c->stale_pending) MDP_HIP(c, hipEventSynchronize(c->ev_stale)); // (a deferred check still writes the flag words)
+    c->stale_pending = false;
+    c->check_now = false;
     MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
     MDP_HIP(c, hipStreamSynchronize(c->stream));
     stale = h[0] != 0;
+    if (c->prune_valid && h[2]) c->prune_stale = true;
     return MDP_OK;
   }
   // deferred by one compute
@@ -3122,6 +3178,7 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
     MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
   mdp_time_mark(c, 1);
   if (c->split_halo || va) {
+    mdp_time_mark(c, 2);
     c->prune_valid = false; // (these paths walk the rows as built)
     for (int k = c->split_halo ? 2 : 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
     if (c->nlocal) {
@@ -3157,10 +3214,11 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
         c->prune_valid = false;
     } else
       c->prune_valid = false;
+    mdp_time_mark(c, 2); // (a row pruning, when one was due, lies between marks 1 and 2)
     for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, /*gather=*/true, eflag, vflag, false));
   }
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 2);
+  mdp_time_mark(c, 3);
   return mdp_acc_end(c, eflag || vflag);
 }
 

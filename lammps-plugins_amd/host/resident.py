@@ -689,7 +689,10 @@ def run_ranks(world: int, fn, device=0):
 
     import os
     old = capi.Context.serialize
-    capi.Context.serialize = os.environ.get("MDP_THREAD_SERIALIZE", "1") != "0"
+    # every rank thread calls the library concurrently (own context, own stream): what a C++ host that drives
+    # several GPUs from threads of one process does.  MDP_THREAD_SERIALIZE=1 puts one process-wide lock around the
+    # library (debugging aid).
+    capi.Context.serialize = os.environ.get("MDP_THREAD_SERIALIZE", "0") != "0"
     try:
         th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
         for t in th:

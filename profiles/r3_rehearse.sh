@@ -1,0 +1,20 @@
+#!/bin/bash
+# multi-rank rehearsal on ONE GPU through the PLAIN command line `python3 bench.py --gpus N` (bench.py starts its own
+# rank processes); MDP_BENCH_BACKEND=gloo: the ranks share the card and the halo is staged through the host.
+# usage: profiles/r3_rehearse.sh <tag> ; output under gpurun_out/<tag>/
+set -u
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-rehearse}; mkdir -p $O
+run() { tag=$1; n=$2; shift 2
+  MDP_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus $n "$@" --no-host-mode > $O/$tag.json 2> $O/$tag.err
+  echo "$tag rc=$?"; grep '^{' $O/$tag.json | python3 -c "
+import json,sys
+for l in sys.stdin:
+    d=json.loads(l); c=d['config']; print('  ', d['value'], d['ms_per_step'], 'n_gpus', d['n_gpus'], 'ranks', c.get('rccl_ranks'), c['parallelism'], c.get('pe_per_atom_end_eV'), c.get('temp_end_K'), 'reneigh', c.get('reneighborings_in_timed_region'), 'nlocal', c.get('nlocal_per_rank'), 'cpu', d.get('cpu_baseline',{}).get('value'), 'frac', d['roofline']['frac'])"
+}
+run rebo1 1 --replicate 10 10 10 --temp 300 --steps 40 --warmup 5 --no-secondary
+run rebo2 2 --replicate 10 10 10 --temp 300 --steps 40 --warmup 5
+run rebo4 4 --replicate 10 10 10 --temp 300 --steps 40 --warmup 5 --no-cpu-baseline
+run aeam1 1 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 5 --no-cpu-baseline
+run aeam4 4 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 5 --no-cpu-baseline
+# what must NOT produce a result: more RCCL ranks than GPUs
+timeout -k 10 200 python3 bench.py --gpus 2 --replicate 4 4 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/refuse.json 2> $O/refuse.err; echo "refuse rc=$? (non-zero expected), stdout bytes: $(wc -c < $O/refuse.json)"

@@ -339,3 +339,38 @@ def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch
     xa_, va_, sa, ba = out["adaptive"]          # the buffer widens by itself when the trigger fires within a dozen computes
     assert sa["late"] == 0 and sa["buffer"] > 0.3 + 1e-9 and sa["prunings"] < sp["prunings"] and ba == bb
     assert np.abs(xa_ - xb).max() < 1e-9 and np.abs(va_ - vb).max() < 1e-7
+
+
+def test_upload_x_invalidates_the_pruned_rows(monkeypatch):
+    """mdp_md_upload_x rewrites the positions outside the integrator (here: every atom moved by up to 0.5 A, more
+    than half of any pruning buffer).  The compute that follows must prune afresh and check the style's own lists
+    before it walks them: forces and energy equal those of the run that walks the rows as built."""
+    s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 1))
+    v0 = S.gaussian_velocities(s, 300.0, seed=5)
+    jit = np.random.default_rng(12).uniform(-0.29, 0.29, size=(s.n, 3))
+    out = {}
+    for tag, env in (("pruned", {"MDP_PRUNE": "1", "MDP_PRUNE_BUFFER": "0.25"}), ("as built", {"MDP_PRUNE": "0"})):
+        for k in ("MDP_PRUNE", "MDP_PRUNE_BUFFER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx, cutghost = _rebo_ctx()
+        d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP, v0=v0)
+        d.compute(0, 0)
+        for _ in range(6):
+            d.step(0, 0, rebuild="auto")
+        if tag == "pruned":
+            assert ctx.md_prune_stats()["active"]
+        tags = d.tags_local
+        x = ctx.md_download(d.nlocal, want=("x",))["x"]
+        ctx.md_upload_x(x + jit[tags - 1])
+        d.compute(3, 1)
+        got = ctx.md_download(d.nlocal, want=("f",))
+        order = np.argsort(tags)
+        out[tag] = (got["f"][order], d.thermo()["pe"], ctx.md_prune_stats())
+        ctx.close()
+    fp, ep, sp = out["pruned"]
+    fb, eb, _ = out["as built"]
+    assert sp["late"] == 0
+    assert np.abs(fp - fb).max() < 1e-9
+    assert ep == pytest.approx(eb, rel=1e-12)
