@@ -560,6 +560,10 @@ int mdp_dd_migrate_end(mdp_ctx *c, int narrive, const double *d_buf)
     dd_order_key_kernel<<<nblk(ntot), 256, 0, st>>>(G, ntot, c->xq.p, c->tag.p, D.dest.p, D.key_a.p, D.idx_a.p);
     MDP_HIP(c, hipGetLastError());
     MDP_TRY(sort_u64(c, D.key_a.p, D.key_b.p, D.idx_a.p, D.idx_b.p, (size_t) ntot, 64));
+    if (c->cfg.style == 1) { // rebomos: element-sorted runs of 32 atoms for the one-atom-row tile lists
+      MDP_TRY(mdp_chunk_by_element(c, ntot, nnew, D.idx_b.p, D.idx_a.p, c->xq.p, nullptr, nullptr));
+      swap_buf(D.idx_a, D.idx_b);
+    }
   }
   if (nnew) {
     dd_permute_kernel<<<nblk(nnew), 256, 0, st>>>(nnew, D.idx_b.p, c->xq.p, c->v.p, c->type.p, c->tag.p, c->mass_type.p,

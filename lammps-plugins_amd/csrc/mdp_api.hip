@@ -405,6 +405,61 @@ static int host_sort_atoms(mdp_ctx *c)
   MDP_HIP(c, c->scan_tmp.reserve(tmp + 16));
   MDP_HIP(c, rocprim::radix_sort_pairs(c->scan_tmp.p, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p,
                                        c->host_perm.p, (size_t) nall, 0, 31, st));
+  if (c->have_rebomos && !c->have_aeam) { // element-sorted runs of 32 owned atoms (one-atom-row tile lists)
+    MDP_TRY(mdp_chunk_by_element(c, nall, c->nlocal, c->host_perm.p, c->cell_of.p, nullptr, c->type.p, c->type.p + nall));
+    int *p = c->host_perm.p;
+    c->host_perm.p = c->cell_of.p;
+    c->cell_of.p = p;
+    const size_t cp = c->host_perm.cap;
+    c->host_perm.cap = c->cell_of.cap;
+    c->cell_of.cap = cp;
+  }
+  return MDP_OK;
+}
+
+// Second ordering pass of the owned atoms: inside every run of 32 consecutive positions (one tile of the one-atom-row
+// lists, csrc/rebomos.hip) the atoms of element 0 come first.  The eight rows that share a wave must have equally long
+// segments, so a wave of one element pads less.  idx_in[pos] = source index of the atom at position pos after the
+// spatial sort; positions >= n_owned (atoms that leave / ghosts) keep their order behind the owned atoms.  Stable.
+namespace {
+__global__ void chunk_key_kernel(const int n, const int n_owned, const int *__restrict__ idx_in,
+                                 const double4 *__restrict__ xq, const int *__restrict__ type,
+                                 const int *__restrict__ map, unsigned *__restrict__ key)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  if (p >= n_owned) {
+    key[p] = (((unsigned) n_owned >> 5) + 1u) << 1;
+    return;
+  }
+  const int o = idx_in[p];
+  int e;
+  if (xq)
+    e = (int) xq[o].w;
+  else {
+    const int t = type[o];
+    e = map ? map[t] : t - 1;
+  }
+  key[p] = (((unsigned) p >> 5) << 1) | (e != 0 ? 1u : 0u);
+}
+} // namespace
+
+int mdp_chunk_by_element(mdp_ctx *c, int n, int n_owned, const int *d_idx_in, int *d_idx_out, const double4 *d_xq,
+                         const int *d_type, const int *d_map)
+{
+  if (n <= 0) return MDP_OK;
+  MDP_HIP(c, c->sort_keys_a.reserve((size_t) n + 1));
+  MDP_HIP(c, c->sort_keys_b.reserve((size_t) n + 1));
+  chunk_key_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, n_owned, d_idx_in, d_xq, d_type, d_map, c->sort_keys_a.p);
+  MDP_HIP(c, hipGetLastError());
+  int bits = 2;
+  while ((1ull << bits) <= ((((unsigned long long) n_owned >> 5) + 2ull) << 1)) bits++;
+  size_t tmp = 0;
+  MDP_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp, c->sort_keys_a.p, c->sort_keys_b.p, d_idx_in, d_idx_out, (size_t) n, 0,
+                                       bits, c->stream));
+  MDP_HIP(c, c->scan_tmp.reserve(tmp + 16));
+  MDP_HIP(c, rocprim::radix_sort_pairs(c->scan_tmp.p, tmp, c->sort_keys_a.p, c->sort_keys_b.p, d_idx_in, d_idx_out,
+                                       (size_t) n, 0, bits, c->stream));
   return MDP_OK;
 }
 
@@ -509,6 +564,7 @@ int mdp_destroy(mdp_ctx *c)
   c->lj.release();
   c->tu.release();
   c->tmask.release();
+  c->tmask32.release();
   c->lj16_in.release();
   c->lj_len_in.release();
   c->lj_split_in.release();

@@ -251,6 +251,8 @@ struct mdp_ctx {
   int tile_small = 0;             // largest union of the "small" launch classes
   DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
   DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
+  DevBuf<unsigned> tmask32;       // the same for tiles of 32 one-atom rows (bit a: atom a of the tile)
+  int tile_rows = 16;             // rows per tile of the current lists: 16 (one or two atoms each) or 32 (one atom each)
   // dynamic pruning of the tile rows (resident mode): between two list builds the rows are re-filtered, from the
   // current positions, to the entries within window + prune_buf of a cluster atom; the kernels walk the pruned rows
   // until an atom has moved prune_buf/2 since (second trigger of moved_kernel), then they are pruned again
@@ -365,6 +367,8 @@ int mdp_write_small(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes); /
 // modules
 int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null); // xraw/type -> xq
 int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // d_out[n] = total (n+1 entries)
+int mdp_chunk_by_element(mdp_ctx *c, int n, int n_owned, const int *d_idx_in, int *d_idx_out, const double4 *d_xq,
+                         const int *d_type, const int *d_map); // element-sorted runs of 32 owned atoms (stable)
 int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n);
 int mdp_rebomos_repack(mdp_ctx *c);
 int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4]);                 // (re-)prune the tile rows from the current positions

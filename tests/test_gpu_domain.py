@@ -291,12 +291,16 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
     assert np.abs(nf - pf).max() < 1e-7
 
 
-@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+@pytest.mark.parametrize("style", ["rebomos", "aeam", "rebomos-rows32"])
 def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch):
     """Dynamic pruning of the tile rows (tile_prune_kernel): a hot run with a narrow buffer prunes every few steps;
     positions and velocities after 60 steps must agree with the run that walks the rows as built to rounding (the
     dropped entries contribute exactly zero; the kept ones land on other lanes, so partial sums differ in the last
     bit), and no pruning may come late."""
+    monkeypatch.delenv("MDP_LJ_ROWS", raising=False)
+    if style == "rebomos-rows32":          # tiles of 32 one-atom rows: their own builder, pruning and compute kernels
+        monkeypatch.setenv("MDP_LJ_ROWS", "32")
+        style = "rebomos"
     if style == "rebomos":
         s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 1))
         temp, skin, map_ = 600.0, 2.0, MAP
