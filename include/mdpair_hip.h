@@ -316,7 +316,8 @@ int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 
  * the current positions is launched.  Trigger: an owned atom moved more than skin/2 - 0.1 A since the last build
  * (the margin covers the step the answer is late by); *dangerous = an atom was beyond skin/2 itself. */
 int mdp_md_moved_async(mdp_ctx *ctx, int *moved, int *dangerous);
-/* owned atoms' "tag" / "type" in device order (the device re-orders atoms at every reneighboring) */
+/* owned atoms' "tag" / "type" in device order (the device re-orders atoms at every reneighboring); "tile_nu"
+ * (diagnostics): {members of the neighbour union, Mo / first-type members} of every 32-atom tile, 2 ints per tile */
 int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):

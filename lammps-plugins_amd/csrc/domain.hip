@@ -839,6 +839,12 @@ int mdp_md_download_int(mdp_ctx *c, const char *name, int *out)
   if (!c || !name || !out) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   const int *src = !strcmp(name, "tag") ? c->tag.p : (!strcmp(name, "type") ? c->type.p : nullptr);
+  if (!strcmp(name, "tile_nu")) { // diagnostics: {members of the union, Mo members} of every tile, 2 * ntile <= nlocal ints
+    if (2 * c->ntile > c->nlocal) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: tile_nu needs 2 * %d ints", c->ntile);
+    if (c->ntile) MDP_HIP(c, hipMemcpyAsync(out, c->tile_nu.p, sizeof(int) * 2 * c->ntile, hipMemcpyDeviceToHost, c->stream));
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    return MDP_OK;
+  }
   if (!src) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: unknown array '%s'", name);
   if (c->nlocal) MDP_HIP(c, hipMemcpyAsync(out, src, sizeof(int) * c->nlocal, hipMemcpyDeviceToHost, c->stream));
   MDP_HIP(c, hipStreamSynchronize(c->stream));

@@ -378,3 +378,21 @@ def test_upload_x_invalidates_the_pruned_rows(monkeypatch):
     assert sp["late"] == 0
     assert np.abs(fp - fb).max() < 1e-9
     assert ep == pytest.approx(eb, rel=1e-12)
+
+
+def test_eight_bricks_hot_run_meets_the_oracle_at_the_seams(oracle):
+    """12x12x12 replica (497 664 atoms) on 2x2x2 bricks at 300 K with a drift, 30 steps, a reneighboring (migration,
+    re-derived ghosts, new lists) every 10: forces of ~500-atom blocks at the box corners, on the brick faces and
+    corners and at random places equal the oracle's -- the decomposed, migrated, pruned state meets the oracle
+    directly, not only the one-brick run."""
+    import blockcheck
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s = S.replicate(S.rebomos_bulk_cell(), (12, 12, 12))
+    v0 = S.gaussian_velocities(s, 300.0, seed=23) + np.array([50.0, -35.0, 20.0])
+    r = _run(8, s, v0, 30, 10)
+    assert r["left"] > 200 and r["builds"] == 4
+    pts = blockcheck.seeds(s.box, r["x"], n_random=1)
+    worst, rows = blockcheck.check_blocks(s.box, r["x"], r["f"], s.type, s.tag, s.mass, pts,
+                                          lambda cs: mdref.RebomosCPU(oracle, P, cs), n_interior=400, shell=11.0,
+                                          margin=16.0, tol=1e-9)
+    assert len(rows) >= 7

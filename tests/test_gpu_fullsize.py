@@ -11,6 +11,8 @@ import pytest
 
 from conftest import GOLDEN, POT_AEAM, POT_REBOMOS
 from lammps_plugins_amd.host import capi, resident, system as S
+import blockcheck
+import mdref
 
 pytestmark = pytest.mark.gpu
 
@@ -108,7 +110,7 @@ def test_aeam_pe_per_atom_does_not_depend_on_system_size():
 
 
 @pytest.mark.timeout(1200)
-def test_aeam_16m_atoms_on_one_gpu():
+def test_aeam_16m_atoms_on_one_gpu(oracle):
     """config #5 on ONE GPU: 159^3 x 4 = 16 078 716 atoms, 0.75 % Si, 863 K.  Known answers: the
     list holds ~85.35 entries per atom, the net force vanishes, PE/atom is that of the 1 M-atom system up to the
     different random Si placement, and NVE conserves energy across on-device reneighborings."""
@@ -128,4 +130,58 @@ def test_aeam_16m_atoms_on_one_gpu():
     d.compute(eflag=1, vflag=0)
     t1 = d.thermo()
     assert abs(t1["pe"] + t1["ke"] - e0) / s.n < 1.5e-4
+    # ... and the forces of this hot, reneighbored, pruned 16 M-atom state meet the oracle block by block
+    T = oracle.aeam_pot(POT_AEAM)
+    assert ctx.md_prune_stats()["prunings"] >= 2
+    got = ctx.md_download(d.nlocal, want=("x", "f"))
+    tags, types = d.tags_local, ctx.md_download_int("type", d.nlocal)
+    nu = ctx.md_download_int("tile_nu", d.nlocal)
+    first = int(np.argmax(nu[0:2 * ((d.nlocal + 31) // 32):2])) * 32
+    si = np.nonzero(types == 2)[0]
+    pts = blockcheck.seeds(s.box, got["x"], extra_points=[got["x"][first], got["x"][si[len(si) // 2]]])
+    worst, rows = blockcheck.check_blocks(s.box, got["x"], got["f"], types, tags, s.mass, pts,
+                                          lambda cs: mdref.AeamCPU(oracle, T, cs), n_interior=500, shell=13.5,
+                                          margin=10.0, tol=1e-9)
+    assert len(rows) >= 8
+    ctx.close()
+
+
+def _tile_atoms(ctx, nlocal, which="largest union"):
+    """device index of the first atom of the tile with the largest neighbour union"""
+    nu = ctx.md_download_int("tile_nu", nlocal)
+    info = ctx.rebomos_list_info()
+    nt = info["tiles"]
+    t = int(np.argmax(nu[0:2 * nt:2]))
+    return t * 32, int(nu[2 * t])                # (a tile is 32 consecutive atoms in either row layout)
+
+
+@pytest.mark.timeout(1200)
+def test_rebomos_4m_atoms_hot_run_meets_the_oracle_block_by_block(oracle, monkeypatch):
+    """3 981 312 atoms from 300 K, 70 steps (inner skin 0.6 A, so that the style rebuilds its lists on its own
+    trigger within the run): at least one style-list build and several row prunings have happened
+    when the positions are taken.  Forces of ~500-atom blocks at the box corners, the brick seams, in the tile
+    with the largest union, in the last tile and at random places equal the oracle's to 1e-9 eV/A."""
+    monkeypatch.setenv("MDP_INNER_SKIN", "0.6")
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s = S.replicate(S.rebomos_bulk_cell(), (24, 24, 24))
+    ctx = capi.Context(0)
+    p = capi.read_rebomos_file(POT_REBOMOS)
+    ctx.rebomos_set_params(p)
+    v0 = S.gaussian_velocities(s, 300.0, seed=1082337)
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1], v0=v0)
+    d.compute(0, 0)
+    builds0 = ctx.md_neighbor_stats()[7]
+    for _ in range(70):
+        d.step(0, 0, rebuild="auto")
+    st = ctx.md_prune_stats()
+    assert ctx.md_neighbor_stats()[7] > builds0 and st["prunings"] >= 3 and st["active"] and st["late"] == 0
+    got = ctx.md_download(d.nlocal, want=("x", "f"))
+    tags, types = d.tags_local, ctx.md_download_int("type", d.nlocal)
+    first, nu = _tile_atoms(ctx, d.nlocal)
+    assert nu > 800                                              # a large union indeed
+    pts = blockcheck.seeds(s.box, got["x"], extra_points=[got["x"][first]])
+    worst, rows = blockcheck.check_blocks(s.box, got["x"], got["f"], types, tags, s.mass, pts,
+                                          lambda cs: mdref.RebomosCPU(oracle, P, cs), n_interior=500, shell=11.0,
+                                          margin=16.0, tol=1e-9)
+    assert len(rows) >= 8
     ctx.close()
