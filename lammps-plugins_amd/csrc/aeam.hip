@@ -1627,7 +1627,8 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
       case 1: aeam_density_kernel<AE_L, 1><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
       case 2: aeam_density_kernel<AE_L, 2><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
       case 3: aeam_density_kernel<AE_L, 3><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
-      default: aeam_density_kernel<AE_L, 4><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      case 4: aeam_density_kernel<AE_L, 4><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      default: aeam_density_kernel<AE_L, MDP_AEAM_MAXT><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
     }
   }
   mdp_time_mark(c, 1);
@@ -1701,7 +1702,8 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
       case 1: if (ev) MDP_AF(1, true); else MDP_AF(1, false); break;
       case 2: if (ev) MDP_AF(2, true); else MDP_AF(2, false); break;
       case 3: if (ev) MDP_AF(3, true); else MDP_AF(3, false); break;
-      default: if (ev) MDP_AF(4, true); else MDP_AF(4, false); break;
+      case 4: if (ev) MDP_AF(4, true); else MDP_AF(4, false); break;
+      default: if (ev) MDP_AF(MDP_AEAM_MAXT, true); else MDP_AF(MDP_AEAM_MAXT, false); break;
     }
 #undef MDP_AF
   }
@@ -1720,8 +1722,9 @@ extern "C" {
 int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
 {
   if (!c || !t) return MDP_EINVAL;
-  if (t->ntypes < 1 || t->ntypes > 4 || t->nelements < 1 || t->nelements > 4 || t->ntypes > t->nelements)
-    return mdp_fail(c, MDP_EINVAL, "aeam: 1..4 atom types/elements supported, ntypes <= nelements");
+  if (t->ntypes < 1 || t->ntypes > MDP_AEAM_MAXT || t->nelements < 1 || t->nelements > MDP_AEAM_MAXT ||
+      t->ntypes > t->nelements)
+    return mdp_fail(c, MDP_EINVAL, "aeam: 1..%d atom types/elements supported, ntypes <= nelements", MDP_AEAM_MAXT);
   MDP_HIP(c, hipSetDevice(c->device));
   AeamDev &A = c->aeam;
   memset(&A, 0, sizeof A);
@@ -1782,15 +1785,16 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     // per pair type: {rho' coefficients | phi' coefficients} in one 64-byte record (tile force kernel)
     const int npair = A.ntypes * A.ntypes, nm1 = A.nrmax + 1;
     MDP_HIP(c, c->aeam_pair_d8.reserve((size_t) npair * nm1 * 6 + 8));
-    MDP_HIP(c, c->aeam_maps.reserve(32));
-    int h_map[32];
-    for (int k = 0; k < 16; k++) {
+    constexpr int kPairs = MDP_AEAM_MAXT * MDP_AEAM_MAXT;
+    MDP_HIP(c, c->aeam_maps.reserve(2 * kPairs));
+    int h_map[2 * kPairs];
+    for (int k = 0; k < kPairs; k++) {
       h_map[k] = A.t2rhor[k];
-      h_map[16 + k] = A.t2z2r[k];
+      h_map[kPairs + k] = A.t2z2r[k];
     }
-    MDP_HIP(c, hipMemcpyAsync(c->aeam_maps.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, c->stream));
+    MDP_TRY(mdp_write_small(c, c->aeam_maps.p, h_map, sizeof(h_map)));
     pair_der_kernel<<<(int) (((size_t) npair * nm1 + 255) / 256), 256, 0, c->stream>>>(
-        npair, nm1, c->aeam_maps.p, c->aeam_maps.p + 16, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
+        npair, nm1, c->aeam_maps.p, c->aeam_maps.p + kPairs, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipStreamSynchronize(c->stream));
     A.pair_d6 = reinterpret_cast<const double2 *>(c->aeam_pair_d8.p);

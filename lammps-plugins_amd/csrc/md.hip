@@ -16,8 +16,8 @@ void mdp_rebomos_fill_dev(mdp_ctx *c, double skin);
 namespace {
 
 struct CutTables {
-  double owned[16]; // cutneighsq[ei*4+ej]  element/type pair
-  double ghost[16]; // 0 => no ghost lists
+  double owned[MDP_AEAM_MAXT * MDP_AEAM_MAXT]; // cutneighsq[ei*ne+ej]  element/type pair
+  double ghost[MDP_AEAM_MAXT * MDP_AEAM_MAXT]; // 0 => no ghost lists
   int ne;           // table stride
   int min_type;     // owned atoms of a lower type get an empty row (AEAM with tile lists: only angular centres read the CSR list)
 };

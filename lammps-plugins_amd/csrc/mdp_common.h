@@ -88,13 +88,16 @@ struct MdpGrid {
   int range; // stencil half width in cells: range * cell width >= the cutoff the grid was made for
 };
 
+// atom types / elements an AEAM potential file may define here (the reference sizes everything from the file,
+// pair_aeam.cpp:752-872; the bundled AlSi.aeam has two)
+#define MDP_AEAM_MAXT 8
 struct AeamDev {
   int ntypes, nelements, nnonangular, nrhomax, nrmax;
-  // per type pair [(ti-1)*ntypes + (tj-1)], ntypes <= 4
-  double cut[16], rdr[16];
-  int nr[16], t2rhor[16], t2z2r[16];
-  double rdrho[4];
-  int nrho[4], t2frho[4];
+  // per type pair [(ti-1)*ntypes + (tj-1)], ntypes <= MDP_AEAM_MAXT
+  double cut[MDP_AEAM_MAXT * MDP_AEAM_MAXT], rdr[MDP_AEAM_MAXT * MDP_AEAM_MAXT];
+  int nr[MDP_AEAM_MAXT * MDP_AEAM_MAXT], t2rhor[MDP_AEAM_MAXT * MDP_AEAM_MAXT], t2z2r[MDP_AEAM_MAXT * MDP_AEAM_MAXT];
+  double rdrho[MDP_AEAM_MAXT];
+  int nrho[MDP_AEAM_MAXT], t2frho[MDP_AEAM_MAXT];
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
   const double2 *rhor_ys, *z2r_ys; // [table][nrmax+1] (value, slope) = columns 6 and 5 of a row: the persistent tile kernels' tables
@@ -282,6 +285,7 @@ struct mdp_ctx {
   DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
   double skin_inner_auto = 1.0;   // adaptive default of it (grows when the displacement trigger fires too often)
+  double skin_inner_cap = 1.0e9;  // a skin at which a candidate row outgrew the 64-bit active mask (dense systems)
   long long computes_since_build = 0;
   bool stale_rebuild = false;     // the pending rebuild was asked for by the displacement trigger
   long long style_builds = 0;     // number of style-list builds so far

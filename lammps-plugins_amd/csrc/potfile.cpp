@@ -179,7 +179,7 @@ int mdp_aeam_file_read(const char *path, mdp_aeam_file **out, char *err, int err
     F->nelements = (int) v[0];
     F->nnonangular = (int) v[1];
     F->nangular = (int) v[2];
-    if (F->nelements < 1 || F->nelements > 4) return fail("unsupported number of elements");
+    if (F->nelements < 1 || F->nelements > 8) return fail("unsupported number of elements (1..8)");
     for (int i = 0; i < F->nelements; i++) {
       while (*s == ' ' || *s == '\t') ++s;
       const size_t len = strcspn(s, " \t\r\n");
@@ -296,7 +296,7 @@ static void spline_rows(int n, double h, const double *y, double *rows)
 // file2array + array2spline for `ntypes` atom types, map[1..ntypes] = element index or -1 (NULL)
 int mdp_aeam_file_build(mdp_aeam_file *F, int ntypes, const int *map, mdp_aeam_tables *out)
 {
-  if (!F || !map || !out || ntypes < 1 || ntypes > 4) return MDP_EINVAL;
+  if (!F || !map || !out || ntypes < 1 || ntypes > 8) return MDP_EINVAL;
   const int ne = F->nelements;
   const size_t fs = (size_t) F->nrhomax + 1, rs = (size_t) F->nrmax + 1;
   F->ntypes = ntypes;

@@ -3086,7 +3086,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
     double want = c->skin_inner_auto;
     if (const char *e = getenv("MDP_INNER_SKIN")) {
       want = atof(e);
-    } else if (c->stale_rebuild && c->computes_since_build < 200 && want + 0.2 < s_in + 1e-9) {
+    } else if (c->stale_rebuild && c->computes_since_build < 200 && want + 0.2 < s_in + 1e-9 &&
+               want + 0.2 < c->skin_inner_cap - 1e-9) { // (never back to a skin whose candidate rows overflowed)
       want += 0.2;
       c->skin_inner_auto = want;
     }
@@ -3369,6 +3370,16 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
   if (hflags[1]) {
     if (getenv("MDP_DIAG")) repack_diag(c);
+    // A candidate row holds the atoms within rcmax + inner skin and the active mask has 64 bits.  Rows that
+    // overflow because of the SKIN (a dense system: the reference's REBO list itself, pair_rebomos.cpp:337-350,
+    // would still be short) are rebuilt with half the skin, down to 0.2 A: then only 65 atoms inside rcmax
+    // itself (3.8 A: six times the density of MoS2) stop the run, with the reference's words.
+    if (c->skin_inner > 0.2 + 1e-9 && !getenv("MDP_INNER_SKIN")) {
+      c->skin_inner_cap = c->skin_inner;
+      c->skin_inner_auto = 0.5 * c->skin_inner > 0.2 ? 0.5 * c->skin_inner : 0.2;
+      c->stale_rebuild = false;
+      return mdp_rebomos_repack(c);
+    }
     return mdp_fail(c, MDP_EOVERFLOW, "rebomos: an atom has more than 64 neighbours inside rcmax+skin (Neighbor list overflow)");
   }
   { // packed candidate heads of the lane-group classes (widths = UA*G of rebo_centre_kernel<G>), per element
@@ -3875,11 +3886,12 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
       }
     }
   } else {
-    // resident runs walk pruned rows (see tile_prune_kernel); host mode re-uploads positions every step and is
-    // bound by that, a per-atom-virial step reads the rows as built
+    // the kernels walk pruned rows (see tile_prune_kernel) -- resident runs with the deferred displacement trigger,
+    // host mode with the blocking check every compute does anyway (rebomos_lists_stale); a per-atom-virial step
+    // reads the rows as built
     const char *ep = getenv("MDP_PRUNE");
     const int prune_on = ep ? atoi(ep) : 1;
-    if (prune_on && c->md && c->lj_tiled && c->ntile > 0) {
+    if (prune_on && c->lj_tiled && c->ntile > 0) {
       mdp_prune_adapt(c, c->skin_inner - 0.2, c->prune_valid && c->prune_stale);
       if (c->prune_buf < c->skin_inner) { // (a buffer as wide as the skin prunes nothing)
         if (!c->prune_valid || c->prune_stale) {

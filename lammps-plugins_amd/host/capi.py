@@ -123,7 +123,7 @@ class AeamFile:
         if rc:
             raise MdpError(rc, err.value.decode())
         ne, nn, na = C.c_int(), C.c_int(), C.c_int()
-        mass = (C.c_double * 4)()
+        mass = (C.c_double * 8)()
         names = C.create_string_buffer(128)
         lib().mdp_aeam_file_info(self.h, C.byref(ne), C.byref(nn), C.byref(na), mass, names, C.c_int(128))
         self.nelements, self.nnonangular, self.nangular = ne.value, nn.value, na.value

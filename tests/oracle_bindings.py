@@ -22,7 +22,7 @@ class RebomosParams(C.Structure):
         ("cut3rebo", C.c_double)]
 
 
-MAXEL = 4
+MAXEL = 8
 
 
 class AeamPot(C.Structure):

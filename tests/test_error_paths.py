@@ -294,3 +294,27 @@ def test_host_reallocates_x_between_steps(register, monkeypatch):
     assert np.abs(f - f0).max() > 1e-3                             # and they really changed
     ctx.close()
     ctx2.close()
+
+
+@gpu
+def test_candidate_rows_that_overflow_only_because_of_the_skin_are_rebuilt_with_a_smaller_skin(oracle):
+    """a simple-cubic block of S atoms 1.5 A apart: 79 atoms within rcmax + 1 A of an interior atom (more than the
+    64 bits of the active mask) but 33 inside rcmax itself, which the reference would simply list
+    (pair_rebomos.cpp:337-350, oneatom = 2000).  The style halves its inner skin until the rows fit and computes;
+    forces equal the oracle's (interior centres go through the general kernel: more than 32 neighbours)."""
+    import mdref
+    g = np.arange(7) * 1.5
+    x = np.array([[a, b, c] for a in g for b in g for c in g]) + 25.0
+    n = len(x)
+    s = S.System(BOX, x, np.full(n, 2, np.int32), np.arange(1, n + 1, dtype=np.int32), np.array([0.0, 95.95, 32.065]))
+    ctx = capi.Context(0)
+    ctx.rebomos_set_params(capi.read_rebomos_file(POT_REBOMOS))
+    ctx.set_atoms_host(n, s.x, s.type, s.tag, 2, map_=[0, 0, 1])
+    ctx.set_skin(2.0)
+    r = ctx.rebomos_compute_host(n)
+    P = oracle.rebomos_params(POT_REBOMOS)
+    o = mdref.RebomosCPU(oracle, P, s).compute(s.x)
+    scale = np.abs(o["f_owned"]).max()
+    assert np.abs(r["f"] - o["f_owned"]).max() < 1e-11 * scale
+    assert r["eng"] == pytest.approx(o["eng"], rel=1e-11)
+    ctx.close()

@@ -232,3 +232,73 @@ def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     assert t["pe"] == pytest.approx(o["eng"], rel=1e-11)
     assert np.allclose(t["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
     ctx.close()
+
+
+def _five_element_file(path):
+    """a 5-element potential file (3 non-angular, 2 angular) made of the blocks of AlSi.aeam: Ala, Alb, Alc behave as
+    Al, Sia and Sib as Si -- so a 5-type system must reproduce the 2-type system atom for atom"""
+    lines = open(POT_AEAM).read().split("\n")
+    head, body = lines[:11], lines[18:]
+    vals = np.array(" ".join(body).split(), dtype=float)
+    n = 10000
+    assert len(vals) == 9 * n
+    F = [vals[0:n], vals[n:2 * n]]
+    rhor = {(a, b): vals[(2 + 2 * a + b) * n:(3 + 2 * a + b) * n] for a in range(2) for b in range(2)}
+    z2r = {(0, 0): vals[6 * n:7 * n], (1, 0): vals[7 * n:8 * n], (1, 1): vals[8 * n:9 * n]}
+    cls = [0, 0, 0, 1, 1]
+    names = ["Ala", "Alb", "Alc", "Sia", "Sib"]
+    el = [lines[12], lines[13]]                      # nrho drho mass of Al, Si
+    pr = {(0, 0): lines[14], (0, 1): lines[15], (1, 0): lines[16], (1, 1): lines[17]}
+    out = head + ["5 3 2 " + " ".join(names)]
+    out += [" ".join(el[c].split()[:3]) + " " + nm for c, nm in zip(cls, names)]
+    out += [" ".join(pr[(cls[i], cls[j])].split()[:3]) for i in range(5) for j in range(5)]
+
+    def block(v):
+        return [" ".join("%.16e" % x for x in v[k:k + 5]) for k in range(0, len(v), 5)]
+    for c in cls:
+        out += block(F[c])
+    for i in range(5):
+        for j in range(5):
+            out += block(rhor[(cls[i], cls[j])])
+    for i in range(5):
+        for j in range(i + 1):
+            out += block(z2r[(max(cls[i], cls[j]), min(cls[i], cls[j]))])
+    open(path, "w").write("\n".join(out) + "\n")
+
+
+def test_five_atom_types_size_everything_from_the_file(oracle, tmp_path):
+    """The reference sizes its tables from the potential file (pair_aeam.cpp:752-872); the bundled file has two
+    elements.  Five types (three metals, two angular) built from the same functions: the device result equals the
+    oracle's for the five-element file AND the two-type AlSi system's, atom for atom (CSR kernels: more than two
+    types have no tile lists)."""
+    path = str(tmp_path / "five.aeam")
+    _five_element_file(path)
+    s2 = S.jitter(S.fcc_cell(4.045, 6, frac_type2=0.08, seed=11), 0.06, seed=12)
+    rng = np.random.default_rng(3)
+    t5 = np.where(s2.type == 1, rng.integers(1, 4, s2.n), rng.integers(4, 6, s2.n)).astype(np.int32)
+    assert set(t5.tolist()) == {1, 2, 3, 4, 5}
+    af5 = capi.AeamFile(path)
+    assert af5.nelements == 5 and af5.nnonangular == 3 and af5.nangular == 2
+    s5 = S.System(s2.box, s2.x.copy(), t5, s2.tag.copy(), np.array([0.0] + list(af5.mass)))
+    out = {}
+    for tag, (af, s) in {"five": (af5, s5), "two": (capi.AeamFile(POT_AEAM), s2)}.items():
+        tabs = af.build()
+        ctx = capi.Context(0)
+        ctx.aeam_set_tables(tabs)
+        s.mass[1:1 + af.nelements] = af.mass
+        d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, float(af.cut_table(tabs).max()) + 1.0, 1.0, None)
+        d.compute(3, 1)
+        th = d.thermo()
+        got = ctx.md_download(d.nlocal, want=("f", "eatom"))
+        order = np.argsort(d.tags_local)
+        out[tag] = (got["f"][order], got["eatom"][order], th)
+        ctx.close()
+    f5, e5, th5 = out["five"]
+    f2, e2, th2 = out["two"]
+    assert np.abs(f5 - f2).max() < 1e-10 and np.abs(e5 - e2).max() < 1e-10
+    assert th5["pe"] == pytest.approx(th2["pe"], rel=1e-12)
+    T5 = oracle.aeam_pot(path)
+    xw = S.wrap(s5.box, s5.x)
+    o = mdref.AeamCPU(oracle, T5, S.System(s5.box, xw, s5.type, s5.tag, s5.mass)).compute(xw)
+    assert np.abs(f5 - o["f_owned"]).max() < 1e-9
+    assert th5["pe"] == pytest.approx(o["eng"], rel=1e-11)
