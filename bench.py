@@ -172,7 +172,7 @@ def host_mode_rate(E, s, workload, pot, skin, cutghost, steps=9):
     capi, S = E["capi"], E["S"]
     xw = S.wrap(s.box, s.x)
     owner, shift = S.make_ghosts(s.box, xw, cutghost)
-    xa = np.ascontiguousarray(np.concatenate([xw, xw[owner] + shift @ s.box.h.T]))
+    xa = np.ascontiguousarray(np.concatenate([xw, xw[owner] + S.mul_upper(shift, s.box.h)]))
     type_all = np.concatenate([s.type, s.type[owner]]).astype(np.int32)
     tag_all = np.concatenate([s.tag, s.tag[owner]]).astype(np.int32)
     n, nall = s.n, len(xa)

@@ -70,7 +70,7 @@ class Decomposition:
             # order: self-images first, then by source rank; inside a group follow the source's local order
             key_rank = np.where(src == r, -1, src)
             order = np.lexsort((self.local_index[gidx], key_rank))
-            self.ghosts.append((gidx[order], gshift[order] @ box.h.T, key_rank[order]))
+            self.ghosts.append((gidx[order], S.mul_upper(gshift[order], box.h), key_rank[order]))
 
     def sub_bounds(self, r):
         g = self.grid

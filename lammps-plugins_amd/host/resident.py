@@ -5,6 +5,7 @@ around Pair::compute() that the bench and the tests need (Verlet::run loop of fi
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 
 import numpy as np
 
@@ -135,7 +136,7 @@ class Domain:
             order = spatial_order(x, s.box.lo, 3.0, group=s.type, box=s.box)
             x, v, t, g = x[order], v[order], t[order], g[order]
         owner, shift = S.make_ghosts(s.box, x, cutghost)
-        shift_cart = shift @ s.box.h.T
+        shift_cart = S.mul_upper(shift, s.box.h)
         if sort and len(owner):
             go = spatial_order(x[owner] + shift_cart, s.box.lo - cutghost - 1.0, 3.0, box=s.box)
             owner, shift_cart = owner[go], shift_cart[go]
@@ -484,6 +485,9 @@ class DeviceDomain:
             f64 = dict(dtype=torch.float64, device=tr.device)
             sc = ctx.dd_migrate_begin()
             rc = tr.counts(sc)
+            if _os.environ.get("MDP_DIAG"):
+                print(f"[dd diag] rank {self.rank} reneighbor {self.builds}: nlocal {ctx.dd_info()['nlocal']} "
+                      f"leave {sc.tolist()} arrive {rc.tolist()}", flush=True)
             send = torch.empty(max(int(sc.sum()) * 8, 1), **f64)
             ctx.dd_migrate_pack(send.data_ptr())
             recv, _ = tr.exchange(send, sc, rc, 8)

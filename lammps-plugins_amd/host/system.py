@@ -20,6 +20,16 @@ NKTV2P = 1.6021765e6
 NEIGHMASK = 0x1FFFFFFF
 
 
+def mul_upper(a: np.ndarray, m: np.ndarray) -> np.ndarray:
+    """rows of `a` times the transpose of the upper-triangular 3x3 matrix m (= a @ m.T), element by element"""
+    a = np.asarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    out[..., 0] = m[0, 0] * a[..., 0] + m[0, 1] * a[..., 1] + m[0, 2] * a[..., 2]
+    out[..., 1] = m[1, 1] * a[..., 1] + m[1, 2] * a[..., 2]
+    out[..., 2] = m[2, 2] * a[..., 2]
+    return out
+
+
 @dataclasses.dataclass
 class Box:
     """LAMMPS (restricted-)triclinic box: edge vectors a=(xprd,0,0), b=(xy,yprd,0), c=(xz,yz,zprd)."""
@@ -34,17 +44,26 @@ class Box:
 
     @property
     def hinv(self) -> np.ndarray:
-        return np.linalg.inv(self.h)
+        # Domain::set_global_box: closed-form inverse of the upper-triangular h (no LAPACK call)
+        xprd, yprd, zprd = self.prd
+        xy, xz, yz = self.tilt
+        return np.array([[1.0 / xprd, -xy / (xprd * yprd), (yz * xy - yprd * xz) / (xprd * yprd * zprd)],
+                         [0.0, 1.0 / yprd, -yz / (yprd * zprd)],
+                         [0.0, 0.0, 1.0 / zprd]])
 
     @property
     def volume(self) -> float:
         return float(np.prod(self.prd))
 
+    # Domain::x2lamda / lamda2x written out term by term (as LAMMPS and csrc/domain.hip do).  No `@`: numpy hands a
+    # matrix product to the BLAS library, and concurrent products from several Python threads -- the rank threads of
+    # resident.run_ranks -- returned wrong rows now and then (measured here: `a @ b.T` in 8 threads), which put atoms
+    # into the wrong brick or on top of each other before the device library ever saw them.
     def x2lamda(self, x: np.ndarray) -> np.ndarray:
-        return (x - self.lo) @ self.hinv.T
+        return mul_upper(np.asarray(x, dtype=np.float64) - self.lo, self.hinv)
 
     def lamda2x(self, lam: np.ndarray) -> np.ndarray:
-        return lam @ self.h.T + self.lo
+        return mul_upper(np.asarray(lam, dtype=np.float64), self.h) + self.lo
 
     def replicate(self, n) -> "Box":
         n = np.asarray(n, dtype=float)
@@ -200,7 +219,7 @@ def make_ghosts(box: Box, x: np.ndarray, cut: float, sublo=None, subhi=None, lam
 def with_ghosts(s: System, cut: float):
     """Single-domain system: returns (x_all, type_all, tag_all, owner, shift_cart, nlocal, nghost)."""
     owner, shift = make_ghosts(s.box, s.x, cut)
-    shift_cart = shift @ s.box.h.T
+    shift_cart = mul_upper(shift, s.box.h)
     xg = s.x[owner] + shift_cart
     x_all = np.ascontiguousarray(np.concatenate([s.x, xg]))
     type_all = np.concatenate([s.type, s.type[owner]]).astype(np.int32)

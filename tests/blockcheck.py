@@ -18,9 +18,9 @@ from lammps_plugins_amd.host import system as S
 def cut_block(box: S.Box, x: np.ndarray, point: np.ndarray, n_interior: int, shell: float):
     """indices of the n_interior atoms nearest to `point` and of all atoms within `shell` of that ball, plus the
     minimum-image displacements of the latter from `point`"""
-    lam = (x - point) @ box.hinv.T
+    lam = S.mul_upper(x - point, box.hinv)
     lam -= np.round(lam)
-    d = lam @ box.h.T
+    d = S.mul_upper(lam, box.h)
     r2 = np.einsum("ij,ij->i", d, d)
     inner = np.argpartition(r2, n_interior)[:n_interior]
     r_int = float(np.sqrt(r2[inner].max()))

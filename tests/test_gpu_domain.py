@@ -64,7 +64,7 @@ def test_device_ghosts_equal_the_host_planned_ghosts():
     d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
     owner, shift = S.make_ghosts(s.box, S.wrap(s.box, s.x), cutghost)
     assert d.nself == len(owner)
-    want = np.round(S.wrap(s.box, s.x)[owner] + shift @ s.box.h.T, 6)
+    want = np.round(S.wrap(s.box, s.x)[owner] + S.mul_upper(shift, s.box.h), 6)
     g = np.round(ctx.md_download_x_all(d.nlocal + d.nghost)[d.nlocal:], 6)
     assert sorted(map(tuple, g)) == sorted(map(tuple, want))
     ctx.close()
@@ -81,7 +81,7 @@ def test_atoms_outside_the_box_are_remapped(oracle):
     got = ctx.md_download(d.nlocal, want=("x",))
     tags = d.tags_local
     rng = np.random.default_rng(5)
-    kick = rng.integers(-1, 2, size=(d.nlocal, 3)).astype(float) @ s.box.h.T
+    kick = rng.integers(-1, 2, size=(d.nlocal, 3)).astype(float) @ s.box.h.T  # (main thread only)
     ctx.md_upload_x(got["x"] + kick)
     d.reneighbor()
     assert d.nlocal == s.n and sorted(d.tags_local.tolist()) == list(range(1, s.n + 1))
