@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MDP_ABI_VERSION 1
+#define MDP_ABI_VERSION 2
 
 enum {
   MDP_OK = 0,
@@ -266,7 +266,8 @@ int mdp_rebomos_list_info(mdp_ctx *ctx, long long out[8]);
  *     mdp_dd_borders_pack   -> 6 doubles per entry, rank-major              [exchange records]
  *     mdp_dd_borders_end    <- remote ghosts; then mdp_md_build_neighbors
  * and per step mdp_dd_forward_pack / _unpack (3 doubles per send-list entry).  A one-rank run needs no transport:
- * mdp_dd_reneighbor does the whole sequence.  All three dimensions are periodic (as in both bundled inputs). */
+ * mdp_dd_reneighbor does the whole sequence.  Dimensions are periodic (as in both bundled inputs) unless
+ * mdp_dd_config.nonperiodic says otherwise. */
 typedef struct {
   double boxlo[3];
   double h[6];        /* xprd, yprd, zprd, yz, xz, xy  (LAMMPS Domain::h) */
@@ -275,6 +276,9 @@ typedef struct {
   double cutghost;    /* ghost-shell width: the host's list cutoff, pair cutoff + skin (log.rebomos-bulk.1:43) */
   int self_remote;    /* 0.  Testing aid: 1 = periodic self-images are treated as remote ghosts that travel through the
                          transport to the rank itself (exercises every exchange with a single rank / GPU) */
+  int nonperiodic[3]; /* 0 0 0 (both bundled inputs: `boundary p p p`).  1 = this dimension is not periodic (LAMMPS
+                         boundary f / s / m: a slab, a free surface, a cluster): no images across it, positions are
+                         not wrapped, atoms beyond the box belong to the brick at that end */
 } mdp_dd_config;
 
 int mdp_dd_setup(mdp_ctx *ctx, const mdp_dd_config *cfg); /* after mdp_md_setup (owned atoms in any order, ghosts optional) */

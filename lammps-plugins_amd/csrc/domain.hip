@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256) void dd_remap_kernel(const DdGeom G, const int
   bool moved = false;
 #pragma unroll
   for (int d = 0; d < 3; d++) {
+    if (G.nonper[d]) { // not periodic: the atom stays where it is, beyond the box it belongs to the brick at that end
+      s[d] = 0.0;
+      continue;
+    }
     s[d] = floor(lam[d]);
     lam[d] -= s[d];
     if (lam[d] >= 1.0) { // lam was a tiny negative number: lam - floor(lam) rounds to 1
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void dd_remap_kernel(const DdGeom G, const int
   int b[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {
-    b[d] = (int) (lam[d] * G.g[d]);
+    b[d] = lam[d] < 0.0 ? 0 : (int) (lam[d] * G.g[d]);
     b[d] = b[d] < 0 ? 0 : (b[d] >= G.g[d] ? G.g[d] - 1 : b[d]);
   }
   const int q = (b[0] * G.g[1] + b[1]) * G.g[2] + b[2];
@@ -185,7 +189,11 @@ __device__ __forceinline__ void dd_dim_hits(const DdGeom &G, const int d, const 
   for (int s = -G.ns[d]; s <= G.ns[d]; s++) {
     const double ls = lam + (double) s;
     for (int b = 0; b < G.g[d]; b++) {
-      const double lo = (double) b / (double) G.g[d] - G.cutl[d], hi = (double) (b + 1) / (double) G.g[d] + G.cutl[d];
+      double lo = (double) b / (double) G.g[d] - G.cutl[d], hi = (double) (b + 1) / (double) G.g[d] + G.cutl[d];
+      if (G.nonper[d]) { // the end bricks of a non-periodic dimension reach to infinity
+        if (b == 0) lo = -1.0e300;
+        if (b == G.g[d] - 1) hi = 1.0e300;
+      }
       if (ls >= lo && ls < hi && H.n < 12) {
         H.s[H.n] = (signed char) s;
         H.b[H.n] = (signed char) b;
@@ -459,7 +467,8 @@ int mdp_dd_setup(mdp_ctx *c, const mdp_dd_config *cfg)
   G.cutl[1] = cfg->cutghost * sqrt(G.hinv[1] * G.hinv[1] + G.hinv[3] * G.hinv[3]);
   G.cutl[2] = cfg->cutghost * G.hinv[2];
   for (int d = 0; d < 3; d++) {
-    G.ns[d] = (int) floor(G.cutl[d]) + 1;
+    G.nonper[d] = cfg->nonperiodic[d] ? 1 : 0;
+    G.ns[d] = G.nonper[d] ? 0 : (int) floor(G.cutl[d]) + 1;
     if (G.ns[d] > 3 || (2 * G.ns[d] + 1) * G.g[d] > 1000000)
       return mdp_fail(c, MDP_EINVAL, "mdp_dd_setup: the ghost cutoff spans more than three box lengths");
     // at most 12 (shift, brick) hits per dimension: (1/g + 2 cutl) * g bricks-widths, one hit each

@@ -148,6 +148,7 @@ struct DdGeom {
   double cutl[3];       // ghost-shell width in lamda (fractional) units
   int ns[3];            // periodic image shifts tested per dimension: -ns .. ns
   int self_remote;      // testing: periodic self-images travel through the transport (to the rank itself)
+  int nonper[3];        // 1: no periodic images / no wrap in this dimension (slab, free surface)
 };
 
 struct MdpDomain {

@@ -42,7 +42,7 @@ class MdConfig(C.Structure):
 class DdConfig(C.Structure):
     """mirror of mdp_dd_config"""
     _fields_ = [("boxlo", C.c_double * 3), ("h", C.c_double * 6), ("procgrid", C.c_int * 3), ("rank", C.c_int),
-                ("cutghost", C.c_double), ("self_remote", C.c_int)]
+                ("cutghost", C.c_double), ("self_remote", C.c_int), ("nonperiodic", C.c_int * 3)]
 
 
 STYLE_REBOMOS, STYLE_AEAM = 1, 2
@@ -400,8 +400,9 @@ class Context:
         return dict(prunings=int(out[0]), late=int(out[1]), active=bool(out[2]), buffer=out[3] * 1e-6)
 
     # ---------------- domain decomposition on the device (csrc/domain.hip)
-    def dd_setup(self, box, procgrid, rank, cutghost, self_remote=False):
-        """box: host.system.Box (restricted triclinic); procgrid: bricks per dimension"""
+    def dd_setup(self, box, procgrid, rank, cutghost, self_remote=False, nonperiodic=(0, 0, 0)):
+        """box: host.system.Box (restricted triclinic); procgrid: bricks per dimension; nonperiodic[d] = 1: no
+        periodic images / no wrap in dimension d (LAMMPS boundary f / s)"""
         cfg = DdConfig()
         xy, xz, yz = (float(t) for t in box.tilt)
         for d in range(3):
@@ -410,6 +411,8 @@ class Context:
         for k, val in enumerate((box.prd[0], box.prd[1], box.prd[2], yz, xz, xy)):
             cfg.h[k] = float(val)
         cfg.rank, cfg.cutghost, cfg.self_remote = int(rank), float(cutghost), 1 if self_remote else 0
+        for d in range(3):
+            cfg.nonperiodic[d] = 1 if nonperiodic[d] else 0
         self._ck(self.L.mdp_dd_setup(self.h, C.byref(cfg)))
         self._dd_nranks = int(procgrid[0]) * int(procgrid[1]) * int(procgrid[2])
 

@@ -431,7 +431,7 @@ class DeviceDomain:
 
     def __init__(self, ctx: capi.Context, style: int, s: S.System, cutghost: float, skin: float, map_, v0=None,
                  dt: float = 0.001, transport: Transport | None = None, master_list: bool = False,
-                 self_remote: bool = False):
+                 self_remote: bool = False, nonperiodic=(0, 0, 0)):
         from . import decomp
         self.ctx, self.style, self.box, self.skin, self.dt = ctx, style, s.box, skin, dt
         self.tr = transport
@@ -439,7 +439,10 @@ class DeviceDomain:
         self.rank = 0 if transport is None else transport.rank
         self.grid = decomp.proc_grid(self.world)
         self.natoms_total = s.n
-        xw = S.wrap(s.box, s.x)
+        # (dimensions that are not periodic -- a slab, a free surface -- are neither wrapped nor given images)
+        lam0 = s.box.x2lamda(s.x)
+        per = np.array([0.0 if nonperiodic[d] else 1.0 for d in range(3)])
+        xw = np.ascontiguousarray(s.box.lamda2x(lam0 - np.floor(lam0) * per))
         if self.world > 1:
             g = np.array(self.grid)
             lam = s.box.x2lamda(xw)
@@ -463,7 +466,7 @@ class DeviceDomain:
             # collectives synchronise with (torch's current stream)
             ctx.set_stream(transport.torch.cuda.current_stream().cuda_stream)
         ctx.md_setup(cfg, x, v, s.type[mine], s.tag[mine], s.mass, map_, e1, e3, e1, e1)
-        ctx.dd_setup(s.box, self.grid, self.rank, cutghost, self_remote=self_remote)
+        ctx.dd_setup(s.box, self.grid, self.rank, cutghost, self_remote=self_remote, nonperiodic=nonperiodic)
         self.native = bool(getattr(transport, "native", False))
         if self.native:
             transport.attach(ctx)

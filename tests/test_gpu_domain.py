@@ -396,3 +396,69 @@ def test_eight_bricks_hot_run_meets_the_oracle_at_the_seams(oracle):
                                           lambda cs: mdref.RebomosCPU(oracle, P, cs), n_interior=400, shell=11.0,
                                           margin=16.0, tol=1e-9)
     assert len(rows) >= 7
+
+
+def test_slab_with_a_non_periodic_dimension(oracle):
+    """`boundary p p f`: a 28 A thick MoS2 slab in a 56 A cell whose z direction is NOT periodic (mdp_dd_config
+    .nonperiodic): no images across z, no wrap, the end bricks take whatever lies beyond the box.  One brick:
+    forces equal the oracle's for the same slab (the oracle is periodic, the 28 A of vacuum keep the images out of
+    range).  2x2x2 bricks (the z seam runs through the slab): same trajectory while atoms drift across the seam; one
+    atom pushed out through the top of the box stays owned, unwrapped, by the upper bricks."""
+    P = oracle.rebomos_params(POT_REBOMOS)
+    b = S.replicate(S.rebomos_bulk_cell(), (4, 3, 2))
+    box = S.Box(b.box.lo.copy(), b.box.prd * np.array([1.0, 1.0, 2.0]), b.box.tilt.copy())
+    x = b.x + np.array([0.0, 0.0, 6.0])          # 6 A of vacuum below, 22 A above: periodic images 28 A apart
+    s = S.jitter(S.System(box, x, b.type, b.tag, b.mass), 0.05, seed=31)
+    nonper = (0, 0, 1)
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP, nonperiodic=nonper)
+    d.compute(3, 1)
+    th = d.thermo()
+    tags, a = _by_tag(d, ("x", "f"))
+    order = np.argsort(tags)
+    o = mdref.RebomosCPU(oracle, P, S.System(box, S.wrap(box, s.x), s.type, s.tag, s.mass)).compute(S.wrap(box, s.x))
+    assert np.abs(a["f"][order] - o["f_owned"]).max() < 1e-9
+    assert th["pe"] == pytest.approx(o["eng"], rel=1e-10)
+    # fewer ghosts than the fully periodic cell would have: none below and above the slab
+    dper = resident.DeviceDomain(_rebo_ctx()[0], capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    assert d.nself < dper.nself
+    dper.ctx.close()
+    ctx.close()
+
+    v0 = S.gaussian_velocities(s, 300.0, seed=4) + np.array([30.0, -20.0, 60.0])
+    top = int(np.argmax(s.x[:, 2]))                             # an atom of the top layer evaporates: it leaves through
+    v0[top] = np.array([0.0, 0.0, 800.0])                        # the top of the box within the run (24 A in 30 steps)
+
+    def run(world):
+        def rank_fn(r, make_tr):
+            c, cg = _rebo_ctx()
+            tr = make_tr(c) if world > 1 else None
+            dd = resident.DeviceDomain(c, capi.STYLE_REBOMOS, s, cg, 2.0, MAP, v0=v0, transport=tr, nonperiodic=nonper)
+            dd.compute(0, 0)
+            left = 0
+            for step in range(1, 31):
+                rb = step % 3 == 0
+                dd.step(0, 0, rebuild=rb)
+                if rb:
+                    left += c.dd_info()["left_last"]
+            t, arr = _by_tag(dd, ("x", "v"))
+            c.close()
+            return t, arr["x"], arr["v"], left
+        res = [rank_fn(0, None)] if world == 1 else resident.run_ranks(world, rank_fn)
+        xx, vv = np.zeros((s.n, 3)), np.zeros((s.n, 3))
+        seen = np.zeros(s.n, dtype=int)
+        for t, xr, vr, _ in res:
+            xx[t - 1], vv[t - 1] = xr, vr
+            seen[t - 1] += 1
+        assert np.all(seen == 1)
+        return xx, vv, sum(r[3] for r in res)
+
+    x1, v1, _ = run(1)
+    x8, v8, left = run(8)
+    assert left > 10                                           # atoms crossed the seams
+    assert x1[top, 2] > box.lo[2] + box.prd[2]                 # the evaporated atom is above the box, not wrapped
+    dx = x8 - x1
+    lam = np.round(S.mul_upper(dx, box.hinv))
+    lam[:, 2] = 0.0                                            # (no periodic image in z to forgive)
+    dx -= S.mul_upper(lam, box.h)
+    assert np.abs(dx).max() < 1e-8 and np.abs(v8 - v1).max() < 1e-7
