@@ -473,8 +473,10 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
       double cs = (ux * q[0] + uy * q[1] + uz * q[2]) * q[kInvF];
       cs = fmin(cs, 1.0);
       cs = fmax(cs, -1.0);
-      double dg;
-      const double g = gspline(cb, cg, cs, dg);
+      double dg, g;
+      // (wave-uniform test: the blend of the two polynomials is skipped when no pair of this trip has cos >= 1/2)
+      if (__any(cs >= 0.5)) g = gspline(cb, cg, cs, dg);
+      else g = poly6(cb, cs, dg);
       double *e = mat + 2 * ((d - 1) * G + m);
       e[0] = g;
       e[1] = dg;
