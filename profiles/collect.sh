@@ -9,9 +9,9 @@ cd $R
 python3 bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 SHA=$(python3 -c "import bench; print(bench.kernel_source_sha())")
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline --no-host-mode > $OUT/trace.json 2> $OUT/trace.err || echo "trace failed"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-mode > /dev/null 2> $OUT/pmc_fetch.err || echo "fetch failed"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-mode > /dev/null 2> $OUT/pmc_write.err || echo "write failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline --no-host-mode --no-secondary > $OUT/trace.json 2> $OUT/trace.err || echo "trace failed"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-mode --no-secondary > /dev/null 2> $OUT/pmc_fetch.err || echo "fetch failed"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-host-mode --no-secondary > /dev/null 2> $OUT/pmc_write.err || echo "write failed"
 cd $R
 python3 profiles/summarize_trace.py $OUT/trace/*/*kernel_trace.csv > $OUT/kernel_summary.txt
 cp $OUT/trace/*/*kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv 2>/dev/null

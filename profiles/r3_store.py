@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""copy the round-3 collection (gpurun_out/r03_*, made by profiles/r3_collect.sh on the GPU box) into profiles/ and
+refresh the entries of profiles/pmc_traffic.json that bench.py reports as `traffic`"""
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tab = json.load(open(os.path.join(P, "pmc_traffic.json")))
+for tag, main in (("r03_rebomos4m", True), ("r03_aeam1m", True), ("r03_rebomos4m_300K", False)):
+    d = os.path.join(G, tag)
+    if not os.path.isdir(d):
+        print("missing", d)
+        continue
+    for src, dst in (("bench.json", "bench.json"), ("kernel_summary.txt", "kernel_summary.txt"),
+                     ("rocprofv3_kernel_stats.csv", "rocprofv3_kernel_stats.csv"), ("pmc_entry.json", "pmc_fetch_write.json")):
+        if os.path.exists(os.path.join(d, src)):
+            shutil.copy(os.path.join(d, src), os.path.join(P, f"{tag}_{dst}"))
+    if main and os.path.exists(os.path.join(d, "pmc_entry.json")):
+        ent = json.load(open(os.path.join(d, "pmc_entry.json")))
+        for k, v in ent.items():
+            if v.get("bytes_per_step", 0) > 0:
+                tab[k] = v
+                print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
+sd = os.path.join(G, "r03_subdomain8")
+if os.path.exists(os.path.join(sd, "timeline.txt")):
+    with open(os.path.join(P, "r03_subdomain8_step_timeline.txt"), "w") as f:
+        f.write(open(os.path.join(sd, "subdomain.json")).read() + "\n" + open(os.path.join(sd, "timeline.txt")).read())
+json.dump(tab, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
