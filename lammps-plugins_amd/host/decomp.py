@@ -43,8 +43,8 @@ class Decomposition:
     def __init__(self, box: S.Box, x: np.ndarray, nranks: int, cutghost: float, sort_cell: float | None = 3.0,
                  type_=None):
         """x: wrapped positions of ALL atoms (identical on every rank); type_: their types (groups the
-        storage order by element inside short stretches of the curve, see resident.spatial_order)"""
-        from .resident import spatial_order
+        storage order by element inside short stretches of the curve, see order.spatial_order)"""
+        from .order import spatial_order
         self.box, self.nranks, self.cut = box, nranks, cutghost
         self.grid = np.array(proc_grid(nranks))
         lam = box.x2lamda(x)

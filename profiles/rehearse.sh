@@ -1,7 +1,7 @@
 #!/bin/bash
 # multi-rank rehearsal on ONE GPU through the PLAIN command line `python3 bench.py --gpus N` (bench.py starts its own
 # rank processes); MDP_BENCH_BACKEND=gloo: the ranks share the card and the halo is staged through the host.
-# usage: profiles/r3_rehearse.sh <tag> ; output under gpurun_out/<tag>/
+# usage: profiles/rehearse.sh <tag> ; output under gpurun_out/<tag>/
 set -u
 cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-rehearse}; mkdir -p $O
 run() { tag=$1; n=$2; shift 2

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""copy the round-3 collection (gpurun_out/r03_*, made by profiles/r3_collect.sh on the GPU box) into profiles/ and
-refresh the entries of profiles/pmc_traffic.json that bench.py reports as `traffic`"""
+"""copy a round's collection (gpurun_out/<round>_*, made by profiles/collect_round.sh on the GPU box) into profiles/
+and refresh the entries of profiles/pmc_traffic.json that bench.py reports as `traffic`.
+usage: python3 profiles/store_round.py r03"""
 import json
 import os
 import shutil
+import sys
+
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 tab = json.load(open(os.path.join(P, "pmc_traffic.json")))
-for tag, main in (("r03_rebomos4m", True), ("r03_aeam1m", True), ("r03_rebomos4m_300K", False)):
+for tag, main in ((RND + "_rebomos4m", True), (RND + "_aeam1m", True), (RND + "_rebomos4m_300K", False)):
     d = os.path.join(G, tag)
     if not os.path.isdir(d):
         print("missing", d)
@@ -23,8 +27,8 @@ for tag, main in (("r03_rebomos4m", True), ("r03_aeam1m", True), ("r03_rebomos4m
             if v.get("bytes_per_step", 0) > 0:
                 tab[k] = v
                 print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
-sd = os.path.join(G, "r03_subdomain8")
+sd = os.path.join(G, RND + "_subdomain8")
 if os.path.exists(os.path.join(sd, "timeline.txt")):
-    with open(os.path.join(P, "r03_subdomain8_step_timeline.txt"), "w") as f:
+    with open(os.path.join(P, RND + "_subdomain8_step_timeline.txt"), "w") as f:
         f.write(open(os.path.join(sd, "subdomain.json")).read() + "\n" + open(os.path.join(sd, "timeline.txt")).read())
 json.dump(tab, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)

@@ -12,6 +12,7 @@ import pytest
 
 from conftest import POT_AEAM, POT_REBOMOS
 from lammps_plugins_amd.host import capi, system as S
+import hostplan
 
 MDP_EINVAL, MDP_EOVERFLOW, MDP_ESTATE = -1, -4, -6
 
@@ -169,7 +170,7 @@ def test_overflow_on_a_force_only_step_is_sticky_until_the_next_host_read():
     ctx.aeam_set_tables(tabs)
     s.mass[1:3] = af.mass[:2]
     cutghost = float(af.cut_table(tabs).max()) + 1.0
-    dom = resident.Domain.single(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
+    dom = hostplan.Domain.single(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
     dom.build_neighbors()
     dom.compute(0, 0)          # overflow happens here, nobody looks
     dom.compute(0, 0)          # ... and the per-compute word is cleared here

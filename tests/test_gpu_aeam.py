@@ -7,6 +7,7 @@ import pytest
 
 from conftest import POT_AEAM
 from lammps_plugins_amd.host import capi, resident, system as S
+import hostplan
 import mdref
 import oracle_bindings as ob
 
@@ -134,7 +135,7 @@ def test_resident_mode_matches_oracle_and_conserves_energy(oracle, T, pot):
     s.mass[1:3] = af.mass
     cutghost = float(af.cut_table(tabs).max()) + 1.0
     v0 = S.gaussian_velocities(s, 600.0, seed=8)
-    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0)
+    d = hostplan.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0)
     d.build_neighbors()
     d.compute(eflag=3, vflag=1)
     t0 = d.thermo()
@@ -151,7 +152,7 @@ def test_resident_mode_matches_oracle_and_conserves_energy(oracle, T, pot):
     for step in range(1, 201):
         d.ctx.md_initial_integrate()
         if step % 10 == 0 and d.needs_rebuild():           # neigh_modify check yes
-            d = resident.reneighbor(d, s, cutghost, None)
+            d = hostplan.reneighbor(d, s, cutghost, None)
         d.compute(0, 0)
         d.ctx.md_final_integrate()
     d.compute(eflag=1, vflag=0)
@@ -172,7 +173,7 @@ def test_resident_force_only_step_matches_oracle(oracle, T, pot, frac, amp):
     s = S.jitter(S.fcc_cell(4.045, 6, frac_type2=frac, seed=11), amp, seed=12)
     s.mass[1:3] = af.mass
     cutghost = float(af.cut_table(tabs).max()) + 1.0
-    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
+    d = hostplan.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
     d.build_neighbors()
     d.compute(eflag=0, vflag=0)                       # tile kernels
     got = ctx.md_download(s.n, want=("x", "f"))
@@ -211,7 +212,7 @@ def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     s = S.jitter(S.fcc_cell(3.55, 6, frac_type2=0.08, seed=21), 0.12, seed=22)   # nearest neighbours at 2.5 A +- 0.3
     s.mass[1:3] = af.mass
     cutghost = float(af.cut_table(tabs).max()) + 1.0
-    d = resident.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
+    d = hostplan.make_domain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None)
     d.build_neighbors()
     d.compute(eflag=0, vflag=0)
     got = ctx.md_download(s.n, want=("x", "f"))

@@ -12,6 +12,7 @@ import pytest
 from conftest import GOLDEN, POT_AEAM, POT_REBOMOS
 from lammps_plugins_amd.host import capi, resident, system as S
 import blockcheck
+import hostplan
 import mdref
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +27,7 @@ def test_rebomos_4m_atoms_known_answers():
     ctx = capi.Context(0)
     p = capi.read_rebomos_file(POT_REBOMOS)
     ctx.rebomos_set_params(p)
-    d = resident.make_domain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1])
+    d = hostplan.make_domain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1])
     d.build_neighbors()
     d.compute(eflag=1, vflag=1)
     t0 = d.thermo()

@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import POT_AEAM, POT_REBOMOS
+import hostplan
 
 pytestmark = pytest.mark.gpu
 
@@ -152,7 +153,7 @@ def _worker(rank, world, port, style, q):
         torch.cuda.set_device(0)
         s, v0 = _build(style)
         ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
-        dom = resident.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0, dist=dist,
+        dom = hostplan.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0, dist=dist,
                                    device=torch.device("cuda", 0), stage_host=True)
         rows = _run(dom, 25)
         tot = []
@@ -184,7 +185,7 @@ def test_two_ranks_on_one_gpu_match_single_domain(style):
     # single-domain reference on the same GPU
     s, v0 = _build(style)
     ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
-    dom = resident.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0)
+    dom = hostplan.make_domain(ctx, st, s, cutghost, skin, map_, v0=v0)
     rows = _run(dom, 25)
     got = ctx.md_download(dom.nlocal, want=("x", "f"))
     x1 = np.zeros((s.n, 3)); f1 = np.zeros((s.n, 3))

@@ -8,6 +8,7 @@ import pytest
 
 from conftest import GOLDEN, POT_REBOMOS
 from lammps_plugins_amd.host import capi, resident, system as S
+import hostplan
 import mdref
 
 pytestmark = pytest.mark.gpu
@@ -24,9 +25,9 @@ def _domain(s, sort, v0=None, skin=2.0):
     ctx.rebomos_set_params(p)
     cutghost = 3.0 * p.rcmax[0][0] + skin
     if sort:
-        d = resident.make_domain(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, [0, 0, 1], v0=v0)
+        d = hostplan.make_domain(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, [0, 0, 1], v0=v0)
     else:   # also build the LAMMPS-style 13.4 A full list, for its statistics (log.rebomos-bulk.1:82)
-        d = resident.Domain.single(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, map_=[0, 0, 1], v0=v0, sort=False,
+        d = hostplan.Domain.single(ctx, capi.STYLE_REBOMOS, s, cutghost, skin, map_=[0, 0, 1], v0=v0, sort=False,
                                    master_list=True)
     d.cutghost = cutghost
     return ctx, d
@@ -91,7 +92,7 @@ def test_rebuild_after_motion_keeps_energy_conserved():
         check = step % 5 == 0
         d.ctx.md_initial_integrate()
         if check and d.needs_rebuild():
-            d = resident.reneighbor(d, s, d0.cutghost, [0, 0, 1])   # re-wrap, re-derive ghosts, rebuild
+            d = hostplan.reneighbor(d, s, d0.cutghost, [0, 0, 1])   # re-wrap, re-derive ghosts, rebuild
         d.ctx.md_compute(1 if check else 0, 0)
         d.ctx.md_final_integrate()
     t1 = d.thermo()

@@ -2,7 +2,7 @@
 consecutive atoms being a compact blob."""
 import numpy as np
 
-from lammps_plugins_amd.host import resident, system as S
+from lammps_plugins_amd.host import resident, system as S, order
 
 
 def _cells(n):
@@ -12,11 +12,11 @@ def _cells(n):
 
 def test_hilbert_curve_has_no_jumps_on_a_full_cube():
     x = _cells(16)
-    o = resident.hilbert_order(x, np.zeros(3), 1.0)
+    o = order.hilbert_order(x, np.zeros(3), 1.0)
     assert sorted(o) == list(range(len(x)))
     step = np.abs(np.diff(x[o], axis=0)).sum(axis=1)
     assert step.max() == 1.0                         # consecutive cells share a face
-    zo = resident.morton_order(x, np.zeros(3), 1.0)
+    zo = order.morton_order(x, np.zeros(3), 1.0)
     assert np.abs(np.diff(x[zo], axis=0)).sum(axis=1).max() > 10   # the Z-order curve jumps
 
 
@@ -34,9 +34,9 @@ def test_runs_of_consecutive_atoms_are_compact_in_a_triclinic_box():
         lam = s.box.x2lamda(xs) * np.linalg.norm(s.box.h, axis=0)
         return np.array([np.ptp(lam[k:k + 32], axis=0).max() for k in range(0, len(xs) - 32, 32)])
 
-    e_box = extents(resident.spatial_order(x, s.box.lo, 3.0, box=s.box))
-    e_cart = extents(resident.hilbert_order(x, s.box.lo, 3.0))
-    e_z = extents(resident.morton_order(x, s.box.lo, 3.0))
+    e_box = extents(order.spatial_order(x, s.box.lo, 3.0, box=s.box))
+    e_cart = extents(order.hilbert_order(x, s.box.lo, 3.0))
+    e_z = extents(order.morton_order(x, s.box.lo, 3.0))
     assert e_box.max() < 30.0
     assert e_box.max() < e_cart.max() < e_z.max()
     assert e_box.mean() <= e_z.mean()
@@ -46,18 +46,18 @@ def test_spatial_order_groups_types_inside_stretches(monkeypatch):
     s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 2))
     x = S.wrap(s.box, s.x)
     monkeypatch.setenv("MDP_ORDER_GROUP", "1")
-    o = resident.spatial_order(x, s.box.lo, 3.0, group=s.type, chunk=96)
+    o = order.spatial_order(x, s.box.lo, 3.0, group=s.type, chunk=96)
     assert sorted(o) == list(range(s.n))
     t = s.type[o]
     for k in range(0, s.n, 96):
         assert np.all(np.diff(t[k:k + 96]) >= 0)     # sorted by type inside every stretch of the curve
     monkeypatch.setenv("MDP_ORDER_GROUP", "0")
-    o0 = resident.spatial_order(x, s.box.lo, 3.0, group=s.type)
-    assert np.array_equal(o0, resident.hilbert_order(x, s.box.lo, 3.0))
+    o0 = order.spatial_order(x, s.box.lo, 3.0, group=s.type)
+    assert np.array_equal(o0, order.hilbert_order(x, s.box.lo, 3.0))
 
 
 def test_empty_input():
-    assert len(resident.hilbert_order(np.zeros((0, 3)), np.zeros(3), 3.0)) == 0
+    assert len(order.hilbert_order(np.zeros((0, 3)), np.zeros(3), 3.0)) == 0
 
 
 def test_box_transforms_are_safe_in_rank_threads():
