@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic of ONE step of rank 0's sub-domain in an N-brick run, from two rocprofv3 --pmc passes (FETCH_SIZE,
+WRITE_SIZE; separate runs, KB units, gfx950 FETCH_SIZE counts 64 B per 128-B request and is doubled -- as
+MI355X_MICROARCH.md prescribes) over profiles/subdomain_step.py, whose last `steps` steps are rank 0 stepping alone:
+per path kernel the last steps x (launches per step) dispatches are summed and divided by the steps.
+usage: pmc_subdomain_entry.py <dir with pmc_fetch/ pmc_write/> <key e.g. rebomos:24x24x24:8> <kernel_source_sha> <steps>"""
+import collections, csv, glob, json, os, re, sys
+
+root, key, sha, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+PATH = ("rebo_centre_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_tile32_kernel",
+        "rebo_lj_gather_kernel", "rebo_gather_kernel")
+
+
+def short(k):
+    k = re.sub(r"^void ", "", k).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", k)
+
+
+def per_step(sub, counter):
+    rows = []
+    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                rows.append((int(r.get("Dispatch_Id", 0)), short(r["Kernel_Name"]), float(r["Counter_Value"])))
+    rows.sort()
+    by = collections.defaultdict(list)
+    for _, k, v in rows:
+        if any(k.startswith(p) for p in PATH):
+            by[k].append(v)
+    out = {}
+    # launches per step of a kernel in the final loop: found from the tail of the dispatch sequence
+    tail = [k for _, k, _ in rows if any(k.startswith(p) for p in PATH)]
+    for k, vals in by.items():
+        lps = max(1, round(sum(1 for t in tail[-steps * 8:] if t == k) / min(steps, max(1, len(tail) // 8))))
+        n = steps * lps
+        out[k] = (sum(vals[-n:]) / steps, lps)
+    return out
+
+
+fetch, write = per_step("pmc_fetch", "FETCH_SIZE"), per_step("pmc_write", "WRITE_SIZE")
+per, total = {}, 0.0
+for k in sorted(set(fetch) | set(write)):
+    fkb, lps = fetch.get(k, (0.0, 1))
+    wkb = write.get(k, (0.0, 1))[0]
+    b = (2.0 * fkb + wkb) * 1024.0
+    per[k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "hbm_bytes": b, "launches_per_step": lps}
+    total += b
+print(json.dumps({key: {"bytes_per_step": total, "kernel_source_sha": sha,
+                        "note": "rank 0's sub-domain of the N-brick run, all bricks set up on one GPU, rank 0 stepping alone "
+                                "(profiles/subdomain_step.py): (2*FETCH_SIZE + WRITE_SIZE)*1024 of the path kernels summed "
+                                "over the last steps and divided by them, separate rocprofv3 --pmc passes",
+                        "per_kernel": per}}, indent=1))

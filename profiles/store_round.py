@@ -27,8 +27,16 @@ for tag, main in ((RND + "_rebomos4m", True), (RND + "_aeam1m", True), (RND + "_
             if v.get("bytes_per_step", 0) > 0:
                 tab[k] = v
                 print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
-sd = os.path.join(G, RND + "_subdomain8")
-if os.path.exists(os.path.join(sd, "timeline.txt")):
-    with open(os.path.join(P, RND + "_subdomain8_step_timeline.txt"), "w") as f:
-        f.write(open(os.path.join(sd, "subdomain.json")).read() + "\n" + open(os.path.join(sd, "timeline.txt")).read())
+for n in (2, 4, 8):
+    sd = os.path.join(G, RND + "_subdomain%d" % n)
+    if os.path.exists(os.path.join(sd, "timeline.txt")):
+        with open(os.path.join(P, RND + "_subdomain%d_step_timeline.txt" % n), "w") as f:
+            f.write(open(os.path.join(sd, "subdomain.json")).read() + "\n" + open(os.path.join(sd, "timeline.txt")).read())
+    pe = os.path.join(sd, "pmc_entry.json")
+    if os.path.exists(pe) and os.path.getsize(pe) > 10:
+        ent = json.load(open(pe))
+        for k, v in ent.items():
+            if v.get("bytes_per_step", 0) > 0:
+                tab[k] = v
+                print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
 json.dump(tab, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)

@@ -5,7 +5,8 @@
 tiles, gather, integrator -- against the ghost positions of the last exchange while the other ranks wait.  What the
 timeline cannot show is the wire time of the all-to-all itself (5.1 MB per GPU and step), which the
 real run overlaps with the interior tiles.
-usage: rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/subdomain_step.py [nrep] [steps]"""
+usage: rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/subdomain_step.py [nrep] [steps] [bricks]
+(bricks = 2, 4 or 8: the per-rank sub-domain of the 2-, 4- and 8-GPU runs)"""
 import json
 import os
 import sys
@@ -22,6 +23,7 @@ from lammps_plugins_amd.host import capi, resident, system as S
 
 nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+world = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 pot = os.path.join(ROOT, "tests", "golden", "potentials", "MoS.REBO.set5b")
 s = S.replicate(S.rebomos_bulk_cell(), (nrep, nrep, nrep))
 out = {}
@@ -51,7 +53,7 @@ def rank_fn(r, make_tr):
         d.step(0, 0)                      # real exchanges again: the halo buffers hold current ghost positions
     tr.sh.barrier.wait()
     if r == 0:
-        out["reneighbor_wall_ms_8_bricks_sharing_one_gpu"] = round(tre * 1e3, 2)
+        out["reneighbor_wall_ms_bricks_sharing_one_gpu"] = round(tre * 1e3, 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):            # rank 0 alone; ghosts keep the positions of the last exchange
@@ -63,7 +65,7 @@ def rank_fn(r, make_tr):
             ctx.md_final_integrate()
         ctx.sync()
         dt = (time.perf_counter() - t0) / steps
-        out.update(atoms_total=s.n, nlocal=d.nlocal, self_ghosts=d.nself, remote_ghosts=d.nrecv, send_entries=d.nsend,
+        out.update(bricks=world, atoms_total=s.n, nlocal=d.nlocal, self_ghosts=d.nself, remote_ghosts=d.nrecv, send_entries=d.nsend,
                    halo_bytes_each_way=int(d.nsend * 24), pe_per_atom=th["pe"] / s.n, steps=steps,
                    ms_per_step_rank0_alone=round(dt * 1e3, 4))
     tr.sh.barrier.wait()
@@ -71,5 +73,5 @@ def rank_fn(r, make_tr):
     return None
 
 
-resident.run_ranks(8, rank_fn)
+resident.run_ranks(world, rank_fn)
 print(json.dumps(out))
