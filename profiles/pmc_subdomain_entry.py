@@ -17,24 +17,24 @@ def short(k):
 
 
 def per_step(sub, counter):
+    """sum per kernel over the window of the last `steps` steps (delimited by the force-only Lennard-Jones dispatches,
+    one per step), divided by the steps; also the launches per step seen in that window"""
     rows = []
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                rows.append((int(r.get("Dispatch_Id", 0)), short(r["Kernel_Name"]), float(r["Counter_Value"])))
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
     rows.sort()
-    by = collections.defaultdict(list)
-    for _, k, v in rows:
-        if any(k.startswith(p) for p in PATH):
-            by[k].append(v)
-    out = {}
-    # launches per step of a kernel in the final loop: found from the tail of the dispatch sequence
-    tail = [k for _, k, _ in rows if any(k.startswith(p) for p in PATH)]
-    for k, vals in by.items():
-        lps = max(1, round(sum(1 for t in tail[-steps * 8:] if t == k) / min(steps, max(1, len(tail) // 8))))
-        n = steps * lps
-        out[k] = (sum(vals[-n:]) / steps, lps)
-    return out
+    lj = [d for d, k, _ in rows if k.startswith("rebo_lj_tile") and "<false" in k]
+    if len(lj) <= steps:
+        return {}
+    start = lj[-steps - 1]                      # everything after the Lennard-Jones kernel of the step before the window
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for d, k, v in rows:
+        if d > start and any(k.startswith(p) for p in PATH):
+            tot[k] += v
+            cnt[k] += 1
+    return {k: (tot[k] / steps, cnt[k] / steps) for k in tot}
 
 
 fetch, write = per_step("pmc_fetch", "FETCH_SIZE"), per_step("pmc_write", "WRITE_SIZE")
