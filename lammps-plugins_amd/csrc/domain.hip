@@ -832,7 +832,7 @@ int mdp_md_moved_async(mdp_ctx *c, int *moved, int *dangerous)
   if (m || !c->nlocal || !c->neigh_set) return MDP_OK; // the caller rebuilds now: nothing to check until then
   h[0] = h[1] = 0;
   const double hard = 0.5 * c->cfg.skin;
-  double trig = hard - 0.1;
+  double trig = hard - 0.1 * mdp_margin_scale(c);
   if (trig < 0.5 * hard) trig = 0.5 * hard;
   const int grid = nblk(c->nlocal) < 1024 ? nblk(c->nlocal) : 1024;
   dd_moved_kernel<<<grid, 256, 0, st>>>(c->nlocal, trig * trig, hard * hard, c->xq.p, c->xhold.p, h);

@@ -343,6 +343,11 @@ struct mdp_ctx {
 
 int mdp_fail(mdp_ctx *c, int code, const char *fmt, ...);
 
+// The deferred displacement triggers are read one compute late, so they fire `margin` early.  The margins were
+// measured for the reference inputs' 1 fs step (0.1 A covers two steps at 50 A/ps); they scale with the time step of a
+// resident run (a 5 fs step moves atoms five times as far before the answer is read).
+inline double mdp_margin_scale(const mdp_ctx *c) { return c->md && c->cfg.dt > 0.001 ? c->cfg.dt / 0.001 : 1.0; }
+
 // Small device <-> host transfers (counts, totals, flag words) go through a pinned scratch buffer of the CONTEXT and
 // are complete on return: no asynchronous copy ever targets a stack variable or a std::vector (pageable memory goes
 // through the runtime's shared staging path, and a host that drives several contexts from several threads must not

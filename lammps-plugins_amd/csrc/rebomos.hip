@@ -3507,7 +3507,7 @@ static int rebomos_check_launch(mdp_ctx *c, const double trig)
   h[0] = h[1] = h[2] = h[3] = 0;
   // (pruned rows: their own, smaller trigger against the positions of the last pruning)
   const bool pr = c->prune_valid;
-  double ptrig = 0.5 * c->prune_buf - kPruneMargin;
+  double ptrig = 0.5 * c->prune_buf - kPruneMargin * mdp_margin_scale(c);
   if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
   const double phard = 0.5 * c->prune_buf;
   c->prune_check_epoch = c->prune_epoch;
@@ -3548,7 +3548,7 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
     c->stale_pending = false;
   }
   if (!stale) {
-    double trig = 0.5 * c->skin_inner - kStaleMargin;
+    double trig = 0.5 * c->skin_inner - kStaleMargin * mdp_margin_scale(c);
     if (trig < 0.25 * c->skin_inner) trig = 0.25 * c->skin_inner;
     MDP_TRY(rebomos_check_launch(c, trig));
     MDP_HIP(c, hipEventRecord(c->ev_stale, c->stream));
@@ -3691,7 +3691,7 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin)
   }
   c->computes_since_prune++;
   if (!c->ev_prune) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_prune, hipEventDisableTiming));
-  double ptrig = 0.5 * c->prune_buf - kPruneMargin;
+  double ptrig = 0.5 * c->prune_buf - kPruneMargin * mdp_margin_scale(c);
   if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
   const double phard = 0.5 * c->prune_buf;
   h[2] = h[3] = 0;

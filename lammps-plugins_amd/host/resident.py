@@ -302,6 +302,8 @@ class DeviceDomain:
         """blocking check, collective over the ranks: some owned atom moved more than skin/2 - margin"""
         t = self.ctx.md_thermo()
         need = t["maxdisp2"] > max(0.5 * self.skin - margin, 0.25 * self.skin) ** 2
+        if t["maxdisp2"] > (0.5 * self.skin) ** 2:
+            self.dangerous += 1              # (an atom of THIS rank was beyond half the skin already: a late build)
         return self.tr.any(need) if self.tr is not None else need
 
 
