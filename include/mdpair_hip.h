@@ -54,8 +54,9 @@ int mdp_device_count(void);
 int mdp_create(mdp_ctx **ctx, int device);
 int mdp_destroy(mdp_ctx *ctx);
 const char *mdp_last_error(const mdp_ctx *ctx);
-/* bytes of device memory the library holds in this process: what Pair::memory_usage() should add for the style's
- * device-side lists and work arrays (the reference reports the lists it holds: pair_rebomos.cpp:1113-1124) */
+/* bytes of device memory THIS context holds (ctx = NULL: all contexts of the process): what Pair::memory_usage() should
+ * add for the style's device-side lists and work arrays (the reference reports the lists it holds:
+ * pair_rebomos.cpp:1113-1124) */
 double mdp_device_bytes(const mdp_ctx *ctx);
 /* host arrays are staged through pinned buffers of the context by default.  With MDP_HOST_REGISTER=1 large arrays
  * (atom->x) are page-locked in place instead; a host that opts in must call this before it frees or re-allocates

@@ -645,8 +645,35 @@ int mdp_set_stream(mdp_ctx *c, void *s)
 
 double mdp_device_bytes(const mdp_ctx *c)
 {
-  (void) c;
-  return (double) mdp_device_bytes_counter();
+  // this context's share: the capacities of ITS buffers (every DevBuf member of mdp_ctx and of its MdpDomain); the
+  // process-wide total of all contexts is mdp_device_bytes_counter()
+  if (!c) return (double) mdp_device_bytes_counter().load();
+  const MdpDomain &D = c->dd;
+  const size_t parts[] = {
+      c->aeam_frho.bytes(), c->aeam_rhor.bytes(), c->aeam_z2r.bytes(), c->aeam_rhor_v4.bytes(),
+      c->aeam_rhor_d4.bytes(), c->aeam_z2r_v4.bytes(), c->aeam_z2r_d4.bytes(), c->aeam_pair_d8.bytes(),
+      c->aeam_rhor_ys.bytes(), c->aeam_z2r_ys.bytes(), c->aeam_maps.bytes(), c->xq.bytes(), c->xraw.bytes(),
+      c->host_perm.bytes(), c->host_stage.bytes(), c->tag.bytes(), c->type.bytes(), c->f.bytes(),
+      c->eatom.bytes(), c->vatom.bytes(), c->acc.bytes(), c->flags.bytes(), c->nb_off.bytes(), c->nb.bytes(),
+      c->cand_cnt.bytes(), c->cand_off.bytes(), c->cand.bytes(), c->lj_off.bytes(), c->lj_cnt.bytes(),
+      c->lj.bytes(), c->cl_flag.bytes(), c->cl_pos.bytes(), c->cl_order.bytes(), c->lj_split.bytes(),
+      c->tu.bytes(), c->tmask.bytes(), c->tmask32.bytes(), c->lj16_in.bytes(), c->lj_len_in.bytes(),
+      c->lj_split_in.bytes(), c->xhold_prune.bytes(), c->tile_nu.bytes(), c->tile_flag.bytes(),
+      c->lj16.bytes(), c->is_center.bytes(), c->class_list.bytes(), c->class_count.bytes(), c->pk_cand.bytes(),
+      c->amask.bytes(), c->rev.bytes(), c->rev16.bytes(), c->ovf.bytes(), c->xhold_all.bytes(),
+      c->fnbr.bytes(), c->fown.bytes(), c->vslot.bytes(), c->scan_tmp.bytes(), c->rho.bytes(), c->fp.bytes(),
+      c->ang_list.bytes(), c->ang_count.bytes(), c->v.bytes(), c->xhold.bytes(), c->rmass.bytes(),
+      c->ghost_owner.bytes(), c->ghost_shift.bytes(), c->mass_type.bytes(), c->cell_of.bytes(),
+      c->cell_perm.bytes(), c->cell_start.bytes(), c->sort_keys_a.bytes(), c->sort_keys_b.bytes(),
+      c->sort_vals_b.bytes(), c->nb_cnt.bytes(),
+      D.dest.bytes(), D.counters.bytes(), D.idx_a.bytes(), D.idx_b.bytes(), D.ent_atom.bytes(),
+      D.ent_code.bytes(), D.ent_cnt.bytes(), D.ent_off.bytes(), D.sendlist.bytes(), D.type_tmp.bytes(),
+      D.tag_tmp.bytes(), D.key_a.bytes(), D.key_b.bytes(), D.sendshift.bytes(), D.v_tmp.bytes(),
+      D.xq_tmp.bytes(), D.sbuf.bytes(), D.rbuf.bytes(), D.abuf.bytes(), D.cnt_dev.bytes(),
+  };
+  double sum = 0.0;
+  for (const size_t b : parts) sum += (double) b;
+  return sum;
 }
 
 int mdp_host_release(mdp_ctx *c, const void *ptr)

@@ -144,3 +144,21 @@ def test_tile_lists_against_the_per_cluster_path_and_large_union_classes():
         assert np.abs(e - e0).max() < 1e-10
         assert th["pe"] == pytest.approx(th0["pe"], rel=1e-12)
         assert np.allclose(th["virial"], th0["virial"], rtol=1e-10, atol=1e-7)
+
+
+def test_device_bytes_are_reported_per_context():
+    """Pair::memory_usage() of a style must report ITS device memory, not every context's in the process"""
+    L = capi.lib()
+    L.mdp_device_bytes.restype = capi.C.c_double
+    s_small = S.rebomos_bulk_cell()
+    s_big = S.replicate(S.rebomos_bulk_cell(), (4, 4, 2))
+    ctx1, d1 = _domain(s_small, True)
+    ctx2, d2 = _domain(s_big, True)
+    d1.build_neighbors()
+    d2.build_neighbors()
+    b1, b2, tot = ctx1.device_bytes(), ctx2.device_bytes(), float(L.mdp_device_bytes(None))
+    assert 0 < b1 < b2                                 # the larger system holds more
+    assert tot >= b1 + b2 - 1.0                        # and the process total covers both
+    ctx1.close()
+    assert ctx2.device_bytes() == b2
+    ctx2.close()
