@@ -203,3 +203,64 @@ def test_two_ranks_on_one_gpu_match_single_domain(style):
     assert np.abs(x2 - x1).max() < 1e-9     # 25 steps of identical dynamics
     assert np.abs(f2 - f1).max() < 1e-7
     ctx.close()
+
+
+def _worker_rccl_self(port, style, q):
+    """the DEFAULT transport of bench.py -- resident.Transport on the "nccl" backend (RCCL), device buffers straight into
+    all_to_all_single, the exchange asynchronous behind the interior centres -- with a one-rank process group:
+    `self_remote` makes every periodic self-image a remote ghost that travels through the all-to-all to the rank itself"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import conftest  # noqa: F401
+    from lammps_plugins_amd.host import resident
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s, v0 = _build(style)
+        v0 = v0 + np.array([150.0, 40.0, -60.0])
+        out = []
+        for remote in (False, True):
+            ctx, st, cutghost, skin, map_, keep = _setup_ctx(style)
+            tr = resident.Transport(dist, dev, stage_host=False) if remote else None
+            dom = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0, transport=tr, self_remote=remote)
+            if remote:
+                assert dom.nself == 0 and dom.nrecv > 0 and dom.nsend == dom.nrecv
+            dom.compute(1, 1)
+            rows = [dom.thermo()]
+            for k in range(1, 25):
+                dom.step(0, 0, rebuild=k % 4 == 0)
+            dom.compute(1, 1)
+            rows.append(dom.thermo())
+            got = ctx.md_download(dom.nlocal, want=("x", "f"))
+            order = np.argsort(dom.tags_local)
+            out.append((got["x"][order], got["f"][order], [[r["ke"], r["pe"], *r["virial"]] for r in rows], dom.nrecv))
+            ctx.close()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_default_rccl_transport_with_one_rank(style):
+    """what the N-GPU bench line runs per step (pack -> all_to_all_single on RCCL, asynchronous || interior centres ->
+    wait -> unpack; counts through all_gather; migration and border records at every reneighboring), on one GPU: the
+    trajectory must equal the plain one-GPU run"""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_worker_rccl_self, args=(_free_port(), style, q))
+    p.start()
+    (xp, fp, rp, _), (xr, fr, rr, nrecv) = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and nrecv > 0
+    s, _ = _build(style)
+    dx = xr - xp
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-9 and np.abs(fr - fp).max() < 1e-7
+    for k in range(2):
+        assert rr[k][1] == pytest.approx(rp[k][1], rel=1e-10)
+        assert rr[k][0] == pytest.approx(rp[k][0], rel=1e-9, abs=1e-12)
