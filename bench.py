@@ -287,7 +287,7 @@ def run_job(E, job, par):
         tr = resident.NativeTransport(world, rank, bcast)
     else:
         tr = resident.Transport(dist, dev, stage_host)
-    dom = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr)
+    dom = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr, self_remote=par.get("self_remote", False))
     dom.compute(1, 1)
     th = dom.thermo()
     pe0 = th["pe"]
@@ -413,7 +413,8 @@ def run_job(E, job, par):
         "ns_per_day": round(job["steps"] / elapsed * 0.001 * 86.4, 4),
         "config": {"workload": wname, "atoms": s.n, "style": wl, "parallelism": f"spatial-dd{world}",
                    "transport": (("rccl (library, ncclSend/ncclRecv)" if native else "rccl (torch.distributed all_to_all)")
-                                 if not stage_host else par["backend"] + "-staged (rehearsal)") if world > 1 else "none (one GPU)",
+                                 if not stage_host else par["backend"] + "-staged (rehearsal)") + (" to the rank itself (one-rank rehearsal)" if par.get("self_remote") else "")
+                   if dist is not None else "none (one GPU)",
                    "initial_temp_K": job["temp"], "skin": skin, "thermo_every": thermo_every,
                    "displacement_check": "every step, deferred on-device flag" if dist is None
                    else f"every {check_every} steps, collective",
@@ -441,7 +442,7 @@ def run_job(E, job, par):
                               "frac": round(flops_path / FP64_PEAK_TFLOPS, 5),
                               "whole_step_frac": round(flops_step / FP64_PEAK_TFLOPS, 5)}},
     }
-    if world > 1:
+    if dist is not None:
         # per-rank shape of the decomposition (log.rebomos-bulk.4:72-75 prints the same per-rank counts)
         mine = torch.tensor([dom.nlocal, dom.nself, dom.nrecv, dom.nsend], dtype=torch.int64, device="cpu" if stage_host else dev)
         rows = [torch.empty_like(mine) for _ in range(world)]
@@ -478,6 +479,11 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))      # the parent has made no GPU call; the children are fresh processes
+    # stdout carries ONE line, the result.  Libraries print there too (RCCL writes a version banner to stdout when a
+    # communicator comes up), so file descriptor 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -510,7 +516,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, rccl_ranks = None, 1
-    if world > 1:
+    # MDP_BENCH_SELF_REMOTE=1 (rehearsal on one GPU): a ONE-rank run takes the N>1 code path -- process group on RCCL,
+    # collective displacement checks, per-rank gathers -- and every periodic self-image travels through the all-to-all
+    # to the rank itself.  The line says so (config.transport); it is not the one-GPU headline.
+    self_remote = world == 1 and os.environ.get("MDP_BENCH_SELF_REMOTE", "0") not in ("", "0")
+    if world > 1 or self_remote:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if stage_host:
@@ -527,13 +537,13 @@ def main():
     # process group then only distributes the communicator id)
     native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "torch") == "native" and not stage_host
     par = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, dev=dev, stage_host=stage_host, native=native,
-               backend=backend)
+               backend=backend, self_remote=self_remote)
 
     job = dict(workload=args.workload, replicate=list(args.replicate), temp=args.temp, steps=args.steps, warmup=args.warmup,
                thermo_every=THERMO_EVERY[args.workload] if args.thermo is None else args.thermo, check_every=args.check_every)
     out, pieces = run_job(E, job, par)
     out["config"]["rccl_ranks"] = rccl_ranks
-    if rank == 0 and world == 1 and not args.no_host_mode:
+    if rank == 0 and world == 1 and dist is None and not args.no_host_mode:
         try:
             hm = host_mode_rate(E, pieces["s"], args.workload, pieces["pot"], pieces["skin"], pieces["cutghost"])
             out["host_mode_ms_per_step"] = round(hm, 3)
@@ -543,7 +553,7 @@ def main():
     pieces = None
 
     # ---- secondary block of the default one-GPU run: what the cold-start headline does not show ----
-    if world == 1 and not custom and not args.no_secondary:
+    if world == 1 and dist is None and not custom and not args.no_secondary:
         sec = {}
         try:
             hot = dict(job, temp=300.0, steps=max(200, args.steps), warmup=20)
@@ -578,7 +588,10 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         attach_cpu_baseline(out, args.workload, 8.0)
     if rank == 0:
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,3 +18,11 @@ run aeam1 1 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 
 run aeam4 4 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 5 --no-cpu-baseline
 # what must NOT produce a result: more RCCL ranks than GPUs
 timeout -k 10 200 python3 bench.py --gpus 2 --replicate 4 4 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/refuse.json 2> $O/refuse.err; echo "refuse rc=$? (non-zero expected), stdout bytes: $(wc -c < $O/refuse.json)"
+# the N>1 code path of bench.py over RCCL itself with ONE rank: every periodic self-image travels through the transport
+# to the rank itself (torch.distributed all_to_all on the "nccl" backend, then the library's ncclSend/ncclRecv)
+for tr in torch native; do
+  MDP_BENCH_SELF_REMOTE=1 MDP_BENCH_TRANSPORT=$tr timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --replicate 12 12 12 --temp 300 --steps 60 --warmup 5 --no-cpu-baseline > $O/self_$tr.json 2> $O/self_$tr.err
+  echo "self_$tr rc=$? stdout lines: $(wc -l < $O/self_$tr.json)"; python3 -c "
+import json;d=json.load(open('$O/self_$tr.json'));c=d['config'];print('  ', d['value'], d['ms_per_step'], c['transport'], c['pe_per_atom_end_eV'], c['temp_end_K'])"
+done
+
