@@ -462,3 +462,24 @@ def test_slab_with_a_non_periodic_dimension(oracle):
     lam[:, 2] = 0.0                                            # (no periodic image in z to forgive)
     dx -= S.mul_upper(lam, box.h)
     assert np.abs(dx).max() < 1e-8 and np.abs(v8 - v1).max() < 1e-7
+
+
+def test_device_order_is_element_sorted_inside_every_run_of_32_atoms():
+    """rebomos: after the device's reneighboring the owned atoms lie along the Hilbert curve of the brick, and inside
+    every run of 32 consecutive atoms (one tile of the Lennard-Jones lists) the Mo atoms come first -- two-atom rows
+    are then element-pure wherever the run allows, and the rows sharing a wave pad alike.  The runs themselves stay
+    compact blobs of the curve."""
+    s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (3, 3, 2)), 0.05, seed=2)
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    t = ctx.md_download_int("type", d.nlocal)
+    x = ctx.md_download(d.nlocal, want=("x",))["x"]
+    nrun = d.nlocal // 32
+    for r in range(nrun):
+        tt = t[32 * r:32 * r + 32]
+        assert np.all(np.diff(tt) >= 0)                       # type 1 (Mo) first, then type 2 (S)
+    ext = np.array([np.ptp(x[32 * r:32 * r + 32], axis=0).max() for r in range(nrun)])
+    assert np.median(ext) < 12.0                              # 32 atoms of MoS2 fill ~ (8.7 A)^3: compact runs
+    mixed = sum(1 for k in range(d.nlocal // 2) if t[2 * k] != t[2 * k + 1])
+    assert mixed <= nrun                                      # at most one mixed two-atom row per run
+    ctx.close()
