@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Tile-list variants (resident mode, two atom types, force-only steps).  Same scheme as the REBO-MoS
+// Tile-list variants (resident mode and device-built lists).  Same scheme as the REBO-MoS
 // Lennard-Jones kernel (csrc/rebomos.hip): one workgroup = one tile of 16 two-atom clusters; the UNION of their
 // neighbourhoods is gathered once into LDS, the cluster rows are 16-bit indices into it, segmented by the
 // neighbour's type (so every table selector is a choice between two scalars by the cluster atom's type) and
@@ -201,8 +201,45 @@ template <int TJ, bool TRANSPOSED> __device__ __forceinline__ TilePar tile_par(c
   return q;
 }
 
+// More than two atom types (MULTI): the tile lists keep their two segments -- neighbours of type 0 | neighbours of
+// any other type -- and the kernels read the type of an entry of the second segment from LDS next to its
+// coordinates; the per-pair-type parameters of all ntypes^2 pairs sit in LDS as well (the two-type kernels select
+// them from scalars by the cluster atom's type).  Layout behind the union's records:
+//   double cut[P], rdr[P]; int nr[P], trho[P], tz2r[P]  (P = MAXT^2)   then   int type[capL]
+constexpr int kParN = MDP_AEAM_MAXT * MDP_AEAM_MAXT;
+constexpr size_t kParBytes = (size_t) kParN * (2 * sizeof(double) + 3 * sizeof(int));
+struct ParLds {
+  const double *cut, *rdr;
+  const int *nr, *trho, *tz2r;
+};
+__device__ __forceinline__ ParLds par_fill(const AeamDev &A, double *base, const int tid)
+{
+  double *cut = base, *rdr = base + kParN;
+  int *nr = reinterpret_cast<int *>(base + 2 * kParN), *trho = nr + kParN, *tz2r = trho + kParN;
+  const int np = A.ntypes * A.ntypes;
+  if (tid < np) {
+    cut[tid] = A.cut[tid];
+    rdr[tid] = A.rdr[tid];
+    nr[tid] = A.nr[tid];
+    trho[tid] = A.t2rhor[tid];
+    tz2r[tid] = A.t2z2r[tid];
+  }
+  return ParLds{cut, rdr, nr, trho, tz2r};
+}
+__device__ __forceinline__ TilePar par_at(const ParLds &T, const int pt)
+{
+  TilePar q;
+  q.cut = T.cut[pt];
+  q.rdr = T.rdr[pt];
+  q.nr = T.nr[pt];
+  q.trho = T.trho[pt];
+  q.tz2r = T.tz2r[pt];
+  q.pair = pt;
+  return q;
+}
+
 // pass 1, metal centres (pair_aeam.cpp:174-205)
-template <int CL>
+template <int CL, bool MULTI>
 __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const int cap, const int capL,
     const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
@@ -210,7 +247,7 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     const unsigned short *__restrict__ lj16, double *__restrict__ rho)
 {
   constexpr int L = 16, SK = 3;
-  extern __shared__ double s_pos[]; // [capL][3]
+  extern __shared__ double s_pos[]; // [capL][3]  (MULTI: then the parameter block and type[capL])
   const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
   const int t = xcd_contiguous(blockIdx.x, gridDim.x);
   const int kc = t * kTile + tid / L;
@@ -227,6 +264,12 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
   double4 xa[CL];
 #pragma unroll
   for (int c = 0; c < CL; c++) xa[c] = xq[have && kc * CL + c < nlocal ? kc * CL + c : nlocal - 1];
+  ParLds T = {};
+  int *s_ty = nullptr;
+  if (MULTI) {
+    T = par_fill(A, s_pos + 3 * (size_t) capL, tid);
+    s_ty = reinterpret_cast<int *>(reinterpret_cast<char *>(s_pos + 3 * (size_t) capL) + kParBytes);
+  }
   {
     double4 sv[SK];
 #pragma unroll
@@ -238,6 +281,7 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
         s_pos[3 * u] = sv[k].x;
         s_pos[3 * u + 1] = sv[k].y;
         s_pos[3 * u + 2] = sv[k].z;
+        if (MULTI) s_ty[u] = (int) sv[k].w;
       }
     }
   }
@@ -246,11 +290,13 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     s_pos[3 * u] = v.x;
     s_pos[3 * u + 1] = v.y;
     s_pos[3 * u + 2] = v.z;
+    if (MULTI) s_ty[u] = (int) v.w;
   }
   if (tid == 0) {
     s_pos[3 * nU] = 1.0e30;
     s_pos[3 * nU + 1] = 0.0;
     s_pos[3 * nU + 2] = 0.0;
+    if (MULTI) s_ty[nU] = 0;
   }
   int ta[CL];
   bool metal[CL];
@@ -268,13 +314,18 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
     const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
     TilePar q[CL];
 #pragma unroll
-    for (int c = 0; c < CL; c++) q[c] = tile_par<TJ, false>(A, ta[c]);
+    for (int c = 0; c < CL; c++) q[c] = MULTI ? par_at(T, ta[c] * A.ntypes) : tile_par<TJ, false>(A, ta[c]);
     int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is requested one trip ahead
     for (int k = kb + s; k < ke; k += L) {
       const int li = li_next;
       li_next = k + L < ke ? (int) row[k + L] : nU;
       const double *p3 = s_pos + 3 * li;
       const double xj = p3[0], yj = p3[1], zj = p3[2];
+      if (MULTI && TJ == 1) { // the entry's own type
+        const int tj = s_ty[li];
+#pragma unroll
+        for (int c = 0; c < CL; c++) q[c] = par_at(T, ta[c] * A.ntypes + tj);
+      }
 #pragma unroll
       for (int c = 0; c < CL; c++) {
         const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
@@ -306,7 +357,7 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
 // aeam_force_kernel.  LDS record of a union member: x y z q with q = Fptmp*F' of metal neighbours, 0 otherwise.
 // EV: also the pair energy (global and per atom) and the global virial of this rank's own visits, tallied exactly
 // as aeam_force_kernel<.., true> does (ev_tally of the visit i = a: pair_aeam.cpp:386-393).
-template <int CL, bool EV>
+template <int CL, bool EV, bool MULTI>
 __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const double *__restrict__ fp,
     const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
@@ -338,6 +389,12 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     xa[c] = xq[ia];
     qa[c] = fp[ia];
   }
+  ParLds T = {};
+  int *s_ty = nullptr;
+  if (MULTI) {
+    T = par_fill(A, s_rec + 4 * (size_t) capL, tid);
+    s_ty = reinterpret_cast<int *>(reinterpret_cast<char *>(s_rec + 4 * (size_t) capL) + kParBytes);
+  }
   {
     double4 sv[SK];
     double sq[SK];
@@ -350,15 +407,24 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
 #pragma unroll
     for (int k = 0; k < SK; k++) {
       const int u = tid + 256 * k;
-      if (u < nU) s4[u] = make_double4(sv[k].x, sv[k].y, sv[k].z, (u < N0 ? 0 : 1) < A.nnonangular ? sq[k] : 0.0);
+      if (u < nU) {
+        const int tu_ = MULTI ? (int) sv[k].w : (u < N0 ? 0 : 1);
+        s4[u] = make_double4(sv[k].x, sv[k].y, sv[k].z, tu_ < A.nnonangular ? sq[k] : 0.0);
+        if (MULTI) s_ty[u] = tu_;
+      }
     }
   }
   for (int u = tid + 256 * SK; u < nU; u += 256) {
     const int j = mem[u];
     const double4 v = xq[j];
-    s4[u] = make_double4(v.x, v.y, v.z, (u < N0 ? 0 : 1) < A.nnonangular ? fp[j] : 0.0);
+    const int tu_ = MULTI ? (int) v.w : (u < N0 ? 0 : 1);
+    s4[u] = make_double4(v.x, v.y, v.z, tu_ < A.nnonangular ? fp[j] : 0.0);
+    if (MULTI) s_ty[u] = tu_;
   }
-  if (tid == 0) s4[nU] = make_double4(1.0e30, 0.0, 0.0, 0.0);
+  if (tid == 0) {
+    s4[nU] = make_double4(1.0e30, 0.0, 0.0, 0.0);
+    if (MULTI) s_ty[nU] = 0;
+  }
   int ta[CL];
   bool real[CL];
   double fx[CL], fy[CL], fz[CL], ea[CL];
@@ -378,8 +444,8 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     TilePar qA[CL], qJ[CL];
 #pragma unroll
     for (int c = 0; c < CL; c++) {
-      qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
-      qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
+      qA[c] = MULTI ? par_at(T, ta[c] * A.ntypes) : tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
+      qJ[c] = MULTI ? par_at(T, ta[c]) : tile_par<TJ, true>(A, ta[c]);             // visit (i = j, a)
     }
     // Per trip: the geometry of all cluster atoms first, then the records of their visits (a -> j) requested
     // together (each under its own predicate), then the arithmetic: the round trips of the cluster atoms overlap.
@@ -387,6 +453,15 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     int li_next = kb + s < ke ? (int) row[kb + s] : nU; // the next entry's index is requested one trip ahead
     for (int k = kb + s; k < ke; k += L) {
       const double4 xj = s4[li_next];
+      int tj = TJ;
+      if (MULTI && TJ == 1) { // the entry's own type
+        tj = s_ty[li_next];
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          qA[c] = par_at(T, ta[c] * A.ntypes + tj);
+          qJ[c] = par_at(T, tj * A.ntypes + ta[c]);
+        }
+      }
       li_next = k + L < ke ? (int) row[k + L] : nU;
       double dx[CL], dy[CL], dz[CL], recip[CL], r[CL], pfa[CL];
       bool in_a[CL], in_j[CL];
@@ -428,7 +503,7 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
         }
         if (in_j[c]) {
           const double qj = xj.w;
-          if (TJ == ta[c] && in_a[c]) { // same element: both visits read the same table rows
+          if (tj == ta[c] && in_a[c]) { // same element: both visits read the same table rows
             fpair_j = fpair_a + (qa[c] - qj) * dfa * recip[c];
           } else {
             double pf;
@@ -1422,6 +1497,20 @@ inline int nblk(long long n, int per) { return (int) ((n + per - 1) / per); }
 
 } // namespace
 
+// largest cutoff between the two classes of the tile lists (type 0 | every other type), either visit of a pair
+static void aeam_class_cuts(const mdp_ctx *c, double out[4])
+{
+  const int nt = c->aeam.ntypes;
+  for (int k = 0; k < 4; k++) out[k] = 0.0;
+  for (int ti = 0; ti < nt; ti++)
+    for (int tj = 0; tj < nt; tj++) {
+      const double a = c->aeam.cut[ti * nt + tj], b = c->aeam.cut[tj * nt + ti];
+      const double m = a > b ? a : b;
+      const int k = (ti > 1 ? 1 : ti) * 2 + (tj > 1 ? 1 : tj);
+      if (m > out[k]) out[k] = m;
+    }
+}
+
 int mdp_aeam_prepare(mdp_ctx *c)
 {
   if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
@@ -1436,18 +1525,14 @@ int mdp_aeam_prepare(mdp_ctx *c)
     ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof(int), &c->h_ang_count));
-  // resident mode, two atom types: tile lists next to the CSR list (which the angular kernels and the steps
+  // resident mode: tile lists next to the CSR list (which the angular kernels and the steps
   // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
   c->aeam_tiled = false;
   const char *e = getenv("MDP_AEAM_TILE");
-  if ((c->md || c->aeam_device_lists) && c->aeam.ntypes == 2 && c->nlocal > 0 && !(e && atoi(e) == 0)) {
+  if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0)) {
     double cutsq[4];
-    for (int ti = 0; ti < 2; ti++)
-      for (int tj = 0; tj < 2; tj++) { // either visit of the pair may need it
-        const double a = c->aeam.cut[ti * 2 + tj], b = c->aeam.cut[tj * 2 + ti];
-        const double rc = (a > b ? a : b) + c->cfg.skin;
-        cutsq[ti * 2 + tj] = rc * rc;
-      }
+    aeam_class_cuts(c, cutsq); // either visit of the pair may need it
+    for (int k = 0; k < 4; k++) cutsq[k] = (cutsq[k] + c->cfg.skin) * (cutsq[k] + c->cfg.skin);
     const char *ecl = getenv("MDP_AEAM_CLUSTER");
     // two atoms per 16-lane group: the LDS read of a neighbour and its row index serve both, and the union staging
     // is amortised over 32 atoms (with unions sorted by atom index this beats one atom per group by 11 % at 863 K)
@@ -1471,6 +1556,7 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
   const char *epers = getenv("MDP_AEAM_PERSIST"); // unset: decided here; 0: never; 1: whenever a window fits
   if (epers && atoi(epers) == 0) return MDP_OK;
   if (c->tile_rowmax <= 0) return MDP_OK;
+  if (c->aeam.ntypes != 2) return MDP_OK; // (its cold passes select between the parameters of two types)
   // the LDS-resident table is the (0,0) pair's: with many atoms of the other type most pairs would take the cold
   // pass (rows from global memory, behind the hot pass) and the gather kernels are the better choice
   if (!epers && (double) c->h_ang_count > 0.1 * (double) c->nlocal) return MDP_OK;
@@ -1593,11 +1679,7 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
     // resident runs walk rows pruned to the pairs within reach right now (tile_prune_kernel in rebomos.hip): a third
     // of the entries of a list built with 1 A of skin on a 6.5 A cutoff are skin
     double cut[4];
-    for (int ti = 0; ti < 2; ti++)
-      for (int tj = 0; tj < 2; tj++) { // either visit of the pair may need the entry
-        const double a = c->aeam.cut[ti * 2 + tj], b = c->aeam.cut[tj * 2 + ti];
-        cut[ti * 2 + tj] = a > b ? a : b;
-      }
+    aeam_class_cuts(c, cut); // either visit of the pair may need the entry
     MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin));
   } else
     c->prune_valid = false;
@@ -1607,19 +1689,25 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   if (persistent) {
   } else if (nlocal && c->aeam_tiled) {
     const int capL = (c->tile_maxu + 1 + 7) & ~7;
-    const size_t lds = (size_t) capL * 3 * sizeof(double);
-#define MDP_ATD(CLV)                                                                                                 \
+    const bool multi = c->aeam.ntypes != 2; // per-entry types and an LDS parameter block (see par_fill)
+    const size_t lds = (size_t) capL * 3 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
+#define MDP_ATD(CLV, MV)                                                                                             \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_density_kernel<CLV>,                                    \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_density_kernel<CLV, MV>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_density_kernel<CLV><<<c->ntile, 256, lds, st>>>(                                                        \
+    aeam_tile_density_kernel<CLV, MV><<<c->ntile, 256, lds, st>>>(                                                    \
         c->aeam, nlocal, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,                    \
         c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
         c->prune_valid ? c->lj16_in.p : c->lj16.p, c->rho.p);                                                         \
   } while (0)
-    if (c->aeam_cl == 1) MDP_ATD(1);
-    else MDP_ATD(2);
+    if (multi) {
+      if (c->aeam_cl == 1) MDP_ATD(1, true);
+      else MDP_ATD(2, true);
+    } else {
+      if (c->aeam_cl == 1) MDP_ATD(1, false);
+      else MDP_ATD(2, false);
+    }
 #undef MDP_ATD
   } else if (nlocal) {
     const int grid = nblk(nlocal, 256 / AE_L);
@@ -1668,25 +1756,32 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
   if (persistent) {
   } else if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
     const int capL = (c->tile_maxu + 1 + 7) & ~7;
-    const size_t lds = (size_t) capL * 4 * sizeof(double);
+    const bool multi = c->aeam.ntypes != 2;
+    const size_t lds = (size_t) capL * 4 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
     const bool ev = eflag || vflag;
-#define MDP_ATF(CLV, EVV)                                                                                            \
+#define MDP_ATF(CLV, EVV, MV)                                                                                        \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV, EVV>,                                 \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV, EVV, MV>,                             \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_force_kernel<CLV, EVV><<<c->ntile, 256, lds, st>>>(                                                     \
+    aeam_tile_force_kernel<CLV, EVV, MV><<<c->ntile, 256, lds, st>>>(                                                 \
         c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,           \
         c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
         c->prune_valid ? c->lj16_in.p : c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                       \
   } while (0)
+#define MDP_ATF_M(CLV, EVV)                                                                                          \
+  do {                                                                                                                \
+    if (multi) MDP_ATF(CLV, EVV, true);                                                                               \
+    else MDP_ATF(CLV, EVV, false);                                                                                    \
+  } while (0)
     if (c->aeam_cl == 1) {
-      if (ev) MDP_ATF(1, true);
-      else MDP_ATF(1, false);
+      if (ev) MDP_ATF_M(1, true);
+      else MDP_ATF_M(1, false);
     } else {
-      if (ev) MDP_ATF(2, true);
-      else MDP_ATF(2, false);
+      if (ev) MDP_ATF_M(2, true);
+      else MDP_ATF_M(2, false);
     }
+#undef MDP_ATF_M
 #undef MDP_ATF
   } else if (nlocal) {
     if (!c->csr_full) { // first per-atom-virial step of a tiled run: build the rows of the metal atoms now (and from now on)

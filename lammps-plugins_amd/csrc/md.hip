@@ -394,12 +394,12 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
     if (!c->have_aeam) return mdp_fail(c, MDP_ESTATE, "aeam tables not set");
     const int nt = c->aeam.ntypes;
     ct.ne = nt;
-    // With tile lists (resident mode, two types) the metal atoms never touch the CSR list: force-only AND energy /
+    // With tile lists (resident mode) the metal atoms never touch the CSR list: force-only AND energy /
     // virial steps run the tile kernels.  Only the angular centres (0.75 % in sample.in) read it, so only their
     // rows are built -- a quarter of the reneighboring time at 1 M atoms.  A per-atom-virial step (CSR kernels)
     // asks for the full list (c->csr_want_full) and gets it rebuilt on the spot.
     const char *e = getenv("MDP_AEAM_TILE");
-    const bool tiles = (c->md || c->aeam_device_lists) && nt == 2 && !(e && atoi(e) == 0);
+    const bool tiles = (c->md || c->aeam_device_lists) && !(e && atoi(e) == 0);
     ct.min_type = (tiles && !c->csr_want_full && !c->cfg.master_list) ? c->aeam.nnonangular : 0;
     c->csr_full = ct.min_type == 0;
     for (int a = 0; a < nt; a++)

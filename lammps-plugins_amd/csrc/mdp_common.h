@@ -305,7 +305,7 @@ struct mdp_ctx {
   DevBuf<int> ang_count;
   int h_ang_count = 0;
   int aeam_cl = 1;                // atoms per cluster of the AEAM tile lists
-  bool aeam_tiled = false;        // resident mode, two types: tile lists (tu / lj16 ...) serve the force-only steps
+  bool aeam_tiled = false;        // resident mode: tile lists (tu / lj16 ...) serve the force-only steps
   bool aeam_device_lists = false; // host mode: lists built on the device from the positions (as rebomos), host list unused
   bool skin_set = false;
   bool csr_full = true;           // the CSR list holds rows for every owned atom (false: angular centres only)
@@ -384,7 +384,7 @@ int mdp_rebomos_repack(mdp_ctx *c);
 int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4]);                 // (re-)prune the tile rows from the current positions
 void mdp_prune_adapt(mdp_ctx *c, double buf_max, bool fired);
 int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], double skin);      // trigger + pruning for a style without its own displacement check
-int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok); // tile lists (cl atoms per cluster) for a two-type style; needs the bin grid
+int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok); // tile lists (cl atoms per cluster), two classes of atoms (type 0 | others); needs the bin grid
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag);
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag);

@@ -1729,8 +1729,9 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
     const int ia = t * NA + tid;
     bool valid = ia < nlocal;
     const double4 xa = xq[valid ? ia : (nlocal > 0 ? nlocal - 1 : 0)];
-    const int ta = (int) xa.w;
+    int ta = (int) xa.w;
     if (ta < 0) valid = false; // NULL-mapped atom: lists nothing
+    ta = ta > 1 ? 1 : ta;      // two classes: type 0 | every other type (a style with more types sorts them out itself)
     s_xa[tid] = xa;
     s_cut[tid][0] = valid ? P.ljlist_cutsq[ta * 2 + 0] : -1.0;
     s_cut[tid][1] = valid ? P.ljlist_cutsq[ta * 2 + 1] : -1.0;
@@ -1805,6 +1806,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
         j = perm[s_pb[lo] + gi - s_off[lo]];
         const double4 xj = xq[j];
         tj = (int) xj.w;
+        tj = tj > 1 ? 1 : tj;
         if (tj >= 0) {
 #pragma unroll 8
           for (int a = 0; a < NA; a++) {
@@ -2089,6 +2091,7 @@ __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, 
       real[c] = false;
       ta[c] = 0;
     }
+    ta[c] = ta[c] > 1 ? 1 : ta[c]; // (the two classes of tile_scan_kernel)
   }
   __syncthreads();
   const unsigned long long below = (1ull << s) - 1ull;

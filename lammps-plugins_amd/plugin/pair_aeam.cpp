@@ -176,10 +176,10 @@ void PairAEAM::init_style()
   cut_el = const_cast<double *>(tables.cut);
   open_device();
   if (mdp_aeam_set_tables(dev, &tables) != MDP_OK) fail_one(MDP_EINVAL, "table upload");
-  // two atom types (the alloy the style exists for): lists built on the device; MDP_AEAM_HOST_LIST=1 streams the
-  // host's list instead, as do systems with more types
+  // lists built on the device from the positions (the host's list is only checked); MDP_AEAM_HOST_LIST=1 streams
+  // the host's list instead
   const char *ehl = getenv("MDP_AEAM_HOST_LIST");
-  device_lists = atom->ntypes == 2 && !(ehl && atoi(ehl) != 0);
+  device_lists = !(ehl && atoi(ehl) != 0);
   if (mdp_aeam_device_lists(dev, device_lists ? 1 : 0) != MDP_OK) fail_one(MDP_EINVAL, "list mode");
 
   neighbor->add_request(this, NeighConst::REQ_FULL);

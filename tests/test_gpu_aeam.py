@@ -7,6 +7,7 @@ import pytest
 
 from conftest import POT_AEAM
 from lammps_plugins_amd.host import capi, resident, system as S
+import aeam_five
 import hostplan
 import mdref
 import oracle_bindings as ob
@@ -72,14 +73,14 @@ def test_host_mode_matches_oracle(oracle, T, pot, ncell, frac, amp):
     ctx.close()
 
 
-def _host_mode_device_lists(ctx, eng, x, steps_of_motion=0):
-    """the drop-in path of the aeam plugin with two atom types: the host reports its skin, its list is only CHECKED
+def _host_mode_device_lists(ctx, eng, x, ntypes=2):
+    """the drop-in path of the aeam plugin: the host reports its skin, its list is only CHECKED
     (mdp_aeam_check_host_list); bins, tile lists and the angular centres' rows are built on the device from the
     positions, the device keeps a Hilbert-sorted copy of the atoms and returns everything in the host's order"""
     xa = eng.all_positions(x)
     nall, nloc = len(xa), eng.nlocal
     ctx.aeam_device_lists(True)
-    ctx.set_atoms_host(nloc, xa, eng.type_all, eng.tag_all, 2, map_=None)
+    ctx.set_atoms_host(nloc, xa, eng.type_all, eng.tag_all, ntypes, map_=None)
     ctx.set_skin(1.0)
     rows = [np.ascontiguousarray(eng.nb[eng.off[i]:eng.off[i] + eng.nn[i]], dtype=np.int32) for i in range(nall)]
     ctx.aeam_check_host_list(np.arange(nloc, dtype=np.int32), eng.nn, rows, 1.0)
@@ -235,43 +236,50 @@ def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     ctx.close()
 
 
+def test_host_mode_with_device_lists_five_types(oracle, tmp_path):
+    """the same drop-in path with five atom types (three metals, two angular): tile lists with per-entry types in
+    host mode, everything against the oracle on the five-element file"""
+    path = str(tmp_path / "five.aeam")
+    _five_element_file(path)
+    af5 = capi.AeamFile(path)
+    T5 = oracle.aeam_pot(path)
+    s2 = S.jitter(S.fcc_cell(4.045, 5, frac_type2=0.08, seed=99), 0.075, seed=100)
+    rng = np.random.default_rng(7)
+    t5 = np.where(s2.type == 1, rng.integers(1, 4, s2.n), rng.integers(4, 6, s2.n)).astype(np.int32)
+    s5 = S.System(s2.box, s2.x.copy(), t5, s2.tag.copy(), np.array([0.0] + list(af5.mass)))
+    eng = mdref.AeamCPU(oracle, T5, s5)
+    ctx = capi.Context(0)
+    ctx.aeam_set_tables(af5.build())
+    g = _host_mode_device_lists(ctx, eng, s5.x, ntypes=5)
+    o = eng.compute(s5.x)
+    assert np.abs(g["rho"] - o["rho"][:s5.n]).max() < 1e-11
+    assert np.abs(g["f"] - o["f_owned"]).max() < 1e-9
+    assert g["eng"] == pytest.approx(o["eng"], rel=1e-11)
+    assert np.abs(g["eatom"] - o["eatom"][:s5.n]).max() < 1e-9
+    assert np.allclose(g["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
+    x2 = s5.x + 0.02 * np.random.default_rng(3).standard_normal(s5.x.shape)
+    xa2 = eng.all_positions(x2)
+    ctx.set_positions_host(xa2)
+    d = ctx.aeam_density_host(eng.nlocal, eflag=0)
+    r = ctx.aeam_force_host(len(xa2), eng.nlocal, np.concatenate([d["fp"], d["fp"][eng.owner]]), eflag=0, vflag=0)
+    o2 = eng.compute(x2)
+    assert np.abs(ob.fold_ghost_forces(r["f"], eng.owner, eng.nlocal) - o2["f_owned"]).max() < 1e-9
+    ctx.close()
+
+
 def _five_element_file(path):
-    """a 5-element potential file (3 non-angular, 2 angular) made of the blocks of AlSi.aeam: Ala, Alb, Alc behave as
-    Al, Sia and Sib as Si -- so a 5-type system must reproduce the 2-type system atom for atom"""
-    lines = open(POT_AEAM).read().split("\n")
-    head, body = lines[:11], lines[18:]
-    vals = np.array(" ".join(body).split(), dtype=float)
-    n = 10000
-    assert len(vals) == 9 * n
-    F = [vals[0:n], vals[n:2 * n]]
-    rhor = {(a, b): vals[(2 + 2 * a + b) * n:(3 + 2 * a + b) * n] for a in range(2) for b in range(2)}
-    z2r = {(0, 0): vals[6 * n:7 * n], (1, 0): vals[7 * n:8 * n], (1, 1): vals[8 * n:9 * n]}
-    cls = [0, 0, 0, 1, 1]
-    names = ["Ala", "Alb", "Alc", "Sia", "Sib"]
-    el = [lines[12], lines[13]]                      # nrho drho mass of Al, Si
-    pr = {(0, 0): lines[14], (0, 1): lines[15], (1, 0): lines[16], (1, 1): lines[17]}
-    out = head + ["5 3 2 " + " ".join(names)]
-    out += [" ".join(el[c].split()[:3]) + " " + nm for c, nm in zip(cls, names)]
-    out += [" ".join(pr[(cls[i], cls[j])].split()[:3]) for i in range(5) for j in range(5)]
-
-    def block(v):
-        return [" ".join("%.16e" % x for x in v[k:k + 5]) for k in range(0, len(v), 5)]
-    for c in cls:
-        out += block(F[c])
-    for i in range(5):
-        for j in range(5):
-            out += block(rhor[(cls[i], cls[j])])
-    for i in range(5):
-        for j in range(i + 1):
-            out += block(z2r[(max(cls[i], cls[j]), min(cls[i], cls[j]))])
-    open(path, "w").write("\n".join(out) + "\n")
+    aeam_five.write_five_element_file(path, POT_AEAM)
 
 
-def test_five_atom_types_size_everything_from_the_file(oracle, tmp_path):
+@pytest.mark.parametrize("tiles", [True, False])
+def test_five_atom_types_size_everything_from_the_file(oracle, tmp_path, tiles, monkeypatch):
     """The reference sizes its tables from the potential file (pair_aeam.cpp:752-872); the bundled file has two
     elements.  Five types (three metals, two angular) built from the same functions: the device result equals the
-    oracle's for the five-element file AND the two-type AlSi system's, atom for atom (CSR kernels: more than two
-    types have no tile lists)."""
+    oracle's for the five-element file AND the two-type AlSi system's, atom for atom -- through the tile kernels
+    (two list segments: type 0 | the other four, the entry's own type and the 25 parameter sets read from LDS) on
+    force-only and on tallying steps, and through the CSR kernels (MDP_AEAM_TILE=0)."""
+    if not tiles:
+        monkeypatch.setenv("MDP_AEAM_TILE", "0")
     path = str(tmp_path / "five.aeam")
     _five_element_file(path)
     s2 = S.jitter(S.fcc_cell(4.045, 6, frac_type2=0.08, seed=11), 0.06, seed=12)
@@ -288,18 +296,58 @@ def test_five_atom_types_size_everything_from_the_file(oracle, tmp_path):
         ctx.aeam_set_tables(tabs)
         s.mass[1:1 + af.nelements] = af.mass
         d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, float(af.cut_table(tabs).max()) + 1.0, 1.0, None)
+        d.compute(0, 0)                                   # force-only kernels
+        f_only = ctx.md_download(d.nlocal, want=("f",))["f"]
         d.compute(3, 1)
         th = d.thermo()
         got = ctx.md_download(d.nlocal, want=("f", "eatom"))
         order = np.argsort(d.tags_local)
-        out[tag] = (got["f"][order], got["eatom"][order], th)
+        out[tag] = (got["f"][order], got["eatom"][order], th, f_only[order])
         ctx.close()
-    f5, e5, th5 = out["five"]
-    f2, e2, th2 = out["two"]
+    f5, e5, th5, fo5 = out["five"]
+    f2, e2, th2, fo2 = out["two"]
     assert np.abs(f5 - f2).max() < 1e-10 and np.abs(e5 - e2).max() < 1e-10
+    assert np.abs(fo5 - fo2).max() < 1e-10
     assert th5["pe"] == pytest.approx(th2["pe"], rel=1e-12)
     T5 = oracle.aeam_pot(path)
     xw = S.wrap(s5.box, s5.x)
     o = mdref.AeamCPU(oracle, T5, S.System(s5.box, xw, s5.type, s5.tag, s5.mass)).compute(xw)
     assert np.abs(f5 - o["f_owned"]).max() < 1e-9
+    assert np.abs(fo5 - o["f_owned"]).max() < 1e-9
     assert th5["pe"] == pytest.approx(o["eng"], rel=1e-11)
+
+
+def test_five_atom_types_hot_run_equals_the_two_type_run(tmp_path):
+    """60 hot NVE steps (pruned rows, reneighborings on the device) of the five-type system and of the two-type
+    system it is a relabelling of: same functions, same masses per class -- the trajectories agree to rounding.  The
+    five-type run walks the tile lists with per-entry types, the two-type run the specialised kernels (persistent
+    density kernel included)."""
+    path = str(tmp_path / "five.aeam")
+    _five_element_file(path)
+    s2 = S.jitter(S.fcc_cell(4.045, 8, frac_type2=0.05, seed=31), 0.02, seed=32)
+    rng = np.random.default_rng(5)
+    t5 = np.where(s2.type == 1, rng.integers(1, 4, s2.n), rng.integers(4, 6, s2.n)).astype(np.int32)
+    af5 = capi.AeamFile(path)
+    s5 = S.System(s2.box, s2.x.copy(), t5, s2.tag.copy(), np.array([0.0] + list(af5.mass)))
+    v0 = S.gaussian_velocities(s2, 800.0, seed=33)
+    res = {}
+    for tag, (af, s) in {"five": (af5, s5), "two": (capi.AeamFile(POT_AEAM), s2)}.items():
+        tabs = af.build()
+        ctx = capi.Context(0)
+        ctx.aeam_set_tables(tabs)
+        s.mass[1:1 + af.nelements] = af.mass
+        d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, float(af.cut_table(tabs).max()) + 1.0, 1.0, None, v0=v0)
+        d.compute(0, 0)
+        for step in range(60):
+            d.step(0, 0, rebuild="auto")
+        got = ctx.md_download(d.nlocal, want=("x", "f"))
+        order = np.argsort(d.tags_local)
+        res[tag] = (got["x"][order], got["f"][order], d.builds, ctx.md_prune_stats())
+        ctx.close()
+    x5, f5, b5, p5 = res["five"]
+    x2, f2, b2, p2 = res["two"]
+    assert p5["prunings"] >= 1 and p2["prunings"] >= 1
+    dx = x5 - x2
+    dx -= np.round(dx / np.diag(s2.box.h)) * np.diag(s2.box.h)      # (an atom may have been wrapped in one run only)
+    assert np.abs(dx).max() < 1e-9
+    assert np.abs(f5 - f2).max() < 1e-7
