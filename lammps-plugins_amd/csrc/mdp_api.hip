@@ -4,7 +4,11 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 
 #include <cmath>
 
@@ -282,22 +286,132 @@ static bool host_register(mdp_ctx *c, const void *ptr, size_t bytes)
   return false;
 }
 
+// Host-side copies and adds of the host-mode path (tens of MB per step) are split over a few worker threads.  The
+// workers are started once per process and sleep on a condition variable between calls: starting and joining
+// eight threads for each of the fifteen 12-16 MB pieces of a step cost about as much as moving the bytes.
+// One parallel section at a time; a second caller (another context's thread) runs its pieces itself.
+namespace {
+class HostWorkers
+{
+ public:
+  static HostWorkers &get()
+  {
+    static HostWorkers w;
+    return w;
+  }
+  unsigned width() const { return nthreads; }
+  // fn(k) for k = 0 .. n-1, the caller taking part
+  template <typename F> void run(const unsigned n, const F &fn)
+  {
+    if (n <= 1 || nthreads <= 1 || !busy.try_lock()) {
+      for (unsigned k = 0; k < n; k++) fn(k);
+      return;
+    }
+    std::function<void(unsigned)> f = fn;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      start();
+      job = &f;
+      njobs = n;
+      next = done = 0;
+      gen++;
+    }
+    cv.notify_all();
+    work();
+    {
+      std::unique_lock<std::mutex> g(mu);
+      cv_done.wait(g, [&] { return done == njobs; });
+      job = nullptr;
+    }
+    busy.unlock();
+  }
+
+ private:
+  HostWorkers()
+  {
+    unsigned hc = std::thread::hardware_concurrency(), cap = 8; // (a host usually runs more than this one rank)
+    if (const char *e = getenv("MDP_HOST_THREADS")) {
+      hc = (unsigned) atoi(e);
+      cap = 64;
+    }
+    nthreads = hc > cap ? cap : (hc < 1 ? 1 : hc);
+  }
+  ~HostWorkers()
+  {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) {
+      if (getpid() == owner) t.join();
+      else t.detach(); // (a forked child inherits the objects, not the threads)
+    }
+  }
+  void start() // (mu held)
+  {
+    if (!th.empty() && getpid() == owner) return;
+    if (!th.empty()) { // forked child: the workers stayed with the parent
+      for (auto &t : th) t.detach();
+      th.clear();
+    }
+    owner = getpid();
+    for (unsigned t = 1; t < nthreads; t++)
+      th.emplace_back([this] {
+        unsigned long seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+          }
+          work();
+        }
+      });
+  }
+  void work()
+  {
+    for (;;) {
+      unsigned k;
+      const std::function<void(unsigned)> *f;
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (!job || next >= njobs) return;
+        k = next++;
+        f = job;
+      }
+      (*f)(k);
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (++done == njobs) cv_done.notify_all();
+      }
+    }
+  }
+  std::mutex busy, mu;
+  std::condition_variable cv, cv_done;
+  std::vector<std::thread> th;
+  const std::function<void(unsigned)> *job = nullptr;
+  unsigned nthreads = 1, njobs = 0, next = 0, done = 0;
+  unsigned long gen = 0;
+  bool stop = false;
+  pid_t owner = 0;
+};
+} // namespace
+
 static void host_copy_threads(char *dst, const char *src, size_t n)
 {
-  unsigned nt = n > (4u << 20) ? std::thread::hardware_concurrency() : 1;
-  nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+  HostWorkers &W = HostWorkers::get();
+  const unsigned nt = n > (4u << 20) ? W.width() : 1;
   if (nt == 1) {
     memcpy(dst, src, n);
     return;
   }
-  std::vector<std::thread> th;
   const size_t chunk = ((n + nt - 1) / nt + 4095) & ~(size_t) 4095;
-  for (unsigned t = 0; t < nt; t++) {
+  W.run(nt, [=](unsigned t) {
     const size_t b = t * chunk, e2 = b + chunk < n ? b + chunk : n;
-    if (b >= e2) break;
-    th.emplace_back([=] { memcpy(dst + b, src + b, e2 - b); });
-  }
-  for (auto &t : th) t.join();
+    if (b < e2) memcpy(dst + b, src + b, e2 - b);
+  });
 }
 
 // host array -> device, asynchronously on the context's stream; the host array may be reused on return
@@ -341,23 +455,17 @@ int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles)
 // dst[k] += src[k], split over a few threads for arrays that take milliseconds
 void mdp_host_add(double *dst, const double *src, size_t n)
 {
-  unsigned nt = n > (1u << 20) ? std::thread::hardware_concurrency() : 1;
-  nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
-  if (n < (4u << 20) && nt > 4) nt = 4; // chunked downloads: a few threads per chunk are enough
+  HostWorkers &W = HostWorkers::get();
+  const unsigned nt = n > (1u << 20) ? W.width() : 1;
   if (nt == 1) {
     for (size_t k = 0; k < n; k++) dst[k] += src[k];
     return;
   }
-  std::vector<std::thread> th;
-  const size_t chunk = (n + nt - 1) / nt;
-  for (unsigned t = 0; t < nt; t++) {
+  const size_t chunk = ((n + nt - 1) / nt + 7) & ~(size_t) 7;
+  W.run(nt, [=](unsigned t) {
     const size_t b = t * chunk, e = b + chunk < n ? b + chunk : n;
-    if (b >= e) break;
-    th.emplace_back([=] {
-      for (size_t k = b; k < e; k++) dst[k] += src[k];
-    });
-  }
-  for (auto &t : th) t.join();
+    for (size_t k = b; k < e; k++) dst[k] += src[k];
+  });
 }
 
 // xraw (device [n][3]) (+ device type[]) -> xq.  d_type null: keep the element already in xq.w
