@@ -12,10 +12,12 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 tab = json.load(open(os.path.join(P, "pmc_traffic.json")))
-for tag, main in ((RND + "_rebomos4m", True), (RND + "_aeam1m", True), (RND + "_rebomos4m_300K", False)):
+for tag, main in ((RND + "_rebomos4m", True), (RND + "_aeam1m", True), (RND + "_rebomos4m_300K", False),
+                  (RND + "_aeam16m", True)):  # (the last one: profiles/collect.sh by hand, configuration #5 on one GPU)
     d = os.path.join(G, tag)
     if not os.path.isdir(d):
-        print("missing", d)
+        if not tag.endswith("16m"):
+            print("missing", d)
         continue
     for src, dst in (("bench.json", "bench.json"), ("kernel_summary.txt", "kernel_summary.txt"),
                      ("rocprofv3_kernel_stats.csv", "rocprofv3_kernel_stats.csv"), ("pmc_entry.json", "pmc_fetch_write.json")):
