@@ -351,3 +351,38 @@ def test_five_atom_types_hot_run_equals_the_two_type_run(tmp_path):
     dx -= np.round(dx / np.diag(s2.box.h)) * np.diag(s2.box.h)      # (an atom may have been wrapped in one run only)
     assert np.abs(dx).max() < 1e-9
     assert np.abs(f5 - f2).max() < 1e-7
+
+
+@pytest.mark.parametrize("cls,names", [([0], ["Al"]), ([0, 1, 1], ["Al", "Sia", "Sib"]), ([0, 0, 0, 0, 1, 1, 1, 1], list("ABCDEFGH"))])
+def test_other_type_counts_through_the_tile_kernels(oracle, tmp_path, cls, names):
+    """one element (pure metal: the second list segment is empty), three (one metal: the per-entry types are all
+    angular) and eight (the maximum): tile kernels on a force-only and a tallying compute against the oracle on the
+    same file"""
+    path = str(tmp_path / "n.aeam")
+    aeam_five.write_relabelled_file(path, POT_AEAM, cls, names)
+    af = capi.AeamFile(path)
+    assert af.nelements == len(cls)
+    s2 = S.jitter(S.fcc_cell(4.045, 5, frac_type2=0.1 if 1 in cls else 0.0, seed=41), 0.06, seed=42)
+    rng = np.random.default_rng(9)
+    metals = [k + 1 for k, c in enumerate(cls) if c == 0]
+    angular = [k + 1 for k, c in enumerate(cls) if c == 1] or metals
+    tn = np.where(s2.type == 1, rng.choice(metals, s2.n), rng.choice(angular, s2.n)).astype(np.int32)
+    sn = S.System(s2.box, s2.x.copy(), tn, s2.tag.copy(), np.array([0.0] + list(af.mass)))
+    ctx = capi.Context(0)
+    ctx.aeam_set_tables(af.build())
+    d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, sn, float(af.cut_table(af.build()).max()) + 1.0, 1.0, None)
+    d.compute(0, 0)
+    f_only = ctx.md_download(d.nlocal, want=("f",))["f"]
+    d.compute(3, 1)
+    th = d.thermo()
+    got = ctx.md_download(d.nlocal, want=("f", "eatom"))
+    order = np.argsort(d.tags_local)
+    ctx.close()
+    Tn = oracle.aeam_pot(path)
+    xw = S.wrap(sn.box, sn.x)
+    o = mdref.AeamCPU(oracle, Tn, S.System(sn.box, xw, sn.type, sn.tag, sn.mass)).compute(xw)
+    assert np.abs(f_only[order] - o["f_owned"]).max() < 1e-9
+    assert np.abs(got["f"][order] - o["f_owned"]).max() < 1e-9
+    assert np.abs(got["eatom"][order] - o["eatom"][:sn.n]).max() < 1e-9
+    assert th["pe"] == pytest.approx(o["eng"], rel=1e-11)
+    assert np.allclose(th["virial"], o["virial_fdotr"], rtol=1e-9, atol=1e-7)
