@@ -317,7 +317,9 @@ def run_job(E, job, par):
             else:
                 rebuild = bool(check_every and n % check_every == 0 and dom.needs_rebuild(margin))
             b0 = dom.builds
-            dom.step(ev, ev, rebuild=rebuild)
+            # steps without thermo output leave their final_integrate to the first kernel of the next step (one pass
+            # over the atoms for both half-kicks, same arithmetic); thermo steps complete theirs at once
+            dom.step(ev, ev, rebuild=rebuild, defer_final=not ev and k < nsteps)
             rebuilds += dom.builds - b0
             if on_step is not None:
                 on_step(dom.builds - b0, ev)

@@ -210,6 +210,11 @@ int mdp_md_setup(mdp_ctx *ctx, const mdp_md_config *cfg, const double *x, const 
 int mdp_md_build_neighbors(mdp_ctx *ctx);
 int mdp_md_initial_integrate(mdp_ctx *ctx); /* fix nve: v += dt/2 f/m; x += dt v; refresh self-image ghosts */
 int mdp_md_final_integrate(mdp_ctx *ctx);   /* v += dt/2 f/m */
+/* final_integrate of the finished step and initial_integrate of the next in one pass over the atoms (same operations,
+ * same order: bit-identical trajectory).  For a host that needs the full-step velocities of the finished step for
+ * nothing (no thermo output, no dump at that step): it skips mdp_md_final_integrate there and opens the next step
+ * with this call instead of mdp_md_initial_integrate. */
+int mdp_md_final_initial_integrate(mdp_ctx *ctx);
 int mdp_md_compute(mdp_ctx *ctx, int eflag, int vflag); /* force_clear + Pair::compute on the device */
 /* the same in two halves for multi-GPU runs: _begin needs only owned atoms, self-image ghosts and LAST step's
  * remote ghosts (it runs while this step's halo exchange is in flight: Lennard-Jones work of the clusters
@@ -321,6 +326,9 @@ int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 
  * the current positions is launched.  Trigger: an owned atom moved more than skin/2 - 0.1 A since the last build
  * (the margin covers the step the answer is late by); *dangerous = an atom was beyond skin/2 itself. */
 int mdp_md_moved_async(mdp_ctx *ctx, int *moved, int *dangerous);
+/* mdp_md_initial_integrate (with_final != 0: mdp_md_final_initial_integrate) and mdp_md_moved_async in one call and one
+ * pass over the atoms: same results, the check reads the new positions while they are in registers. */
+int mdp_md_integrate_check(mdp_ctx *ctx, int with_final, int *moved, int *dangerous);
 /* owned atoms' "tag" / "type" in device order (the device re-orders atoms at every reneighboring); "tile_nu"
  * (diagnostics): {members of the neighbour union, Mo / first-type members} of every 32-atom tile, 2 ints per tile */
 int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);

@@ -842,6 +842,36 @@ int mdp_md_moved_async(mdp_ctx *c, int *moved, int *dangerous)
   return MDP_OK;
 }
 
+// mdp_md_initial_integrate (or, with_final, mdp_md_final_initial_integrate) and mdp_md_moved_async in one call and
+// one pass over the atoms: *moved / *dangerous = result of the check launched by the previous call of either kind,
+// then the positions are advanced and -- unless the caller is about to reneighbor anyway -- checked in the same kernel.
+int mdp_md_integrate_check(mdp_ctx *c, int with_final, int *moved, int *dangerous)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  MdpDomain &D = c->dd;
+  int *h = (int *) (c->h_pinned + 28);
+  if (!D.ev_moved) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_moved, hipEventDisableTiming));
+  int m = 0, dg = 0;
+  if (D.moved_pending) {
+    MDP_HIP(c, hipEventSynchronize(D.ev_moved));
+    m = h[0];
+    dg = h[1];
+    D.moved_pending = false;
+  }
+  if (moved) *moved = m;
+  if (dangerous) *dangerous = dg;
+  if (m || !c->nlocal || !c->neigh_set) return mdp_md_advance(c, with_final != 0, nullptr, 0.0, 0.0);
+  h[0] = h[1] = 0;
+  const double hard = 0.5 * c->cfg.skin;
+  double trig = hard - 0.1 * mdp_margin_scale(c);
+  if (trig < 0.5 * hard) trig = 0.5 * hard;
+  MDP_TRY(mdp_md_advance(c, with_final != 0, h, trig * trig, hard * hard));
+  MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+  D.moved_pending = true;
+  return MDP_OK;
+}
+
 // owned atoms' integer properties in device order ("tag", "type"); the device re-orders atoms at every reneighboring
 int mdp_md_download_int(mdp_ctx *c, const char *name, int *out)
 {

@@ -197,23 +197,50 @@ __global__ void ang_select_kernel(const int nlocal, const int min_type, const do
   if (i < nlocal && (int) xq[i].w >= min_type) list[atomicAdd(count, 1)] = i;
 }
 
-__global__ void nve_initial_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
-                                   const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq)
+// fix nve on the device.  FINAL: the final_integrate of the step just finished and the initial_integrate of the next
+// one in one pass (both half-kicks use the same forces) -- saves reading f, v, rmass and writing v once per step; the
+// same operations in the same order as the two kernels, so the trajectory is bit-identical.  CHECK: `neigh_modify
+// check yes` of the new positions against the positions of the last reneighboring in the same pass (what
+// dd_moved_kernel does in a pass of its own): flag[0] = some atom beyond the trigger, flag[1] = beyond half the skin.
+template <bool FINAL, bool CHECK>
+__global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
+                                   const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
+                                   const double *__restrict__ xhold, const double trigsq, const double hardsq,
+                                   int *__restrict__ flag)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nlocal) return;
-  const double s = dtf / rmass[i];
-  double vx = v[3 * (size_t) i] + s * f[3 * (size_t) i];
-  double vy = v[3 * (size_t) i + 1] + s * f[3 * (size_t) i + 1];
-  double vz = v[3 * (size_t) i + 2] + s * f[3 * (size_t) i + 2];
-  v[3 * (size_t) i] = vx;
-  v[3 * (size_t) i + 1] = vy;
-  v[3 * (size_t) i + 2] = vz;
-  double4 x = xq[i];
-  x.x += dt * vx;
-  x.y += dt * vy;
-  x.z += dt * vz;
-  xq[i] = x;
+  bool t = false, h = false;
+  if (i < nlocal) {
+    const double s = dtf / rmass[i];
+    const double fx = f[3 * (size_t) i], fy = f[3 * (size_t) i + 1], fz = f[3 * (size_t) i + 2];
+    double vx = v[3 * (size_t) i], vy = v[3 * (size_t) i + 1], vz = v[3 * (size_t) i + 2];
+    if (FINAL) { // final_integrate (step n)
+      vx += s * fx;
+      vy += s * fy;
+      vz += s * fz;
+    }
+    vx = vx + s * fx; // initial_integrate (step n+1)
+    vy = vy + s * fy;
+    vz = vz + s * fz;
+    v[3 * (size_t) i] = vx;
+    v[3 * (size_t) i + 1] = vy;
+    v[3 * (size_t) i + 2] = vz;
+    double4 x = xq[i];
+    x.x += dt * vx;
+    x.y += dt * vy;
+    x.z += dt * vz;
+    xq[i] = x;
+    if (CHECK) {
+      const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1], dz = x.z - xhold[3 * (size_t) i + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      t = d2 > trigsq;
+      h = d2 > hardsq;
+    }
+  }
+  if (CHECK) { // (pinned host words zeroed by the host before the launch: plain idempotent stores)
+    if (__ballot(t) && (threadIdx.x & 63) == 0) flag[0] = 1;
+    if (__ballot(h) && (threadIdx.x & 63) == 0) flag[1] = 1;
+  }
 }
 
 __global__ void nve_final_kernel(int nlocal, double dtf, const double *__restrict__ rmass,
@@ -609,22 +636,48 @@ int mdp_md_build_neighbors_impl(mdp_ctx *c)
   return mdp_aeam_prepare(c);
 }
 
-extern "C" {
-
-int mdp_md_initial_integrate(mdp_ctx *c)
+// launches the integrate kernel of the next step (with_final: after the pending final half-kick of the finished one)
+// and the refresh of the periodic self-images; flag != null: the displacement check of the new positions in the same
+// pass (see mdp_md_integrate_check in domain.hip)
+int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq)
 {
-  if (!c) return MDP_EINVAL;
-  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
-  if (c->nlocal)
-    nve_initial_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p,
-                                                               c->xq.p);
+  if (c->nlocal) {
+    const int g = nblk(c->nlocal);
+#define MDP_ADV(FV, CV)                                                                                               \
+  nve_advance_kernel<FV, CV><<<g, 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p, c->xq.p, \
+                                                      c->xhold.p, trigsq, hardsq, flag)
+    if (with_final) {
+      if (flag) MDP_ADV(true, true);
+      else MDP_ADV(true, false);
+    } else {
+      if (flag) MDP_ADV(false, true);
+      else MDP_ADV(false, false);
+    }
+#undef MDP_ADV
+  }
   // periodic self-images come first in the ghost range; remote ghosts are refreshed by the halo exchange
   const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
   if (nself)
     ghost_refresh_kernel<<<nblk(nself), 256, 0, c->stream>>>(c->nlocal, nself, c->ghost_owner.p, c->ghost_shift.p, c->xq.p);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
+}
+
+extern "C" {
+
+int mdp_md_initial_integrate(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  return mdp_md_advance(c, false, nullptr, 0.0, 0.0);
+}
+
+int mdp_md_final_initial_integrate(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  return mdp_md_advance(c, true, nullptr, 0.0, 0.0);
 }
 
 int mdp_md_final_integrate(mdp_ctx *c)

@@ -397,6 +397,7 @@ void mdp_dd_release(mdp_ctx *c); // frees everything domain.hip / comm_rccl.hip 
 int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
+int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq); // integrate kernel (+ displacement check)
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
 int mdp_to_host_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst);   // per-atom arrays, device -> host order
 int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst); // host -> device order

@@ -52,7 +52,7 @@ EXPORTS = [
     "mdp_aeam_set_tables", "mdp_aeam_file_read", "mdp_aeam_file_info", "mdp_aeam_file_build", "mdp_aeam_file_free", "mdp_set_atoms_host", "mdp_set_positions_host",
     "mdp_set_neighbors_host", "mdp_set_skin", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
     "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
-    "mdp_md_final_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
+    "mdp_md_final_integrate", "mdp_md_final_initial_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
     "mdp_md_neighbor_stats", "mdp_md_prune_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
@@ -60,7 +60,7 @@ EXPORTS = [
     "mdp_dd_setup", "mdp_dd_reneighbor", "mdp_dd_migrate_begin", "mdp_dd_migrate_pack", "mdp_dd_migrate_end",
     "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
     "mdp_dd_forward_unpack", "mdp_dd_forward_scalar_pack", "mdp_dd_forward_scalar_unpack", "mdp_dd_reverse_pack",
-    "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_download_int", "mdp_md_download_x_all",
+    "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_integrate_check", "mdp_md_download_int", "mdp_md_download_x_all",
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
     "mdp_dd_comm_allreduce", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
@@ -338,6 +338,9 @@ class Context:
     def md_final_integrate(self):
         self._ck(self.L.mdp_md_final_integrate(self.h))
 
+    def md_final_initial_integrate(self):
+        self._ck(self.L.mdp_md_final_initial_integrate(self.h))
+
     def md_compute(self, eflag=0, vflag=0):
         self._ck(self.L.mdp_md_compute(self.h, C.c_int(eflag), C.c_int(vflag)))
 
@@ -504,6 +507,12 @@ class Context:
         """(moved, dangerous) of the check launched by the previous call; launches the next one"""
         m, d = C.c_int(0), C.c_int(0)
         self._ck(self.L.mdp_md_moved_async(self.h, C.byref(m), C.byref(d)))
+        return bool(m.value), bool(d.value)
+
+    def md_integrate_check(self, with_final=False):
+        """initial_integrate (after the pending final half-kick if with_final) + md_moved_async in one kernel"""
+        m, d = C.c_int(0), C.c_int(0)
+        self._ck(self.L.mdp_md_integrate_check(self.h, C.c_int(1 if with_final else 0), C.byref(m), C.byref(d)))
         return bool(m.value), bool(d.value)
 
     def md_download_int(self, name: str, nlocal: int):

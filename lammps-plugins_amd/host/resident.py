@@ -155,11 +155,13 @@ class DeviceDomain:
         self.send3 = self.recv3 = self.send1 = self.recv1 = None
         self.builds = 0
         self.dangerous = 0
+        self._final_pending = False
         self.reneighbor()
 
     # ------------------------------------------------------------------ reneighboring
     def reneighbor(self):
         """Comm::exchange + Comm::borders + Neighbor::build, per rank on the device"""
+        self.flush()
         ctx, tr = self.ctx, self.tr
         if tr is None:
             ctx.dd_reneighbor()
@@ -242,6 +244,7 @@ class DeviceDomain:
     # ------------------------------------------------------------------ MD
     def compute(self, eflag=0, vflag=0):
         """Pair::compute for the current positions (ghosts must be current)"""
+        self.flush()
         if self.style == capi.STYLE_REBOMOS or not self._active():
             self.ctx.md_compute(eflag, vflag)
             return
@@ -250,15 +253,30 @@ class DeviceDomain:
         self.ctx.md_aeam_force(eflag, vflag)
         self.reverse_forces()
 
-    def step(self, eflag=0, vflag=0, rebuild=False):
+    def flush(self):
+        """the final_integrate a step(defer_final=True) left to the next step's fused kernel, now (before anything
+        that reads the velocities or replaces the forces)"""
+        if self._final_pending:
+            self.ctx.md_final_integrate()
+            self._final_pending = False
+
+    def step(self, eflag=0, vflag=0, rebuild=False, defer_final=False):
         """one velocity-Verlet step, Verlet::run order: initial_integrate, [reneighbor], forward comm, force,
-        final_integrate.  REBO-MoS on several GPUs hides the ghost exchange behind the interior Lennard-Jones work."""
+        final_integrate.  REBO-MoS on several GPUs hides the ghost exchange behind the interior Lennard-Jones work.
+        defer_final: leave this step's final_integrate to the next step, whose first kernel then does both
+        half-kicks in one pass (mdp_md_final_initial_integrate; same arithmetic) -- for steps after which nothing
+        reads the velocities; thermo() / compute() / reneighbor() / flush() complete it otherwise."""
         ctx = self.ctx
-        ctx.md_initial_integrate()
         if isinstance(rebuild, str):        # "auto": one GPU, deferred on-device flag read every step
             if self.tr is not None:
                 raise ValueError("rebuild='auto' is for one-GPU runs; several ranks decide collectively (needs_rebuild)")
-            rebuild = self.moved()
+            rebuild, late = ctx.md_integrate_check(self._final_pending)   # integrate + check in one pass
+            self.dangerous += int(late)
+        elif self._final_pending:
+            ctx.md_final_initial_integrate()
+        else:
+            ctx.md_initial_integrate()
+        self._final_pending = False
         if rebuild:
             self.reneighbor()               # the border exchange carries the current positions
         fresh, self.fresh_ghosts = self.fresh_ghosts and rebuild, False
@@ -279,10 +297,14 @@ class DeviceDomain:
             if not fresh:
                 self.forward_positions()
             self.compute(eflag, vflag)
-        ctx.md_final_integrate()
+        if defer_final:
+            self._final_pending = True
+        else:
+            ctx.md_final_integrate()
 
     def thermo(self, reduce=True):
         """KE, PE, virial (summed over ranks), T and P of the whole system"""
+        self.flush()
         t = self.ctx.md_thermo()
         if self.tr is not None and reduce:
             tot = self.tr.sum([t["ke"], t["pe"], *t["virial"], ])

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, POT_REBOMOS
+from conftest import GOLDEN, POT_AEAM, POT_REBOMOS
 from lammps_plugins_amd.host import capi, resident, system as S
 import hostplan
 import mdref
@@ -162,3 +162,52 @@ def test_device_bytes_are_reported_per_context():
     ctx1.close()
     assert ctx2.device_bytes() == b2
     ctx2.close()
+
+
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_deferred_final_integrate_gives_the_same_trajectory(style):
+    """step(defer_final=True) leaves the final half-kick to the first kernel of the next step
+    (mdp_md_final_initial_integrate: both half-kicks in one pass): positions, velocities and forces after 40 hot steps
+    with reneighborings and thermo steps in between are bit-identical to the run with separate kernels (rebomos; the
+    aeam angular kernels use FP64 atomics, whose order is not fixed: equal to rounding there)."""
+    res = {}
+    for defer in (False, True):
+        ctx = capi.Context(0)
+        if style == "rebomos":
+            p = capi.read_rebomos_file(POT_REBOMOS)
+            ctx.rebomos_set_params(p)
+            s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 3))
+            v0 = S.gaussian_velocities(s, 900.0, seed=3)
+            d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1], v0=v0)
+        else:
+            af = capi.AeamFile(POT_AEAM)
+            tabs = af.build()
+            ctx.aeam_set_tables(tabs)
+            s = S.fcc_cell(4.045, 7, frac_type2=0.02, seed=5)
+            s.mass[1:3] = af.mass
+            v0 = S.gaussian_velocities(s, 1500.0, seed=3)
+            d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, float(af.cut_table(tabs).max()) + 1.0, 1.0, None, v0=v0)
+        d.compute(0, 0)
+        pe = []
+        for k in range(1, 41):
+            ev = 1 if k % 10 == 0 else 0
+            d.step(ev, 0, rebuild="auto", defer_final=defer and not ev)
+            if ev:
+                pe.append(d.thermo())
+        d.flush()
+        got = ctx.md_download(d.nlocal, want=("x", "v", "f"))
+        order = np.argsort(d.tags_local)
+        res[defer] = (got["x"][order], got["v"][order], got["f"][order], pe, d.builds)
+        ctx.close()
+    a, b = res[False], res[True]
+    assert a[4] == b[4]                                    # same reneighborings ...
+    if style == "aeam":
+        assert a[4] >= 2                                   # ... and there were some (1 A of skin, 1500 K)
+    for k in range(3):
+        if style == "rebomos":
+            assert np.array_equal(a[k], b[k])
+        else:   # (the angular kernels add with FP64 atomics: two runs of the same steps differ in the last bits)
+            assert np.abs(a[k] - b[k]).max() < 1e-7
+    for ta, tb in zip(a[3], b[3]):
+        assert ta["ke"] == pytest.approx(tb["ke"], rel=1e-13)   # (sums through atomics: not ordered)
+        assert ta["pe"] == pytest.approx(tb["pe"], rel=1e-13)
