@@ -6,7 +6,7 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/trace/*/*kernel_trace.csv"))[-1]
 navg = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "nve_initial" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "nve_advance" in r["Kernel_Name"] or "nve_initial" in r["Kernel_Name"]]
 short = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:46]
 a, b = idx[-11], idx[-10]            # one step of the final loop, ten from the end
 t0 = int(rows[a]["Start_Timestamp"]); prev = t0
