@@ -353,11 +353,14 @@ def test_five_atom_types_hot_run_equals_the_two_type_run(tmp_path):
     assert np.abs(f5 - f2).max() < 1e-7
 
 
-@pytest.mark.parametrize("cls,names", [([0], ["Al"]), ([0, 1, 1], ["Al", "Sia", "Sib"]), ([0, 0, 0, 0, 1, 1, 1, 1], list("ABCDEFGH"))])
-def test_other_type_counts_through_the_tile_kernels(oracle, tmp_path, cls, names):
+@pytest.mark.parametrize("cls,names,cluster", [([0], ["Al"], "2"), ([0, 1, 1], ["Al", "Sia", "Sib"], "2"),
+                                               ([0, 0, 1], ["Ala", "Alb", "Si"], "1"),
+                                               ([0, 0, 0, 0, 1, 1, 1, 1], list("ABCDEFGH"), "2")])
+def test_other_type_counts_through_the_tile_kernels(oracle, tmp_path, cls, names, cluster, monkeypatch):
     """one element (pure metal: the second list segment is empty), three (one metal: the per-entry types are all
     angular) and eight (the maximum): tile kernels on a force-only and a tallying compute against the oracle on the
     same file"""
+    monkeypatch.setenv("MDP_AEAM_CLUSTER", cluster)          # (1: one atom per 16-lane group, the other tile layout)
     path = str(tmp_path / "n.aeam")
     aeam_five.write_relabelled_file(path, POT_AEAM, cls, names)
     af = capi.AeamFile(path)

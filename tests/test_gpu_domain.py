@@ -98,7 +98,7 @@ def test_atoms_outside_the_box_are_remapped(oracle):
     ctx.close()
 
 
-def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None):
+def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None, defer=False):
     """NVE run on `world` bricks (threads), forced reneighboring every `rebuild_every` steps; returns per-tag
     x, v and the thermo of the last step, plus per-rank counts"""
 
@@ -108,7 +108,7 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None)
             skin, map_ = 2.0, MAP
         else:
             ctx = capi.Context(0)
-            af = capi.AeamFile(POT_AEAM)
+            af = capi.AeamFile(pot or POT_AEAM)
             tabs = af.build()
             ctx.aeam_set_tables(tabs)
             skin, map_ = 1.0, None
@@ -122,7 +122,7 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None)
         left = 0
         for step in range(1, steps + 1):
             rb = rebuild_every and step % rebuild_every == 0
-            d.step(1 if step == steps else 0, 1 if step == steps else 0, rebuild=rb)
+            d.step(1 if step == steps else 0, 1 if step == steps else 0, rebuild=rb, defer_final=defer and step != steps)
             if rb:
                 left += ctx.dd_info()["left_last"]
         th = d.thermo()
@@ -208,6 +208,35 @@ def test_aeam_bricks_with_halo_of_fp_and_ghost_forces(oracle):
         dx = many["x"] - one["x"]
         dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
         assert np.abs(dx).max() < 1e-8
+        assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+
+
+def test_aeam_bricks_with_five_atom_types(oracle, tmp_path):
+    """the same on 2 and 4 bricks with a five-element file (tile kernels with per-entry types; types of remote ghosts
+    arrive with the border exchange), the steps run with the final half-kick deferred into the next step's kernel"""
+    import aeam_five
+    path = str(tmp_path / "five.aeam")
+    aeam_five.write_five_element_file(path, POT_AEAM)
+    af5 = capi.AeamFile(path)
+    T5 = oracle.aeam_pot(path)
+    s2 = S.jitter(S.fcc_cell(4.045, 8, frac_type2=0.06, seed=3), 0.05, seed=4)
+    rng = np.random.default_rng(11)
+    t5 = np.where(s2.type == 1, rng.integers(1, 4, s2.n), rng.integers(4, 6, s2.n)).astype(np.int32)
+    s = S.System(s2.box, s2.x.copy(), t5, s2.tag.copy(), np.array([0.0] + list(af5.mass)))
+    v0 = S.gaussian_velocities(s, 600.0, seed=2) + np.array([40.0, 25.0, -30.0])
+    xw = S.wrap(s.box, s.x)
+    o = mdref.AeamCPU(oracle, T5, S.System(s.box, xw, s.type, s.tag, s.mass)).compute(xw)
+    one = _run(1, s, v0, 24, 3, style=capi.STYLE_AEAM, pot=path)
+    for world in (2, 4):
+        st = _run(world, s, v0, 0, 0, style=capi.STYLE_AEAM, pot=path)
+        assert np.abs(st["f"] - o["f_owned"]).max() < 1e-9
+        assert st["th0"]["pe"] == pytest.approx(o["eng"], rel=1e-11)
+        many = _run(world, s, v0, 24, 3, style=capi.STYLE_AEAM, pot=path, defer=True)
+        assert many["left"] > 5
+        dx = many["x"] - one["x"]
+        dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+        assert np.abs(dx).max() < 1e-8
+        assert np.abs(many["v"] - one["v"]).max() < 1e-7
         assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
 
 
