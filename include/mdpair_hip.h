@@ -217,8 +217,10 @@ int mdp_md_final_integrate(mdp_ctx *ctx);   /* v += dt/2 f/m */
 int mdp_md_final_initial_integrate(mdp_ctx *ctx);
 int mdp_md_compute(mdp_ctx *ctx, int eflag, int vflag); /* force_clear + Pair::compute on the device */
 /* the same in two halves for multi-GPU runs: _begin needs only owned atoms, self-image ghosts and LAST step's
- * remote ghosts (it runs while this step's halo exchange is in flight: Lennard-Jones work of the clusters
- * whose lists reach no remote ghost); _end needs the unpacked halo.  rebomos only; aeam: _begin is a no-op. */
+ * remote ghosts (it runs while this step's halo exchange is in flight: the work whose lists reach no remote
+ * ghost -- rebomos: the interior REBO centres; aeam: the density of the interior tiles); _end needs the unpacked
+ * halo (aeam: _end is density + force + self-image fold for a host without exchanges of its own; a multi-GPU host
+ * calls the four aeam phases below instead). */
 int mdp_md_compute_begin(mdp_ctx *ctx, int eflag, int vflag);
 int mdp_md_compute_end(mdp_ctx *ctx, int eflag, int vflag);
 /* halo plumbing for multi-GPU: pack x (or the AEAM fp) of owned atoms sendlist[n] (+shift) into buf;
@@ -230,9 +232,22 @@ int mdp_md_unpack_scalar(mdp_ctx *ctx, int which, int first_ghost, int n, const 
 int mdp_md_pack_ghost_f(mdp_ctx *ctx, int first_ghost, int n, double *d_buf);       /* reverse comm */
 int mdp_md_unpack_add_f(mdp_ctx *ctx, int n, const int *d_sendlist, const double *d_buf);
 int mdp_md_fold_self_ghost_f(mdp_ctx *ctx); /* reverse comm for periodic self-images */
-/* AEAM only: split compute around the fp halo */
+/* AEAM only: compute in phases around the style's own exchanges -- forward_comm of fp (pair_aeam.cpp:307, 946-963)
+ * and the host's reverse_comm of the forces that three-body terms put on ghosts (pair_aeam.cpp:462-470):
+ *   mdp_md_compute_begin     [optional] density of the tiles that reach no remote ghost | position halo in flight
+ *   mdp_md_aeam_density      the remaining density, angular centres, embedding; when _compute_begin did run, also the
+ *                            three-body forces (they need the centre's own F' only), so that ghost forces are final
+ *   mdp_md_aeam_force_begin  [optional] pair forces of the interior tiles           | fp and ghost forces in flight
+ *   mdp_md_aeam_force        the remaining pair forces (three-body forces if not done yet); needs fp on the ghosts
+ * Without the optional calls the two others do everything, as before.  eflag / vflag must agree between the phases
+ * of one compute.  mdp_md_aeam_state: out[0] = phases done so far in the current compute (bit 1: interior density,
+ * bit 2: three-body forces, bit 3: interior forces), [1] = tiles that reach no remote ghost, [2] = tiles,
+ * [3] = 1 when an angular centre may have a remote ghost in its row (otherwise no ghost force is ever non-zero and
+ * the reverse exchange can be skipped by all ranks alike). */
 int mdp_md_aeam_density(mdp_ctx *ctx, int eflag);
+int mdp_md_aeam_force_begin(mdp_ctx *ctx, int eflag, int vflag);
 int mdp_md_aeam_force(mdp_ctx *ctx, int eflag, int vflag);
+int mdp_md_aeam_state(mdp_ctx *ctx, int out[4]);
 /* thermo: out[0]=KE(owned), [1]=PE (eng_vdwl of last compute), [2..7]=virial of last compute,
  * [8] = max squared displacement since the last neighbor build (neigh_modify check yes) */
 int mdp_md_thermo(mdp_ctx *ctx, double out[9]);
@@ -319,6 +334,13 @@ int mdp_dd_comm_forward_begin(mdp_ctx *ctx);    /* Comm::forward_comm: x of the 
 int mdp_dd_comm_forward_end(mdp_ctx *ctx);
 int mdp_dd_comm_forward_scalar(mdp_ctx *ctx);   /* AEAM fp (pair_aeam.cpp:307) */
 int mdp_dd_comm_reverse(mdp_ctx *ctx);          /* Comm::reverse_comm of f (AEAM angular terms) */
+/* the two aeam exchanges of a step in one group of sends and receives on the communication stream, between
+ * mdp_md_aeam_density (after mdp_md_compute_begin: three-body forces done) and mdp_md_aeam_force; work launched in
+ * between (mdp_md_aeam_force_begin) overlaps them.  with_reverse = 0 leaves the ghost forces out (all ranks alike:
+ * no rank has an angular centre next to a remote ghost, mdp_md_aeam_state out[3] reduced over the ranks).  _begin
+ * also folds the periodic self-images' forces (mdp_md_fold_self_ghost_f). */
+int mdp_dd_comm_aeam_exchange_begin(mdp_ctx *ctx, int with_reverse);
+int mdp_dd_comm_aeam_exchange_end(mdp_ctx *ctx);
 int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 max */);
 
 /* `neigh_modify every 1 delay 0 check yes` (sample.in:17-18, log.rebomos-bulk.1:46) without a host round trip per

@@ -241,15 +241,15 @@ __device__ __forceinline__ TilePar par_at(const ParLds &T, const int pt)
 // pass 1, metal centres (pair_aeam.cpp:174-205)
 template <int CL, bool MULTI>
 __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
-    const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const int cap, const int capL,
-    const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
+    const AeamDev A, const int nlocal, const int nclus, const int t_begin, const double4 *__restrict__ xq, const int cap,
+    const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
     const int *__restrict__ lj_len /* lengths of pruned rows, or null */, const int *__restrict__ lj_split,
     const unsigned short *__restrict__ lj16, double *__restrict__ rho)
 {
   constexpr int L = 16, SK = 3;
   extern __shared__ double s_pos[]; // [capL][3]  (MULTI: then the parameter block and type[capL])
   const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
-  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int t = t_begin + xcd_contiguous(blockIdx.x, gridDim.x); // the launch walks tiles [t_begin, t_begin + grid)
   const int kc = t * kTile + tid / L;
   const bool have = kc < nclus;
   const int nU = tile_nu[2 * t];
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
 // as aeam_force_kernel<.., true> does (ev_tally of the visit i = a: pair_aeam.cpp:386-393).
 template <int CL, bool EV, bool MULTI>
 __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
-    const AeamDev A, const int nlocal, const int nclus, const double4 *__restrict__ xq, const double *__restrict__ fp,
-    const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
+    const AeamDev A, const int nlocal, const int nclus, const int t_begin, const double4 *__restrict__ xq,
+    const double *__restrict__ fp, const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
     const long long *__restrict__ lj_off, const int *__restrict__ lj_len /* lengths of pruned rows, or null */,
     const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16,
     double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag)
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
   extern __shared__ double s_rec[]; // [capL][4]
   double4 *__restrict__ s4 = reinterpret_cast<double4 *>(s_rec);
   const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
-  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int t = t_begin + xcd_contiguous(blockIdx.x, gridDim.x); // the launch walks tiles [t_begin, t_begin + grid)
   const int kc = t * kTile + tid / L;
   const bool have = kc < nclus;
   const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1]; // members [0,N0) are of type 0
@@ -583,57 +583,46 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Persistent tile kernels: the spline table of the majority pair type lives in LDS.
+// Persistent density kernel: the spline table of the majority pair type lives in LDS.
 //
 // The tile kernels above fetch one spline row per in-range pair from global memory, every lane a different row of
 // a 200-300 KB table: the vector L1 misses nearly always and its fill path (one 128-byte line per ~2.3 clocks
 // per CU, profiles/ubench/tcp_gather.hip) is what bounds them.  A row's four value coefficients are the cubic
-// Hermite expressions of the tabulated value Y and slope S at rows m and m+1 (pair_aeam.cpp:929-935), and the
-// derivative's three are those times 1/dr (:937-941) -- so 16 bytes per row hold everything, and the rows that
-// are ever addressed (r from ~2.3 A to the cutoff) of ONE function fit the 160 KB LDS of a CU next to the
-// staging buffers.  Hence one function per pass:
-//   PT_DENSITY  rho(r)            pass 1 of metal centres
-//   PT_FRHO     rho'(r) terms     pass 3, embedding part of both visits
-//   PT_FPHI     phi'(r) terms     pass 3, pair part of both visits (and the pair energy on tallying steps)
+// Hermite expressions of the tabulated value Y and slope S at rows m and m+1 (pair_aeam.cpp:929-935) -- so 16 bytes
+// per row hold everything, and the rows that are ever addressed (r from ~2.3 A to the cutoff) of ONE function fit
+// the 160 KB LDS of a CU next to the staging buffers: rho(r) of the (0,0) pair, pass 1 of the metal centres.
+// (The force pass needs two functions per pair, rho' and phi'; as two such passes it measured 1.4 ms against
+// 0.65 ms for the gather kernel and is not part of the library -- DESIGN.md section 4 item 10.)
 // One workgroup per CU stays resident: NSUB sub-blocks of 256 threads each walk their share of the workgroup's
 // contiguous run of tiles.  A sub-block's next tile (union coordinates, rows, cluster heads) is requested into
 // registers BEFORE the current tile is computed and written to LDS after it; the compute phase itself reads LDS
 // only, so the loads in flight never sit in front of a wait.  Pairs of other type pairs (1.5 % in sample.in),
 // and rows below the window, read the same (Y,S) rows from global memory.
 // ------------------------------------------------------------------------------------------------------
-enum { PT_DENSITY = 0, PT_FRHO = 1, PT_FPHI = 2 };
-
 struct PTile {
-  int nlocal, nclus, ntile, cap, capL, rowcapB, per; // per = tiles per workgroup
-  int wlo, nw, lds_table;                           // LDS window: rows [wlo, wlo + nw) of table lds_table
-  double hot_rsqmax;                                // largest r^2 inside the (0,0) pair's cutoff
+  int nlocal, nclus, cap, capL, rowcapB, per; // per = tiles per workgroup
+  int t_begin, t_end;                         // the launch walks tiles [t_begin, t_end)
+  int wlo, nw, lds_table;                     // LDS window: rows [wlo, wlo + nw) of table lds_table
+  double hot_rsqmax;                          // largest r^2 inside the (0,0) pair's cutoff
   const double4 *xq;
-  const double *fp;
   const int *tu, *tile_nu;
   const long long *lj_off;
   const int *lj_len; // lengths of pruned rows (at the offsets of the rows as built), or null
   const int *lj_split;
   const unsigned short *lj16;
-  const double2 *ys; // [table][nrmax+1] (value, slope) rows of the pass's function
-  double *rho, *f, *eatom, *acc;
-  int eflag, vflag;
+  const double2 *ys; // [table][nrmax+1] (value, slope) rows of rho(r)
+  double *rho;
 };
 
 struct YsRow {
   double2 a, b; // rows m and m+1
 };
-// value and derivative (per unit of the row coordinate) of the row's cubic
+// value of the row's cubic (p = position inside the row)
 __device__ __forceinline__ double ys_val(const YsRow w, const double p)
 {
   const double d = w.b.x - w.a.x;
   const double c4 = 3.0 * d - 2.0 * w.a.y - w.b.y, c3 = w.a.y + w.b.y - 2.0 * d;
   return ((c3 * p + c4) * p + w.a.y) * p + w.a.x;
-}
-__device__ __forceinline__ double ys_der(const YsRow w, const double p)
-{
-  const double d = w.b.x - w.a.x;
-  const double c4 = 3.0 * d - 2.0 * w.a.y - w.b.y, c3 = w.a.y + w.b.y - 2.0 * d;
-  return (3.0 * c3 * p + 2.0 * c4) * p + w.a.y;
 }
 
 // explicit address spaces for the two sources of a table row: left generic, the compiler folds "LDS or global"
@@ -642,11 +631,11 @@ __device__ __forceinline__ double ys_der(const YsRow w, const double p)
 typedef __attribute__((address_space(3))) const double lds_double;
 typedef __attribute__((address_space(1))) const double glb_double;
 
-template <int MODE, int NSUB, int CL, bool EV>
+template <int NSUB, int CL>
 __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A, const PTile P)
 {
   constexpr int L = 16, SK = CL == 2 ? 3 : 2, RK = 2;
-  constexpr int REC = MODE == PT_FRHO ? 4 : 3; // doubles per union record: x y z (q)
+  constexpr int REC = 3; // doubles per union record: x y z
   extern __shared__ double2 s_dyn[];
   double2 *__restrict__ s_tab = s_dyn; // [nw]
   const int tid = threadIdx.x, sub = tid >> 8, t8 = tid & 255, lane = tid & 63, s = lane % L, gq = t8 / L;
@@ -660,8 +649,8 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     for (int i = tid; i < P.nw; i += NSUB * 256) s_tab[i] = src[i];
   }
   const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int t_first = wg * P.per;
-  const int t_last = t_first + P.per < P.ntile ? t_first + P.per : P.ntile; // exclusive
+  const int t_first = P.t_begin + wg * P.per;
+  const int t_last = t_first + P.per < P.t_end ? t_first + P.per : P.t_end; // exclusive
   const int rounds = (P.per + NSUB - 1) / NSUB;
 
   // Both stages only REQUEST: nothing loaded is touched (no select, no difference) before the next stage or
@@ -676,7 +665,7 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
   const int *__restrict__ off_lo = reinterpret_cast<const int *>(P.lj_off);
   auto load_meta = [&](const int tt) {
     m_valid = tt < t_last;
-    m_t = m_valid ? tt : P.ntile - 1;
+    m_t = m_valid ? tt : P.t_end - 1;
     m_nu = reinterpret_cast<const int2 *>(P.tile_nu)[m_t];
     m_rb = P.lj_off[(size_t) m_t * kTile];
     m_re = off_lo[2 * ((size_t) m_t * kTile + kTile)];
@@ -685,23 +674,20 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     for (int k = 0; k < SK; k++) m_idx[k] = mem[t8 + 256 * k];
   };
   // ---- stage 2: the union's coordinates, the tile's rows, the cluster heads (one tile ahead) ----------
-  int n_t, n_nU, n_N0, n_rtot, n_split;
+  int n_t, n_nU, n_rtot, n_split;
   long long n_rb;
   int n_b, n_b1;
   double4 n_sv[SK], n_xa[CL];
-  double n_sq[SK], n_qa[CL];
   double n_rv[RK][2];
   auto gather = [&]() {
     n_t = m_t;
     n_nU = m_valid ? m_nu.x : 0;
-    n_N0 = m_valid ? m_nu.y : 0;
     n_rtot = m_valid ? m_re - (int) m_rb : 0;
     n_rb = m_rb;
 #pragma unroll
     for (int k = 0; k < SK; k++) {
       const int j = t8 + 256 * k < n_nU ? m_idx[k] : 0;
       n_sv[k] = P.xq[j];
-      n_sq[k] = MODE == PT_FRHO ? P.fp[j] : 0.0;
     }
     const double2 *__restrict__ rsrc = reinterpret_cast<const double2 *>(P.lj16 + m_rb);
 #pragma unroll
@@ -718,7 +704,6 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     for (int c = 0; c < CL; c++) {
       const int ia = kc * CL + c < P.nlocal ? kc * CL + c : P.nlocal - 1;
       n_xa[c] = P.xq[ia];
-      n_qa[c] = MODE == PT_FRHO ? P.fp[ia] : 0.0;
     }
   };
   // registers -> LDS (between two barriers)
@@ -730,7 +715,6 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
         s_rec[REC * u] = n_sv[k].x;
         s_rec[REC * u + 1] = n_sv[k].y;
         s_rec[REC * u + 2] = n_sv[k].z;
-        if (MODE == PT_FRHO) s_rec[REC * u + 3] = (u < n_N0 ? 0 : 1) < A.nnonangular ? n_sq[k] : 0.0;
       }
     }
     if (n_nU > 256 * SK) { // a union beyond the register stage: fetched here (not seen in practice)
@@ -741,14 +725,12 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
         s_rec[REC * u] = v.x;
         s_rec[REC * u + 1] = v.y;
         s_rec[REC * u + 2] = v.z;
-        if (MODE == PT_FRHO) s_rec[REC * u + 3] = (u < n_N0 ? 0 : 1) < A.nnonangular ? P.fp[j] : 0.0;
       }
     }
     if (t8 == 0) { // the dummy member every padding entry points at: outside every cutoff
       s_rec[REC * n_nU] = 1.0e30;
       s_rec[REC * n_nU + 1] = 0.0;
       s_rec[REC * n_nU + 2] = 0.0;
-      if (MODE == PT_FRHO) s_rec[REC * n_nU + 3] = 0.0;
     }
 #pragma unroll
     for (int k = 0; k < RK; k++) {
@@ -776,17 +758,13 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     const int roff = n_b - (int) n_rb;
     const int kc = t * kTile + gq;
     double4 xa[CL];
-    double qa[CL];
     int ta[CL];
-    bool real[CL], metal[CL];
+    bool metal[CL];
 #pragma unroll
     for (int c = 0; c < CL; c++) {
       xa[c] = n_xa[c];
-      qa[c] = n_qa[c];
       ta[c] = (int) xa[c].w;
-      real[c] = nU > 0 && kc < P.nclus && kc * CL + c < P.nlocal;
-      metal[c] = real[c] && ta[c] < A.nnonangular;
-      if (MODE == PT_FRHO && !(ta[c] < A.nnonangular)) qa[c] = 0.0; // (1 - deli): angular centres embed through the three-body kernel
+      metal[c] = nU > 0 && kc < P.nclus && kc * CL + c < P.nlocal && ta[c] < A.nnonangular;
     }
     // ---- request the next tile, and the header of the one after ----
     // (vmcnt(0): nothing is in flight here -- the commit consumed it -- but only an explicit wait lets the compiler
@@ -796,10 +774,9 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     load_meta(t_first + (rd + 2) * NSUB + sub);
 
     // ---- compute from LDS ----
-    double ac0[CL], ac1[CL], ac2[CL], ea[CL];
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+    double ac0[CL];
 #pragma unroll
-    for (int c = 0; c < CL; c++) ac0[c] = ac1[c] = ac2[c] = ea[c] = 0.0;
+    for (int c = 0; c < CL; c++) ac0[c] = 0.0;
     const unsigned short *__restrict__ row = s_row + roff;
     // A table row comes from the LDS window (HOT pass) or from global memory (COLD pass: other type pairs, rows
     // below the window).  The passes are separate loops because a loop that may read global memory waits for
@@ -823,8 +800,8 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
       w.b.y = src[3];
       return w;
     };
-    // HOT pass: pairs of the majority type pair (0,0) -- both visits read the LDS-resident table at the same row,
-    // and every parameter is a scalar (CutDec never applies to a metal centre, pair_aeam.cpp:187-190)
+    // HOT pass: pairs of the majority type pair (0,0) -- the LDS-resident table, and every parameter is a scalar
+    // (CutDec never applies to a metal centre, pair_aeam.cpp:187-190)
     auto hot_pass = [&](bool &cold_seen) {
       const int kb = 0, ke = split;
       const double rdr = A.rdr[0];
@@ -833,9 +810,8 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
       bool hot[CL];
 #pragma unroll
       for (int c = 0; c < CL; c++) {
-        const bool act = MODE == PT_DENSITY ? metal[c] : real[c];
-        hot[c] = act && ta[c] == 0;
-        if (act && ta[c] != 0) cold_seen = true;
+        hot[c] = metal[c] && ta[c] == 0;
+        if (metal[c] && ta[c] != 0) cold_seen = true;
       }
       bool anyhot = false;
 #pragma unroll
@@ -845,7 +821,6 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
       for (int k = kb + s; k < ke; k += L) {
         const double *__restrict__ pj = s_rec + REC * li_next;
         const double xj = pj[0], yj = pj[1], zj = pj[2];
-        const double qj = MODE == PT_FRHO ? pj[REC - 1] : 0.0;
         li_next = k + L < ke ? (int) row[k + L] : nU;
 #pragma unroll
         for (int c = 0; c < CL; c++) {
@@ -860,27 +835,7 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
             cold_seen = true;
             continue;
           }
-          const YsRow w = lds_row(m);
-          if (MODE == PT_DENSITY) {
-            ac0[c] += ys_val(w, pf);
-          } else {
-            // the two visits' derivative terms: -q f'/r (pair_aeam.cpp:373) or -phi'/(2r) (:375-376)
-            const double der = ys_der(w, pf) * rdr * recip;
-            const double fpair_a = -(MODE == PT_FRHO ? qa[c] : 0.5) * der;
-            const double ft = fpair_a - (MODE == PT_FRHO ? qj : 0.5) * der;
-            if (EV && MODE == PT_FPHI) ea[c] += 0.5 * ys_val(w, pf); // credited to i only (pair_aeam.cpp:386-390)
-            ac0[c] -= dx * ft;
-            ac1[c] -= dy * ft;
-            ac2[c] -= dz * ft;
-            if (EV) { // ev_tally(i = a, j, ..., fpair_a, d): every rank tallies its own visits
-              v0 += dx * dx * fpair_a;
-              v1 += dy * dy * fpair_a;
-              v2 += dz * dz * fpair_a;
-              v3 += dx * dy * fpair_a;
-              v4 += dx * dz * fpair_a;
-              v5 += dy * dz * fpair_a;
-            }
-          }
+          ac0[c] += ys_val(lds_row(m), pf);
         }
       }
     };
@@ -888,63 +843,31 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
     auto cold_pass = [&](auto tjc) {
       constexpr int TJ = decltype(tjc)::value;
       const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
-      TilePar qA[CL], qJ[CL];
+      TilePar qA[CL];
       double c2max[CL];
 #pragma unroll
       for (int c = 0; c < CL; c++) {
         qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
-        qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
-        const double cm = MODE == PT_DENSITY || qA[c].cut > qJ[c].cut ? qA[c].cut : qJ[c].cut;
-        c2max[c] = cm * cm * (1.0 + 1.0e-12);
+        c2max[c] = qA[c].cut * qA[c].cut * (1.0 + 1.0e-12);
       }
       int li_next = kb + s < ke ? (int) row[kb + s] : nU;
       for (int k = kb + s; k < ke; k += L) {
         const double *__restrict__ pj = s_rec + REC * li_next;
         const double xj = pj[0], yj = pj[1], zj = pj[2];
-        const double qj = MODE == PT_FRHO ? pj[REC - 1] : 0.0;
         li_next = k + L < ke ? (int) row[k + L] : nU;
 #pragma unroll
         for (int c = 0; c < CL; c++) {
           const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
           const double rsq = dx * dx + dy * dy + dz * dz;
-          if (!((MODE == PT_DENSITY ? metal[c] : real[c]) && rsq > 0.0 && rsq <= c2max[c])) continue;
+          if (!(metal[c] && rsq > 0.0 && rsq <= c2max[c])) continue;
           const double recip = rsqrt_nr(rsq);
           const double r = rsq * recip;
           const bool hotc = TJ == 0 && ta[c] == 0; // a pair the hot pass owns unless its row lies below the window
-          const bool in_a = r <= qA[c].cut, in_j = MODE != PT_DENSITY && r <= qJ[c].cut;
-          const int tabA = MODE == PT_FPHI ? qA[c].tz2r : qA[c].trho, tabJ = MODE == PT_FPHI ? qJ[c].tz2r : qJ[c].trho;
-          const double wa = MODE == PT_FRHO ? qa[c] : 0.5, wj = MODE == PT_FRHO ? qj : 0.5;
-          double fpair_a = 0.0, fpair_j = 0.0;
-          if (in_a) {
-            double pf;
-            const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
-            if (hotc && m >= P.wlo) continue;
-            const YsRow w = glb_row(tabA, m);
-            if (MODE == PT_DENSITY) {
-              ac0[c] += ys_val(w, pf);
-              continue;
-            }
-            fpair_a = -wa * ys_der(w, pf) * qA[c].rdr * recip;
-            if (EV && MODE == PT_FPHI) ea[c] += 0.5 * ys_val(w, pf);
-          }
-          if (MODE == PT_DENSITY) continue;
-          if (in_j) {
-            double pf;
-            const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
-            fpair_j = -wj * ys_der(glb_row(tabJ, m), pf) * qJ[c].rdr * recip;
-          }
-          const double ft = fpair_a + fpair_j;
-          ac0[c] -= dx * ft;
-          ac1[c] -= dy * ft;
-          ac2[c] -= dz * ft;
-          if (EV) {
-            v0 += dx * dx * fpair_a;
-            v1 += dy * dy * fpair_a;
-            v2 += dz * dz * fpair_a;
-            v3 += dx * dy * fpair_a;
-            v4 += dx * dz * fpair_a;
-            v5 += dy * dz * fpair_a;
-          }
+          if (!(r <= qA[c].cut)) continue;
+          double pf;
+          const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
+          if (hotc && m >= P.wlo) continue;
+          ac0[c] += ys_val(glb_row(qA[c].trho, m), pf);
         }
       }
     };
@@ -955,63 +878,12 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
       if (cnt > split) cold_pass(std::integral_constant<int, 1>{});
     }
     // ---- results of the tile ----
-    if (MODE == PT_DENSITY) {
 #pragma unroll
-      for (int c = 0; c < CL; c++) ac0[c] = lane_sum<L>(ac0[c]);
-      if (s < CL) {
+    for (int c = 0; c < CL; c++) ac0[c] = lane_sum<L>(ac0[c]);
+    if (s < CL) {
 #pragma unroll
-        for (int c = 0; c < CL; c++)
-          if (c == s && metal[c]) P.rho[kc * CL + c] = ac0[c];
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CL; c++) {
-        ac0[c] = lane_sum<L>(ac0[c]);
-        ac1[c] = lane_sum<L>(ac1[c]);
-        ac2[c] = lane_sum<L>(ac2[c]);
-      }
-      double ev_e = 0.0;
-      if (EV && MODE == PT_FPHI) {
-#pragma unroll
-        for (int c = 0; c < CL; c++) {
-          ev_e += ea[c];
-          ea[c] = lane_sum<L>(ea[c]);
-        }
-      }
-      if (s < CL) {
-#pragma unroll
-        for (int c = 0; c < CL; c++)
-          if (c == s && real[c]) { // plain += : only writer of owned f here (stream order); the angular kernel follows
-            double *fo = P.f + 3 * (size_t) (kc * CL + c);
-            fo[0] += ac0[c];
-            fo[1] += ac1[c];
-            fo[2] += ac2[c];
-            if (EV && MODE == PT_FPHI && (P.eflag & MDP_EFLAG_ATOM)) P.eatom[kc * CL + c] += ea[c];
-          }
-      }
-      if (EV) {
-        double *slot = P.acc + MDP_ACC_STRIDE * (1 + ((blockIdx.x * NSUB + sub) & (MDP_ACC_SLOTS - 1)));
-        if (MODE == PT_FPHI && (P.eflag & MDP_EFLAG_GLOBAL)) {
-          ev_e = lane_sum<64>(ev_e);
-          if (lane == 0) atomicAdd(&slot[0], ev_e);
-        }
-        if (P.vflag & MDP_VFLAG_GLOBAL) {
-          v0 = lane_sum<64>(v0);
-          v1 = lane_sum<64>(v1);
-          v2 = lane_sum<64>(v2);
-          v3 = lane_sum<64>(v3);
-          v4 = lane_sum<64>(v4);
-          v5 = lane_sum<64>(v5);
-          if (lane == 0) {
-            atomicAdd(&slot[1], v0);
-            atomicAdd(&slot[2], v1);
-            atomicAdd(&slot[3], v2);
-            atomicAdd(&slot[4], v3);
-            atomicAdd(&slot[5], v4);
-            atomicAdd(&slot[6], v5);
-          }
-        }
-      }
+      for (int c = 0; c < CL; c++)
+        if (c == s && metal[c]) P.rho[kc * CL + c] = ac0[c];
     }
     // ---- the next tile's data goes to LDS ----
     __syncthreads();
@@ -1485,12 +1357,32 @@ __global__ void pair_der_kernel(const int npair, const int nm1, const int *__res
   o[5] = b[2];
 }
 
+// owned angular centres; count[0] = their number, count[2] = 1 when one of them sits in a tile at or behind
+// count[1] = the first tile whose union reaches a remote ghost (its row may then hold one: ghost forces must travel)
 __global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
-                                int *__restrict__ count)
+                                int *__restrict__ count, const int atoms_per_tile)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nlocal) return;
-  if ((int) xq[i].w >= A.nnonangular) list[atomicAdd(count, 1)] = i;
+  if ((int) xq[i].w >= A.nnonangular) {
+    list[atomicAdd(count, 1)] = i;
+    if (i / atoms_per_tile >= count[1]) count[2] = 1;
+  }
+}
+
+// count[1] = first tile whose union holds a remote ghost (index >= remote_start); tiles before it need no halo
+__global__ __launch_bounds__(256) void tile_first_remote_kernel(const int ntile, const int cap, const int remote_start,
+                                                                const int *__restrict__ tile_nu,
+                                                                const int *__restrict__ tu, int *__restrict__ count)
+{
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntile) return;
+  const int *mem = tu + (size_t) t * cap;
+  const int nU = tile_nu[2 * t];
+  int hit = 0;
+  for (int u = lane; u < nU; u += 64) hit |= mem[u] >= remote_start;
+  if (__any(hit) && lane == 0) atomicMin(&count[1], t);
 }
 
 inline int nblk(long long n, int per) { return (int) ((n + per - 1) / per); }
@@ -1520,14 +1412,12 @@ int mdp_aeam_prepare(mdp_ctx *c)
   MDP_HIP(c, c->fp.reserve(c->nall + 1));
   MDP_HIP(c, c->ang_list.reserve(c->nlocal + 1));
   MDP_HIP(c, c->ang_count.reserve(4));
-  MDP_HIP(c, hipMemsetAsync(c->ang_count.p, 0, sizeof(int), st));
-  if (c->nlocal)
-    ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p);
-  MDP_HIP(c, hipGetLastError());
-  MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof(int), &c->h_ang_count));
   // resident mode: tile lists next to the CSR list (which the angular kernels and the steps
   // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
   c->aeam_tiled = false;
+  c->aeam_split = 0;
+  c->aeam_ang_remote = false;
+  c->aeam_phase = 0;
   const char *e = getenv("MDP_AEAM_TILE");
   if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0)) {
     double cutsq[4];
@@ -1541,6 +1431,28 @@ int mdp_aeam_prepare(mdp_ctx *c)
     MDP_TRY(mdp_tile_lists_build(c, cutsq, c->aeam_cl, &ok));
     c->aeam_tiled = ok;
   }
+  {
+    // angular centres; with remote ghosts (multi-GPU): the first tile that reaches one -- the tiles before it run
+    // while the halo is in flight (domain.hip stores the shell atoms of the brick behind the interior ones)
+    const bool remote = c->md && c->remote_start < c->nall;
+    const int init[3] = {0, remote && c->aeam_tiled ? c->ntile : 0, 0};
+    MDP_TRY(mdp_write_small(c, c->ang_count.p, init, sizeof init));
+    if (remote && c->aeam_tiled)
+      tile_first_remote_kernel<<<nblk(c->ntile, 4), 256, 0, st>>>(c->ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
+                                                                  c->tu.p, c->ang_count.p);
+    if (c->nlocal)
+      ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p,
+                                                            kTile * c->aeam_cl);
+    MDP_HIP(c, hipGetLastError());
+    int h[3] = {0, 0, 0};
+    MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof h, h));
+    c->h_ang_count = h[0];
+    c->aeam_split = remote && c->aeam_tiled ? h[1] : 0;
+    c->aeam_ang_remote = remote && h[0] > 0 && (c->aeam_tiled ? h[2] != 0 : true);
+    if (getenv("MDP_DEBUG"))
+      fprintf(stderr, "[mdp] aeam: %d angular centres; tiles [0, %d) of %d reach no remote ghost; ghost forces %s\n", h[0],
+              c->aeam_split, c->ntile, c->aeam_ang_remote ? "travel" : "stay");
+  }
   if (!c->aeam_tiled && !c->csr_full) { // no tile lists after all (a union outgrew LDS): the CSR kernels need every row
     c->csr_want_full = true;
     MDP_TRY(mdp_md_build_master_list(c));
@@ -1548,9 +1460,10 @@ int mdp_aeam_prepare(mdp_ctx *c)
   return MDP_OK;
 }
 
-// Persistent tile kernels (above): geometry of the launch.  *done stays false when the window that fits LDS next to
-// the staging buffers would cover too little of the table -- the caller then runs the gather kernels.
-static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const int vflag, bool *done)
+// Persistent density kernel (above): geometry of the launch over the tiles [t_begin, t_end).  *done stays false when
+// the window that fits LDS next to the staging buffers would cover too little of the table -- the caller then runs
+// the gather kernel.
+static int aeam_ptile_launch(mdp_ctx *c, const int t_begin, const int t_end, bool *done)
 {
   *done = false;
   const char *epers = getenv("MDP_AEAM_PERSIST"); // unset: decided here; 0: never; 1: whenever a window fits
@@ -1568,10 +1481,9 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
     c->num_cu = n > 0 ? n : 256;
   }
   const AeamDev &A = c->aeam;
-  const int rec = mode == PT_FRHO ? 4 : 3;
   const int capL = (c->tile_maxu + 1 + 7) & ~7;
   const int rowcapB = (2 * c->tile_rowmax + 15) & ~15;
-  const size_t sub_bytes = (size_t) capL * rec * 8 + rowcapB;
+  const size_t sub_bytes = (size_t) capL * 3 * 8 + rowcapB;
   const int nr = A.nr[0]; // rows 1..nr of the (0,0) pair's table are addressed: m in [1, nr-1] and m+1
   const char *ens = getenv("MDP_AEAM_PT_NSUB");
   const int force_nsub = ens ? atoi(ens) : 0;
@@ -1591,23 +1503,26 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
     }
   }
   if (!nsub || nw < 2) return MDP_OK;
+  *done = true;
+  const int nt = t_end - t_begin;
+  if (nt <= 0) return MDP_OK;
   PTile P = {};
   P.nlocal = c->nlocal;
   P.nclus = c->nclus;
-  P.ntile = c->ntile;
   P.cap = c->tile_cap;
   P.capL = capL;
   P.rowcapB = rowcapB;
-  int grid = (c->ntile + nsub - 1) / nsub;
+  P.t_begin = t_begin;
+  P.t_end = t_end;
+  int grid = (nt + nsub - 1) / nsub;
   if (grid > c->num_cu) grid = c->num_cu;
-  P.per = (c->ntile + grid - 1) / grid;
-  grid = (c->ntile + P.per - 1) / P.per;
+  P.per = (nt + grid - 1) / grid;
+  grid = (nt + P.per - 1) / P.per;
   P.nw = nw;
   P.wlo = nr + 1 - nw;
-  P.lds_table = mode == PT_FPHI ? A.t2z2r[0] : A.t2rhor[0];
-  P.ys = mode == PT_FPHI ? A.z2r_ys : A.rhor_ys;
+  P.lds_table = A.t2rhor[0];
+  P.ys = A.rhor_ys;
   P.xq = c->xq.p;
-  P.fp = c->fp.p;
   P.tu = c->tu.p;
   P.tile_nu = c->tile_nu.p;
   P.lj_off = c->lj_off.p;
@@ -1615,11 +1530,6 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
   P.lj_split = c->prune_valid ? c->lj_split_in.p : c->lj_split.p;
   P.lj16 = c->prune_valid ? c->lj16_in.p : c->lj16.p;
   P.rho = c->rho.p;
-  P.f = c->f.p;
-  P.eatom = c->eatom.p;
-  P.acc = c->acc.p;
-  P.eflag = eflag;
-  P.vflag = vflag;
   {
     // the reference skips a pair when sqrt(rsq) > cut: the largest rsq that passes, found once on the host
     const double cut = A.cut[0];
@@ -1629,86 +1539,184 @@ static int aeam_ptile_launch(mdp_ctx *c, const int mode, const int eflag, const 
     P.hot_rsqmax = t;
   }
   const size_t lds = (size_t) nw * 16 + (size_t) nsub * sub_bytes;
-  const bool ev = eflag || vflag;
-#define MDP_PT(MODEV, NS, EVV)                                                                                        \
+#define MDP_PT(NS)                                                                                                    \
   do {                                                                                                                \
     if (c->aeam_cl == 2) {                                                                                            \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<MODEV, NS, 2, EVV>,                             \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<NS, 2>,                                         \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-      aeam_ptile_kernel<MODEV, NS, 2, EVV><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                           \
+      aeam_ptile_kernel<NS, 2><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                                       \
     } else {                                                                                                          \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<MODEV, NS, 1, EVV>,                             \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_ptile_kernel<NS, 1>,                                         \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-      aeam_ptile_kernel<MODEV, NS, 1, EVV><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                           \
+      aeam_ptile_kernel<NS, 1><<<grid, NS * 256, lds, c->stream>>>(c->aeam, P);                                       \
     }                                                                                                                 \
   } while (0)
-#define MDP_PT_NS(MODEV, EVV)                                                                                         \
-  do {                                                                                                                \
-    if (nsub == 4) MDP_PT(MODEV, 4, EVV);                                                                             \
-    else if (nsub == 3) MDP_PT(MODEV, 3, EVV);                                                                        \
-    else MDP_PT(MODEV, 2, EVV);                                                                                       \
-  } while (0)
-  if (mode == PT_DENSITY) MDP_PT_NS(PT_DENSITY, false);
-  else if (mode == PT_FRHO) {
-    if (ev) MDP_PT_NS(PT_FRHO, true);
-    else MDP_PT_NS(PT_FRHO, false);
-  } else {
-    if (ev) MDP_PT_NS(PT_FPHI, true);
-    else MDP_PT_NS(PT_FPHI, false);
-  }
-#undef MDP_PT_NS
+  if (nsub == 4) MDP_PT(4);
+  else if (nsub == 3) MDP_PT(3);
+  else MDP_PT(2);
 #undef MDP_PT
   MDP_HIP(c, hipGetLastError());
-  if (getenv("MDP_DEBUG") && !c->ptile_reported[mode]) {
-    c->ptile_reported[mode] = true;
-    fprintf(stderr, "[mdp] aeam persistent tile kernel mode %d: %d workgroups x %d sub-blocks, %d tiles each, window rows [%d, %d] of %d (%.1f KB), staging %zu B per sub-block\n",
-            mode, grid, nsub, P.per, P.wlo, nr, nr, nw * 16 / 1024.0, sub_bytes);
+  if (getenv("MDP_DEBUG") && !c->ptile_reported[0]) {
+    c->ptile_reported[0] = true;
+    fprintf(stderr, "[mdp] aeam persistent density kernel: %d workgroups x %d sub-blocks, %d tiles each, window rows [%d, %d] of %d (%.1f KB), staging %zu B per sub-block\n",
+            grid, nsub, P.per, P.wlo, nr, nr, nw * 16 / 1024.0, sub_bytes);
   }
-  *done = true;
   return MDP_OK;
 }
 
-// passes 1 + 2.  Leaves rho[], fp[] (= Fptmp*F') for owned atoms; embedding energy in the accumulators.
-int mdp_aeam_run_density(mdp_ctx *c, int eflag)
+// ---- one compute() in phases ---------------------------------------------------------------------------------------
+// A step of a multi-GPU run hides its exchanges behind the tiles that reach no remote ghost (tiles [0, aeam_split):
+// the shell atoms of a brick are stored behind the interior ones, csrc/domain.hip):
+//   A  mdp_aeam_run_begin        density of the interior tiles                     | position exchange in flight
+//   B  mdp_aeam_run_density      the other density tiles, angular centres, embedding (pair_aeam.cpp:158-303), and --
+//                                when A ran -- the three-body forces (they need the centre's own F' only,
+//                                pair_aeam.cpp:395-470), so that the forces on ghosts can travel early
+//   C  mdp_aeam_run_force_begin  force tiles of the interior                       | fp forward + force reverse in flight
+//   D  mdp_aeam_run_force        the other force tiles (+ three-body forces if not done), accumulators folded
+// A and C are optional: without them B and D do everything (one GPU, host mode, per-atom-virial steps, CSR lists).
+enum { AE_OPEN = 1, AE_DENS_INT = 2, AE_ANG_F = 4, AE_FORCE_INT = 8, AE_DENS = 16 };
+
+// force_clear + accumulators, once per compute
+static int aeam_open(mdp_ctx *c)
 {
+  if (c->aeam_phase & AE_OPEN) return MDP_OK;
   if (!c->have_aeam || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "aeam: tables / neighbor list not set");
+  MDP_TRY(mdp_acc_begin(c, true));
+  MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, c->stream));
+  c->aeam_phase |= AE_OPEN;
+  return MDP_OK;
+}
+
+// pass 1 of the metal centres over the tiles [t_begin, t_end)
+static int aeam_density_tiles(mdp_ctx *c, const int t_begin, const int t_end)
+{
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
-  MDP_TRY(mdp_acc_begin(c, true));
-  if (c->aeam_tiled) {
-    // resident runs walk rows pruned to the pairs within reach right now (tile_prune_kernel in rebomos.hip): a third
-    // of the entries of a list built with 1 A of skin on a 6.5 A cutoff are skin
-    double cut[4];
-    aeam_class_cuts(c, cut); // either visit of the pair may need the entry
-    MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin));
-  } else
-    c->prune_valid = false;
-  mdp_time_mark(c, 0);
+  if (t_end <= t_begin) return MDP_OK;
   bool persistent = false;
-  if (nlocal && c->aeam_tiled) MDP_TRY(aeam_ptile_launch(c, PT_DENSITY, 0, 0, &persistent));
-  if (persistent) {
-  } else if (nlocal && c->aeam_tiled) {
-    const int capL = (c->tile_maxu + 1 + 7) & ~7;
-    const bool multi = c->aeam.ntypes != 2; // per-entry types and an LDS parameter block (see par_fill)
-    const size_t lds = (size_t) capL * 3 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
+  MDP_TRY(aeam_ptile_launch(c, t_begin, t_end, &persistent));
+  if (persistent) return MDP_OK;
+  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const bool multi = c->aeam.ntypes != 2; // per-entry types and an LDS parameter block (see par_fill)
+  const size_t lds = (size_t) capL * 3 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
 #define MDP_ATD(CLV, MV)                                                                                             \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
       MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_density_kernel<CLV, MV>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_density_kernel<CLV, MV><<<c->ntile, 256, lds, st>>>(                                                    \
-        c->aeam, nlocal, c->nclus, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,                    \
+    aeam_tile_density_kernel<CLV, MV><<<t_end - t_begin, 256, lds, st>>>(                                             \
+        c->aeam, nlocal, c->nclus, t_begin, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,           \
         c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
         c->prune_valid ? c->lj16_in.p : c->lj16.p, c->rho.p);                                                         \
   } while (0)
-    if (multi) {
-      if (c->aeam_cl == 1) MDP_ATD(1, true);
-      else MDP_ATD(2, true);
-    } else {
-      if (c->aeam_cl == 1) MDP_ATD(1, false);
-      else MDP_ATD(2, false);
-    }
+  if (multi) {
+    if (c->aeam_cl == 1) MDP_ATD(1, true);
+    else MDP_ATD(2, true);
+  } else {
+    if (c->aeam_cl == 1) MDP_ATD(1, false);
+    else MDP_ATD(2, false);
+  }
 #undef MDP_ATD
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// pass 3, pair part, over the tiles [t_begin, t_end)
+static int aeam_force_tiles(mdp_ctx *c, const int t_begin, const int t_end, const int eflag, const int vflag)
+{
+  hipStream_t st = c->stream;
+  if (t_end <= t_begin) return MDP_OK;
+  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const bool multi = c->aeam.ntypes != 2;
+  const size_t lds = (size_t) capL * 4 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
+  const bool ev = eflag || vflag;
+#define MDP_ATF(CLV, EVV, MV)                                                                                        \
+  do {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                              \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV, EVV, MV>,                             \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+    aeam_tile_force_kernel<CLV, EVV, MV><<<t_end - t_begin, 256, lds, st>>>(                                          \
+        c->aeam, c->nlocal, c->nclus, t_begin, c->xq.p, c->fp.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p,            \
+        c->lj_off.p, c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,    \
+        c->prune_valid ? c->lj16_in.p : c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                       \
+  } while (0)
+#define MDP_ATF_M(CLV, EVV)                                                                                          \
+  do {                                                                                                                \
+    if (multi) MDP_ATF(CLV, EVV, true);                                                                               \
+    else MDP_ATF(CLV, EVV, false);                                                                                    \
+  } while (0)
+  if (c->aeam_cl == 1) {
+    if (ev) MDP_ATF_M(1, true);
+    else MDP_ATF_M(1, false);
+  } else {
+    if (ev) MDP_ATF_M(2, true);
+    else MDP_ATF_M(2, false);
+  }
+#undef MDP_ATF_M
+#undef MDP_ATF
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+static int aeam_ang_forces(mdp_ctx *c, const int vflag)
+{
+  if (c->h_ang_count)
+    aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, c->stream>>>(c->aeam, c->h_ang_count, c->ang_list.p,
+                                                                          c->xq.p, c->nb_off.p, c->nb.p, c->fp.p,
+                                                                          c->f.p, c->vatom.p, c->acc.p, c->flags.p,
+                                                                          vflag);
+  MDP_HIP(c, hipGetLastError());
+  c->aeam_phase |= AE_ANG_F;
+  return MDP_OK;
+}
+
+static void aeam_prune_cuts(const mdp_ctx *c, double cut[4]) { aeam_class_cuts(c, cut); } // either visit may need the entry
+
+// phase A.  Runs while this step's position exchange is in flight: the remote ghosts still hold the previous step's
+// positions, which the interior tiles never read.  A step that has to (re-)prune the rows -- the pruning reads every
+// atom's position -- leaves everything to phase B.
+int mdp_aeam_run_begin(mdp_ctx *c, int eflag, int vflag)
+{
+  c->aeam_phase = 0;
+  c->aeam_vflag = vflag;
+  if (!c->aeam_tiled || c->aeam_split <= 0 || (vflag & MDP_VFLAG_ATOM) || !c->nlocal) return MDP_OK;
+  if (const char *e = getenv("MDP_AEAM_OVERLAP"))
+    if (atoi(e) == 0) return MDP_OK;
+  double cut[4];
+  aeam_prune_cuts(c, cut);
+  bool due = false;
+  MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin, /*may_prune=*/false, &due));
+  if (due) return MDP_OK;
+  MDP_TRY(aeam_open(c));
+  mdp_span_begin(c, 5);
+  MDP_TRY(aeam_density_tiles(c, 0, c->aeam_split));
+  mdp_span_end(c, 5);
+  c->aeam_phase |= AE_DENS_INT;
+  return MDP_OK;
+}
+
+// phases B: passes 1 + 2.  Leaves rho[], fp[] (= Fptmp*F') for owned atoms; embedding energy in the accumulators.
+int mdp_aeam_run_density(mdp_ctx *c, int eflag)
+{
+  if (!c->have_aeam || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "aeam: tables / neighbor list not set");
+  if (c->aeam_phase & AE_DENS) c->aeam_phase = 0; // (a compute that was never closed by the force pass)
+  hipStream_t st = c->stream;
+  const int nlocal = c->nlocal;
+  const bool early = (c->aeam_phase & AE_DENS_INT) != 0;
+  MDP_TRY(aeam_open(c));
+  if (!early) {
+    if (c->aeam_tiled) {
+      // resident runs walk rows pruned to the pairs within reach right now (tile_prune_kernel in rebomos.hip): a third
+      // of the entries of a list built with 1 A of skin on a 6.5 A cutoff are skin
+      double cut[4];
+      aeam_prune_cuts(c, cut);
+      MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin, /*may_prune=*/true, nullptr));
+    } else
+      c->prune_valid = false;
+  }
+  mdp_span_begin(c, 0);
+  if (nlocal && c->aeam_tiled) {
+    MDP_TRY(aeam_density_tiles(c, early ? c->aeam_split : 0, c->ntile));
   } else if (nlocal) {
     const int grid = nblk(nlocal, 256 / AE_L);
     switch (c->aeam.ntypes) {
@@ -1719,70 +1727,60 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
       default: aeam_density_kernel<AE_L, MDP_AEAM_MAXT><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
     }
   }
-  mdp_time_mark(c, 1);
+  mdp_span_end(c, 0);
+  mdp_span_begin(c, 1);
   if (c->h_ang_count)
     aeam_density_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
                                                                      c->nb_off.p, c->nb.p, c->rho.p, c->flags.p);
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 2);
+  mdp_span_end(c, 1);
+  mdp_span_begin(c, 2);
   if (nlocal)
     aeam_embed_kernel<<<nblk(nlocal, 256), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->rho.p, c->fp.p, c->eatom.p,
                                                          c->acc.p, eflag, /*accumulate=*/0);
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 3);
+  mdp_span_end(c, 2);
+  c->aeam_phase |= AE_DENS;
+  if (early) { // the forces on ghosts are complete after this: their reverse exchange can start with the fp exchange
+    mdp_span_begin(c, 4);
+    MDP_TRY(aeam_ang_forces(c, c->aeam_vflag));
+    mdp_span_end(c, 4);
+  }
   return MDP_OK;
 }
 
-// pass 3.  f[0..nall) is zeroed first; owned forces complete except for the angular terms other ranks'
-// centres put on our atoms; ghost forces hold our angular centres' contributions.
+// phase C: needs fp of owned atoms and periodic self-images only
+int mdp_aeam_run_force_begin(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!(c->aeam_phase & AE_DENS_INT) || !(c->aeam_phase & AE_DENS) || (c->aeam_phase & AE_FORCE_INT)) return MDP_OK;
+  if ((vflag & MDP_VFLAG_ATOM) || vflag != c->aeam_vflag)
+    return mdp_fail(c, MDP_EINVAL, "aeam: vflag differs between the phases of one compute");
+  mdp_span_begin(c, 6);
+  MDP_TRY(aeam_force_tiles(c, 0, c->aeam_split, eflag, vflag));
+  mdp_span_end(c, 6);
+  c->aeam_phase |= AE_FORCE_INT;
+  return MDP_OK;
+}
+
+// phase D: pass 3.  Owned forces complete except for the angular terms other ranks' centres put on our atoms;
+// ghost forces hold our angular centres' contributions.
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
-  MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, st));
+  MDP_TRY(aeam_open(c)); // (force_clear; normally done by the density pass)
+  if ((c->aeam_phase & AE_ANG_F) && vflag != c->aeam_vflag)
+    return mdp_fail(c, MDP_EINVAL, "aeam: vflag differs between the phases of one compute");
   if (vflag & MDP_VFLAG_ATOM) {
     MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, st));
   }
-  bool persistent = false;
-  // (the force pass as two persistent passes -- rho' terms, phi' terms -- is correct and measured slower than the
-  //  gather kernel, which fetches both derivatives of a pair from one record: 1.4 ms against 0.65 ms; kept for tests)
-  const char *epf = getenv("MDP_AEAM_PERSIST_FORCE");
-  const bool persist_force = epf && atoi(epf) != 0;
-  if (persist_force && nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) {
-    MDP_TRY(aeam_ptile_launch(c, PT_FRHO, eflag, vflag, &persistent));
-    if (persistent) MDP_TRY(aeam_ptile_launch(c, PT_FPHI, eflag, vflag, &persistent));
-  }
-  if (persistent) {
-  } else if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
-    const int capL = (c->tile_maxu + 1 + 7) & ~7;
-    const bool multi = c->aeam.ntypes != 2;
-    const size_t lds = (size_t) capL * 4 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
-    const bool ev = eflag || vflag;
-#define MDP_ATF(CLV, EVV, MV)                                                                                        \
-  do {                                                                                                                \
-    if (lds > 48 * 1024)                                                                                              \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_tile_force_kernel<CLV, EVV, MV>,                             \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
-    aeam_tile_force_kernel<CLV, EVV, MV><<<c->ntile, 256, lds, st>>>(                                                 \
-        c->aeam, nlocal, c->nclus, c->xq.p, c->fp.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p, c->lj_off.p,           \
-        c->prune_valid ? c->lj_len_in.p : nullptr, c->prune_valid ? c->lj_split_in.p : c->lj_split.p,                 \
-        c->prune_valid ? c->lj16_in.p : c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag);                       \
-  } while (0)
-#define MDP_ATF_M(CLV, EVV)                                                                                          \
-  do {                                                                                                                \
-    if (multi) MDP_ATF(CLV, EVV, true);                                                                               \
-    else MDP_ATF(CLV, EVV, false);                                                                                    \
-  } while (0)
-    if (c->aeam_cl == 1) {
-      if (ev) MDP_ATF_M(1, true);
-      else MDP_ATF_M(1, false);
-    } else {
-      if (ev) MDP_ATF_M(2, true);
-      else MDP_ATF_M(2, false);
-    }
-#undef MDP_ATF_M
-#undef MDP_ATF
+  mdp_span_begin(c, 3);
+  if (nlocal && c->aeam_tiled && !(vflag & MDP_VFLAG_ATOM)) { // tile lists; per-atom virial steps keep the CSR kernel
+    // (the force pass as two persistent passes like the density's -- rho' terms, phi' terms, one LDS table each -- was
+    //  built and measured slower than this gather kernel, which fetches both derivatives of a pair from one record
+    //  and does the geometry once: 1.4 ms against 0.65 ms)
+    MDP_TRY(aeam_force_tiles(c, (c->aeam_phase & AE_FORCE_INT) ? c->aeam_split : 0, c->ntile, eflag, vflag));
   } else if (nlocal) {
     if (!c->csr_full) { // first per-atom-virial step of a tiled run: build the rows of the metal atoms now (and from now on)
       c->csr_want_full = true;
@@ -1802,13 +1800,14 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
     }
 #undef MDP_AF
   }
-  mdp_time_mark(c, 4);
-  if (c->h_ang_count)
-    aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, st>>>(c->aeam, c->h_ang_count, c->ang_list.p, c->xq.p,
-                                                                   c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->vatom.p,
-                                                                   c->acc.p, c->flags.p, vflag);
+  mdp_span_end(c, 3);
+  if (!(c->aeam_phase & AE_ANG_F)) {
+    mdp_span_begin(c, 4);
+    MDP_TRY(aeam_ang_forces(c, vflag));
+    mdp_span_end(c, 4);
+  }
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 5);
+  c->aeam_phase = 0;
   return mdp_acc_end(c, eflag || vflag); // force-only steps tally nothing: no slots to fold
 }
 

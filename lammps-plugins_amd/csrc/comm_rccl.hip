@@ -276,6 +276,68 @@ int mdp_dd_comm_reverse(mdp_ctx *c)
   return mdp_dd_reverse_unpack(c, D.sbuf.p);
 }
 
+// AEAM, per step, behind the interior force tiles: fp of the send list -> remote ghosts (pair_aeam.cpp:307) and --
+// with_reverse -- the forces three-body terms put on remote ghosts -> their owners (Comm::reverse_comm), both legs in
+// ONE group of ncclSend/ncclRecv on the communication stream.  _begin packs on the context's stream (the three-body
+// forces are final there: mdp_md_aeam_density after mdp_md_compute_begin) and folds the periodic self-images;
+// _end makes the context's stream wait, unpacks fp and adds the forces.  with_reverse must be the same on all ranks
+// (mdp_md_aeam_state out[3], reduced with mdp_dd_comm_allreduce at every reneighboring).
+int mdp_dd_comm_aeam_exchange_begin(mdp_ctx *c, int with_reverse)
+{
+  MDP_TRY(comm_require(c));
+  MdpDomain &D = c->dd;
+  MDP_TRY(mdp_md_fold_self_ghost_f(c));
+  D.aeam_pending = 0;
+  if (!D.nsend && !D.nrecv) return MDP_OK;
+  const int n = D.G.nranks;
+  RcclApi *R = rccl();
+  // sbuf: [fp out: nsend][f in: 3 nsend]   rbuf: [fp in: nrecv][f out: 3 nrecv]
+  MDP_HIP(c, D.sbuf.reserve((size_t) 4 * D.nsend + 8));
+  MDP_HIP(c, D.rbuf.reserve((size_t) 4 * D.nrecv + 8));
+  MDP_TRY(mdp_dd_forward_scalar_pack(c, D.sbuf.p));
+  if (with_reverse) MDP_TRY(mdp_dd_reverse_pack(c, D.rbuf.p + D.nrecv));
+  MDP_HIP(c, hipEventRecord(D.ev_packed, c->stream));
+  MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
+  MDP_NCCL(c, R->GroupStart());
+  ncclResult_t first = ncclSuccess; // (the group is always closed: see exchange())
+  size_t so = 0, ro = 0;
+  for (int q = 0; q < n && first == ncclSuccess; q++) {
+    const size_t ns = (size_t) D.bord_send[q], nr = (size_t) D.bord_recv[q];
+    if (ns) first = R->Send(D.sbuf.p + so, ns, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+    if (nr && first == ncclSuccess)
+      first = R->Recv(D.rbuf.p + ro, nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+    if (with_reverse) {
+      if (nr && first == ncclSuccess)
+        first = R->Send(D.rbuf.p + D.nrecv + 3 * ro, 3 * nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+      if (ns && first == ncclSuccess)
+        first = R->Recv(D.sbuf.p + D.nsend + 3 * so, 3 * ns, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+    }
+    so += ns;
+    ro += nr;
+  }
+  const ncclResult_t end = R->GroupEnd();
+  if (first != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclSend/ncclRecv -> %s", R->GetErrorString(first));
+  if (end != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclGroupEnd -> %s", R->GetErrorString(end));
+  MDP_HIP(c, hipEventRecord(D.ev_arrived, D.comm_stream));
+  D.fwd_pending = true;
+  D.aeam_pending = with_reverse ? 2 : 1;
+  return MDP_OK;
+}
+
+int mdp_dd_comm_aeam_exchange_end(mdp_ctx *c)
+{
+  MDP_TRY(comm_require(c));
+  MdpDomain &D = c->dd;
+  if (!D.aeam_pending) return MDP_OK;
+  MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_arrived, 0));
+  D.fwd_pending = false;
+  const int rev = D.aeam_pending == 2;
+  D.aeam_pending = 0;
+  MDP_TRY(mdp_dd_forward_scalar_unpack(c, D.rbuf.p));
+  if (rev) MDP_TRY(mdp_dd_reverse_unpack(c, D.sbuf.p + D.nsend));
+  return MDP_OK;
+}
+
 // thermo sums / the collective `check yes` decision: vals[n] <- sum (op 0) or max (op 1) over the ranks
 int mdp_dd_comm_allreduce(mdp_ctx *c, double *vals, int n, int op)
 {

@@ -136,9 +136,13 @@ __global__ __launch_bounds__(256) void dd_unpack_arrivals_kernel(const int n, co
 }
 
 // 3. storage order of the owned atoms: Hilbert key over the brick (lamda space) | tag, leavers behind everything
+// shell_last: atoms within the ghost cutoff of a brick face that has a remote neighbour (the only atoms whose lists
+// can reach a remote ghost, and the only ones on the send list) are stored behind all others -- so that "needs this
+// step's halo" is a RANGE of atoms, tiles and clusters, and the interior can be computed while the halo travels
 __global__ __launch_bounds__(256) void dd_order_key_kernel(const DdGeom G, const int n, const double4 *__restrict__ xq,
                                                            const int *__restrict__ tag, const int *__restrict__ dest,
-                                                           unsigned long long *__restrict__ key, int *__restrict__ idx)
+                                                           unsigned long long *__restrict__ key, int *__restrict__ idx,
+                                                           const int shell_last)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -153,7 +157,15 @@ __global__ __launch_bounds__(256) void dd_order_key_kernel(const DdGeom G, const
   unsigned c[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) c[d] = dd_cell10(lam[d] * G.g[d] - G.me[d]);
-  key[i] = ((unsigned long long) mdp_hilbert30(c[0], c[1], c[2]) << 32) | (unsigned) tag[i];
+  unsigned long long shell = 0;
+  if (shell_last) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const double u = lam[d] * G.g[d] - G.me[d], w = G.cutl[d] * G.g[d];
+      if ((G.g[d] > 1 || G.self_remote) && (u < w || u >= 1.0 - w)) shell = 1ull << 62;
+    }
+  }
+  key[i] = shell | ((unsigned long long) mdp_hilbert30(c[0], c[1], c[2]) << 32) | (unsigned) tag[i];
 }
 
 __global__ __launch_bounds__(256) void dd_permute_kernel(const int n, const int *__restrict__ perm,
@@ -566,7 +578,10 @@ int mdp_dd_migrate_end(mdp_ctx *c, int narrive, const double *d_buf)
   MDP_HIP(c, D.tag_tmp.reserve(room + 1));
   MDP_HIP(c, c->rmass.reserve((size_t) nnew + 1));
   if (ntot) {
-    dd_order_key_kernel<<<nblk(ntot), 256, 0, st>>>(G, ntot, c->xq.p, c->tag.p, D.dest.p, D.key_a.p, D.idx_a.p);
+    const char *esh = getenv("MDP_AEAM_SHELL_LAST"); // (0: plain Hilbert order, for comparison)
+    const int shell_last = c->cfg.style == 2 && !(esh && atoi(esh) == 0);
+    dd_order_key_kernel<<<nblk(ntot), 256, 0, st>>>(G, ntot, c->xq.p, c->tag.p, D.dest.p, D.key_a.p, D.idx_a.p,
+                                                    shell_last);
     MDP_HIP(c, hipGetLastError());
     MDP_TRY(sort_u64(c, D.key_a.p, D.key_b.p, D.idx_a.p, D.idx_b.p, (size_t) ntot, 64));
     if (c->cfg.style == 1) { // rebomos: element-sorted runs of 32 atoms for the one-atom-row tile lists

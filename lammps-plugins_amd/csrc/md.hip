@@ -729,6 +729,7 @@ int mdp_md_compute(mdp_ctx *c, int eflag, int vflag)
   if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
   if (c->cfg.style == 1) return mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true);
   // single-rank AEAM: density, self-image fp refresh, force, fold angular ghost forces
+  c->aeam_phase = 0;
   MDP_TRY(mdp_md_aeam_density(c, eflag));
   MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
   return mdp_md_fold_self_ghost_f(c);
@@ -740,6 +741,25 @@ int mdp_md_compute_begin(mdp_ctx *c, int eflag, int vflag)
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (!c->neigh_set) return mdp_fail(c, MDP_ESTATE, "neighbor list not built");
   if (c->cfg.style == 1) return mdp_rebomos_run_begin(c, eflag, vflag);
+  return mdp_aeam_run_begin(c, eflag, vflag);
+}
+
+int mdp_md_aeam_force_begin(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  if (c->cfg.style != 2) return mdp_fail(c, MDP_EINVAL, "not an aeam sub-domain");
+  return mdp_aeam_run_force_begin(c, eflag, vflag);
+}
+
+int mdp_md_aeam_state(mdp_ctx *c, int out[4])
+{
+  if (!c || !out) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  out[0] = c->aeam_phase;
+  out[1] = c->aeam_split;
+  out[2] = c->ntile;
+  out[3] = c->aeam_ang_remote ? 1 : 0;
   return MDP_OK;
 }
 
@@ -748,7 +768,10 @@ int mdp_md_compute_end(mdp_ctx *c, int eflag, int vflag)
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (c->cfg.style == 1) return mdp_rebomos_run_end(c, eflag, vflag);
-  return mdp_md_compute(c, eflag, vflag);
+  // one-rank aeam (or a host that does no exchange of its own): the rest of the compute
+  MDP_TRY(mdp_md_aeam_density(c, eflag));
+  MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
+  return mdp_md_fold_self_ghost_f(c);
 }
 
 int mdp_md_thermo(mdp_ctx *c, double out[9])

@@ -83,6 +83,33 @@ void mdp_time_mark(mdp_ctx *c, int k)
   (void) hipEventRecord(c->ev[k], c->stream);
   if (k == 0) c->ev_marks = 0;
   if (k + 1 > c->ev_marks) c->ev_marks = k + 1;
+  c->timing_spans = false;
+}
+
+static void span_events(mdp_ctx *c)
+{
+  if (c->ev_sb[0]) return;
+  for (int i = 0; i < 8; i++) {
+    (void) hipEventCreate(&c->ev_sb[i]);
+    (void) hipEventCreate(&c->ev_se[i]);
+  }
+}
+
+void mdp_span_begin(mdp_ctx *c, int k)
+{
+  if (!c->timing) return;
+  span_events(c);
+  if (!c->timing_spans) c->span_mask = 0;
+  c->timing_spans = true;
+  (void) hipEventRecord(c->ev_sb[k], c->stream);
+  c->span_mask &= ~(1u << k);
+}
+
+void mdp_span_end(mdp_ctx *c, int k)
+{
+  if (!c->timing || !c->ev_sb[0]) return;
+  (void) hipEventRecord(c->ev_se[k], c->stream);
+  c->span_mask |= 1u << k;
 }
 
 namespace {
@@ -672,7 +699,6 @@ int mdp_destroy(mdp_ctx *c)
   c->lj.release();
   c->tu.release();
   c->tmask.release();
-  c->tmask32.release();
   c->lj16_in.release();
   c->lj_len_in.release();
   c->lj_split_in.release();
@@ -732,6 +758,11 @@ int mdp_destroy(mdp_ctx *c)
   c->h_small = nullptr;
   if (c->ev_made)
     for (int i = 0; i < 8; i++) (void) hipEventDestroy(c->ev[i]);
+  if (c->ev_sb[0])
+    for (int i = 0; i < 8; i++) {
+      (void) hipEventDestroy(c->ev_sb[i]);
+      (void) hipEventDestroy(c->ev_se[i]);
+    }
   if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
   delete c;
   return MDP_OK;
@@ -765,7 +796,7 @@ double mdp_device_bytes(const mdp_ctx *c)
       c->eatom.bytes(), c->vatom.bytes(), c->acc.bytes(), c->flags.bytes(), c->nb_off.bytes(), c->nb.bytes(),
       c->cand_cnt.bytes(), c->cand_off.bytes(), c->cand.bytes(), c->lj_off.bytes(), c->lj_cnt.bytes(),
       c->lj.bytes(), c->cl_flag.bytes(), c->cl_pos.bytes(), c->cl_order.bytes(), c->lj_split.bytes(),
-      c->tu.bytes(), c->tmask.bytes(), c->tmask32.bytes(), c->lj16_in.bytes(), c->lj_len_in.bytes(),
+      c->tu.bytes(), c->tmask.bytes(), c->lj16_in.bytes(), c->lj_len_in.bytes(),
       c->lj_split_in.bytes(), c->xhold_prune.bytes(), c->tile_nu.bytes(), c->tile_flag.bytes(),
       c->lj16.bytes(), c->is_center.bytes(), c->class_list.bytes(), c->class_count.bytes(), c->pk_cand.bytes(),
       c->amask.bytes(), c->rev.bytes(), c->rev16.bytes(), c->ovf.bytes(), c->xhold_all.bytes(),
@@ -815,7 +846,17 @@ int mdp_get_timing(mdp_ctx *c, double ms[8])
 {
   if (!c || !ms) return MDP_EINVAL;
   for (int i = 0; i < 8; i++) ms[i] = 0.0;
-  if (!c->timing || !c->ev_made) return MDP_OK;
+  if (!c->timing || (!c->ev_made && !c->ev_sb[0])) return MDP_OK;
+  if (c->timing_spans) {
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; i++) {
+      float t = 0.f;
+      if (((c->span_mask >> i) & 1u) && hipEventElapsedTime(&t, c->ev_sb[i], c->ev_se[i]) == hipSuccess) ms[i] = t;
+    }
+    (void) hipGetLastError();
+    c->span_mask = 0; // (a span that the next compute does not record reads 0, not a stale time)
+    return MDP_OK;
+  }
   MDP_HIP(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i + 1 < c->ev_marks; i++) {
     float t = 0.f;

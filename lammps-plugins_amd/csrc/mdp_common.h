@@ -172,6 +172,7 @@ struct MdpDomain {
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   DevBuf<double> sbuf, rbuf, abuf; // abuf: the all-reduce's own words
   bool fwd_pending = false;        // a position exchange is in flight between _forward_begin and _forward_end
+  int aeam_pending = 0;            // the aeam fp (1) / fp + ghost force (2) exchange is in flight
   DevBuf<int> cnt_dev;
 };
 
@@ -241,7 +242,6 @@ struct mdp_ctx {
   int nclus = 0, cluster = MDP_CLUSTER;
   // halo overlap (multi-GPU): clusters whose lists reach no remote ghost come first in cl_order
   int remote_start = 1 << 30;
-  bool split_halo = false;        // Lennard-Jones tiles split interior / boundary (MDP_HALO_OVERLAP=lj)
   bool centre_split = false;      // REBO centres split interior / boundary (default with remote ghosts)
   DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
@@ -250,13 +250,11 @@ struct mdp_ctx {
   // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
   bool lj_tiled = false;
   int ntile = 0, tile_cap = 0, tile_maxu = 0, tile_rowmax = 0; // (rowmax: most row entries of one tile, generic builder)
-  int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: interior small/large, boundary small/large
+  int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: small / large unions (the last two are empty)
   bool lj_ordered = false;        // cl_order in use (otherwise natural order, everything in class 0)
   int tile_small = 0;             // largest union of the "small" launch classes
   DevBuf<int> tu;                 // [ntile][tile_cap] union members (atom index), Mo first then S
   DevBuf<unsigned short> tmask;   // [ntile][tile_cap] bit g: cluster g of the tile lists the member
-  DevBuf<unsigned> tmask32;       // the same for tiles of 32 one-atom rows (bit a: atom a of the tile)
-  int tile_rows = 16;             // rows per tile of the current lists: 16 (one or two atoms each) or 32 (one atom each)
   // dynamic pruning of the tile rows (resident mode): between two list builds the rows are re-filtered, from the
   // current positions, to the entries within window + prune_buf of a cluster atom; the kernels walk the pruned rows
   // until an atom has moved prune_buf/2 since (second trigger of moved_kernel), then they are pruned again
@@ -310,6 +308,10 @@ struct mdp_ctx {
   bool skin_set = false;
   bool csr_full = true;           // the CSR list holds rows for every owned atom (false: angular centres only)
   bool csr_want_full = false;     // a per-atom-virial step ran: keep building the full list
+  int aeam_split = 0;             // tiles [0, aeam_split) reach no remote ghost (0: no remote ghosts / no tile lists)
+  bool aeam_ang_remote = false;   // an angular centre may have a remote ghost in its row: ghost forces must travel
+  int aeam_phase = 0;             // phases of the current compute already done (aeam.hip)
+  int aeam_vflag = 0;             // vflag of the current compute (phase A hands it to the early three-body forces)
 
   // ---- binning (shared by the master-list builder and the cluster-list builder)
   MdpGrid grid;
@@ -336,6 +338,9 @@ struct mdp_ctx {
   // ---- timing
   bool timing = false;
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_sb[8] = {}, ev_se[8] = {}; // spans
+  unsigned span_mask = 0;                  // spans recorded since the last mark 0 / span reset
+  bool timing_spans = false;
   bool ev_made = false;
   int ev_marks = 0;
   double t_ms[8] = {};
@@ -383,19 +388,23 @@ int mdp_scan_exclusive_i64(mdp_ctx *c, const int *d_in, long long *d_out, int n)
 int mdp_rebomos_repack(mdp_ctx *c);
 int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4]);                 // (re-)prune the tile rows from the current positions
 void mdp_prune_adapt(mdp_ctx *c, double buf_max, bool fired);
-int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], double skin);      // trigger + pruning for a style without its own displacement check
+int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], double skin, bool may_prune, bool *due); // trigger + pruning for a style without its own displacement check
 int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok); // tile lists (cl atoms per cluster), two classes of atoms (type 0 | others); needs the bin grid
 int mdp_rebomos_run(mdp_ctx *c, int eflag, int vflag, bool zero_f);
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag);
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag);
 int mdp_aeam_prepare(mdp_ctx *c);
+int mdp_aeam_run_begin(mdp_ctx *c, int eflag, int vflag);       // interior density tiles (halo in flight)
 int mdp_aeam_run_density(mdp_ctx *c, int eflag);
+int mdp_aeam_run_force_begin(mdp_ctx *c, int eflag, int vflag); // interior force tiles (fp / ghost forces in flight)
 int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag);
 int mdp_md_build_master_list(mdp_ctx *c);
 int mdp_md_build_neighbors_impl(mdp_ctx *c);
 void mdp_dd_release(mdp_ctx *c); // frees everything domain.hip / comm_rccl.hip hold
 int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi[3]); // fills c->grid, cell_perm, cell_start
 void mdp_time_mark(mdp_ctx *c, int k);
+void mdp_span_begin(mdp_ctx *c, int k); // per-phase device time as independent (begin, end) event pairs: aeam
+void mdp_span_end(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
 int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq); // integrate kernel (+ displacement check)
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays

@@ -1537,9 +1537,8 @@ __global__ __launch_bounds__(256) void rebo_lj_vatom_kernel(const RebomosDev P, 
   }
 }
 
-// launch classes of the Lennard-Jones units (tiles or clusters): key = 2 * (reaches a remote ghost) + (tile
-// union too large for the small LDS allocation).  One-hot flags, scanned separately, give a stable order
-// [interior small | interior large | boundary small | boundary large].
+// launch classes of the Lennard-Jones tiles: key = (tile union too large for the small LDS allocation).  One-hot
+// flags, scanned separately, give a stable order [small | large] (keys 2, 3 -- is_bnd -- are not in use).
 __global__ void unit_class_kernel(const int n, const int *__restrict__ is_bnd, const int *__restrict__ tile_nu,
                                   const int small_limit, int *__restrict__ flag /* [4][n+1] */)
 {
@@ -1559,37 +1558,6 @@ __global__ void unit_order_kernel(const int n, const int *__restrict__ flag, con
 #pragma unroll
   for (int q = 0; q < 4; q++)
     if (flag[(size_t) q * (n + 1) + k]) order[base[q] + pos[(size_t) q * (n + 2) + k]] = k;
-}
-
-// does the cluster's list reach a remote ghost (index >= remote_start)?  Such clusters wait for the halo.
-__global__ __launch_bounds__(256) void cluster_boundary_kernel(const int nclus, const int remote_start,
-                                                               const long long *__restrict__ lj_off,
-                                                               const int *__restrict__ lj, int *__restrict__ is_int,
-                                                               int *__restrict__ is_bnd)
-{
-  constexpr int L = 16;
-  const int s = threadIdx.x % L;
-  const long long k64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
-  const bool have = k64 < nclus;
-  const int k = have ? (int) k64 : 0;
-  int hit = 0;
-  if (have)
-    for (long long q = lj_off[k] + s; q < lj_off[k + 1]; q += L) hit |= lj[q] >= remote_start;
-#pragma unroll
-  for (int o = L / 2; o > 0; o >>= 1) hit |= __shfl_xor(hit, o, 64);
-  if (have && s == 0) {
-    is_int[k] = !hit;
-    is_bnd[k] = hit;
-  }
-}
-
-__global__ void cluster_order_kernel(const int nclus, const int nint, const int *__restrict__ is_int,
-                                     const int *__restrict__ pos_int, const int *__restrict__ pos_bnd,
-                                     int *__restrict__ order)
-{
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nclus) return;
-  order[is_int[k] ? pos_int[k] : nint + pos_bnd[k]] = k; // stable: Morton locality survives inside each part
 }
 
 // cluster pair list straight from the bin grid: every atom j within rcLJmax+skin of ANY atom of the
@@ -1956,9 +1924,6 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const int cap, const int
   }
 }
 
-__global__ void tile32_sort_kernel(const int cap, const int *__restrict__ tile_nu, int *__restrict__ tu,
-                                   unsigned *__restrict__ tmask); // (tiles of 32 one-atom rows, below)
-
 static int tile_sort_launch(mdp_ctx *c, int ntile)
 {
   if (const char *e = getenv("MDP_TILE_SORT"))
@@ -1966,13 +1931,6 @@ static int tile_sort_launch(mdp_ctx *c, int ntile)
   int np = 2;
   while (np < c->tile_maxu) np <<= 1;
   const size_t lds = (size_t) np * sizeof(unsigned long long);
-  if (c->tile_rows == 32) {
-    if (lds > 48 * 1024)
-      MDP_HIP(c, hipFuncSetAttribute((const void *) tile32_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    tile32_sort_kernel<<<ntile, 256, lds, c->stream>>>(c->tile_cap, c->tile_nu.p, c->tu.p, c->tmask32.p);
-    MDP_HIP(c, hipGetLastError());
-    return MDP_OK;
-  }
   if (lds > 48 * 1024)
     MDP_HIP(c, hipFuncSetAttribute((const void *) tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   tile_sort_kernel<<<ntile, 256, lds, c->stream>>>(c->tile_cap, c->tile_nu.p, c->tu.p, c->tmask.p);
@@ -2137,581 +2095,6 @@ __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, 
     uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(lj16_in + rb);
     for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tile lists with ONE ATOM PER ROW ("rows32", MDP_LJ_ROWS=32; measured, not the default): a tile is 32 consecutive atoms
-// = one workgroup, 8 lanes per atom.  A two-atom row walks the UNION of two neighbourhoods -- a fifth of its
-// entries belong to the partner only, and a Mo-S pair of atoms drags each other's longer windows along; with one
-// atom per row every entry tested is in reach of THAT atom with ITS windows.  Atoms are stored element-sorted
-// inside every run of 32 (csrc/domain.hip, host_sort_atoms), so that the eight atoms sharing a wave -- whose
-// padded segment lengths must agree -- are mostly of one element.  Union, 16-bit rows, padding rules, pruning
-// and launch classes are those of the two-atom layout above.
-// ------------------------------------------------------------------------------------------------
-#define MDP_T32 32 // atoms (= rows) per tile
-constexpr int kL32 = 8; // lanes per row
-
-// Pass 1 (see tile_scan_kernel): union of the tile, 32-bit mask per member (bit a: atom a of the tile lists it),
-// padded row lengths
-__global__ __launch_bounds__(256) void tile32_scan_kernel(const MdpGrid g, const RebomosDev P, const int nlocal,
-                                                          const double4 *__restrict__ xq, const int *__restrict__ perm,
-                                                          const int *__restrict__ cell_start, const int cap,
-                                                          int *__restrict__ tu, unsigned *__restrict__ tmask,
-                                                          int *__restrict__ tile_nu, int *__restrict__ cnt,
-                                                          int *__restrict__ split, int *__restrict__ tile_flag)
-{
-  constexpr int NA = MDP_T32;
-  extern __shared__ int s_dyn[];
-  const int wcap = cap / 2; // per-wave segment (a wave sees about a quarter of the union)
-  int *s_idx = s_dyn;                                    // [4][wcap]
-  unsigned *s_m = (unsigned *) (s_dyn + 4 * wcap);       // [4][wcap]
-  unsigned *s_fm = s_m + 4 * wcap;                       // [cap] masks in final order
-  __shared__ double4 s_xa[NA];
-  __shared__ double s_cut[NA][2];
-  __shared__ int s_lo[3], s_hi[3], s_n0[4], s_n1[4], s_over, s_rowsum;
-  const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid < 3) {
-    s_lo[tid] = 1 << 30;
-    s_hi[tid] = -1;
-  }
-  if (tid == 0) s_over = s_rowsum = 0;
-  __syncthreads();
-  if (tid < NA) {
-    const int ia = t * NA + tid;
-    bool valid = ia < nlocal;
-    const double4 xa = xq[valid ? ia : (nlocal > 0 ? nlocal - 1 : 0)];
-    const int ta = (int) xa.w;
-    if (ta < 0) valid = false; // NULL-mapped atom: lists nothing
-    s_xa[tid] = xa;
-    s_cut[tid][0] = valid ? P.ljlist_cutsq[ta * 2 + 0] : -1.0;
-    s_cut[tid][1] = valid ? P.ljlist_cutsq[ta * 2 + 1] : -1.0;
-    if (valid) {
-      int cc[3];
-      cc[0] = (int) ((xa.x - g.lo[0]) * g.inv[0]);
-      cc[1] = (int) ((xa.y - g.lo[1]) * g.inv[1]);
-      cc[2] = (int) ((xa.z - g.lo[2]) * g.inv[2]);
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        cc[d] = cc[d] < 0 ? 0 : (cc[d] >= g.n[d] ? g.n[d] - 1 : cc[d]);
-        atomicMin(&s_lo[d], cc[d]);
-        atomicMax(&s_hi[d], cc[d]);
-      }
-    }
-  }
-  __syncthreads();
-  const int R = g.range;
-  const bool any = s_hi[0] >= 0;
-  const int xlo = max(s_lo[0] - R, 0), xhi = min(s_hi[0] + R, g.n[0] - 1);
-  const int ylo = max(s_lo[1] - R, 0), yhi = min(s_hi[1] + R, g.n[1] - 1);
-  const int zlo = max(s_lo[2] - R, 0), zhi = min(s_hi[2] + R, g.n[2] - 1);
-  const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
-  const int nrows = any ? ny * nz : 0;
-  int *seg_i = s_idx + wave * wcap;
-  unsigned *seg_m = s_m + wave * wcap;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  int n0 = 0, n1 = 0;
-  bool over = false;
-  constexpr int kRows = 256;
-  __shared__ int s_pb[kRows], s_off[kRows + 1], s_wsum[4];
-  for (int rbase = 0; rbase < nrows; rbase += kRows) {
-    const int nr = nrows - rbase < kRows ? nrows - rbase : kRows;
-    int pb = 0, len = 0;
-    if (tid < nr) {
-      const int r = rbase + tid;
-      const int y = ylo + r % ny, z = zlo + r / ny;
-      pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
-      len = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1] - pb;
-    }
-    int incl = len;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += s_wsum[w];
-    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    s_pb[tid] = pb;
-    s_off[tid] = wbase + incl - len;
-    if (tid == 0) s_off[kRows] = total;
-    __syncthreads();
-    for (int g0 = wave * 64; g0 < total && !over; g0 += 256) {
-      const int gi = g0 + lane;
-      unsigned m = 0;
-      int j = 0, tj = 0;
-      if (gi < total) {
-        int lo = 0, hi = kRows; // s_off[lo] <= gi < s_off[hi]  (rows past nr are empty: offset = total)
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-          const int mid = (lo + hi) >> 1;
-          if (s_off[mid] <= gi) lo = mid;
-          else hi = mid;
-        }
-        j = perm[s_pb[lo] + gi - s_off[lo]];
-        const double4 xj = xq[j];
-        tj = (int) xj.w;
-        if (tj >= 0) {
-#pragma unroll 8
-          for (int a = 0; a < NA; a++) {
-            const double4 xa = s_xa[a];
-            const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
-            if (dx * dx + dy * dy + dz * dz <= s_cut[a][tj]) m |= 1u << a;
-          }
-        }
-      }
-      const bool k0 = m != 0 && tj == 0, k1 = m != 0 && tj != 0;
-      const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
-      const int c0 = __popcll(b0), c1 = __popcll(b1);
-      if (n0 + n1 + c0 + c1 > wcap) {
-        over = true;
-        break;
-      }
-      if (k0) {
-        const int pos = n0 + __popcll(b0 & below);
-        seg_i[pos] = j;
-        seg_m[pos] = m;
-      }
-      if (k1) {
-        const int pos = wcap - 1 - (n1 + __popcll(b1 & below));
-        seg_i[pos] = j;
-        seg_m[pos] = m;
-      }
-      n0 += c0;
-      n1 += c1;
-    }
-    __syncthreads(); // (s_pb / s_off are rewritten by the next block of rows)
-  }
-  if (lane == 0) {
-    s_n0[wave] = n0;
-    s_n1[wave] = n1;
-    if (over) s_over = 1;
-  }
-  __syncthreads();
-  const int N0 = s_n0[0] + s_n0[1] + s_n0[2] + s_n0[3];
-  const int N1 = s_n1[0] + s_n1[1] + s_n1[2] + s_n1[3];
-  const int nU = N0 + N1;
-  if (s_over || nU > cap - 1) { // (slot nU is the kernel's dummy entry, so nU <= cap-1)
-    if (tid == 0) {
-      atomicOr(&tile_flag[0], 1);
-      tile_nu[2 * t] = tile_nu[2 * t + 1] = 0;
-    }
-    if (tid < NA) cnt[t * NA + tid] = split[t * NA + tid] = 0;
-    return;
-  }
-  int base0 = 0, base1 = N0;
-  for (int w = 0; w < wave; w++) {
-    base0 += s_n0[w];
-    base1 += s_n1[w];
-  }
-  int *mem = tu + (size_t) t * cap;
-  unsigned *mm = tmask + (size_t) t * cap;
-  for (int i = lane; i < n0; i += 64) {
-    const int u = base0 + i;
-    const unsigned m = seg_m[i];
-    mem[u] = seg_i[i];
-    mm[u] = m;
-    s_fm[u] = m;
-  }
-  for (int i = lane; i < n1; i += 64) {
-    const int u = base1 + i, src = wcap - 1 - i;
-    const unsigned m = seg_m[src];
-    mem[u] = seg_i[src];
-    mm[u] = m;
-    s_fm[u] = m;
-  }
-  __syncthreads();
-  // row lengths: 8 lanes per row; both segments padded with the dummy index to whole 8-lane steps AND to the
-  // longest of the eight rows that share a wave in the compute kernel (wave-uniform loops)
-  const int gq = tid / kL32, sq = tid % kL32;
-  int c0 = 0, c1 = 0;
-  for (int u = sq; u < nU; u += kL32) {
-    const int bit = (s_fm[u] >> gq) & 1;
-    c0 += u < N0 ? bit : 0;
-    c1 += u < N0 ? 0 : bit;
-  }
-#pragma unroll
-  for (int o = kL32 / 2; o > 0; o >>= 1) {
-    c0 += __shfl_xor(c0, o, 64);
-    c1 += __shfl_xor(c1, o, 64);
-  }
-  int p0 = (c0 + kL32 - 1) & ~(kL32 - 1), p1 = (c1 + kL32 - 1) & ~(kL32 - 1);
-#pragma unroll
-  for (int o = kL32; o < 64; o <<= 1) {
-    p0 = max(p0, __shfl_xor(p0, o, 64));
-    p1 = max(p1, __shfl_xor(p1, o, 64));
-  }
-  const int kr = t * NA + gq;
-  if (sq == 0) {
-    cnt[kr] = p0 + p1;
-    split[kr] = p0;
-    atomicAdd(&s_rowsum, p0 + p1);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    tile_nu[2 * t] = nU;
-    tile_nu[2 * t + 1] = N0;
-    atomicMax(&tile_flag[1], nU);
-    atomicMax(&tile_flag[2], s_rowsum); // row entries of the whole tile (the pruning kernel stages a tile's rows in LDS)
-  }
-}
-
-// members of a union sorted by atom index, each element segment by itself (see tile_sort_kernel)
-__global__ __launch_bounds__(256) void tile32_sort_kernel(const int cap, const int *__restrict__ tile_nu,
-                                                          int *__restrict__ tu, unsigned *__restrict__ tmask)
-{
-  extern __shared__ unsigned long long s_key[];
-  const int t = blockIdx.x, tid = threadIdx.x;
-  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1];
-  int *mem = tu + (size_t) t * cap;
-  unsigned *mm = tmask + (size_t) t * cap;
-  for (int seg = 0; seg < 2; seg++) {
-    const int b = seg ? N0 : 0, n = (seg ? nU : N0) - b;
-    if (n <= 1) continue; // (block-uniform)
-    int np = 2;
-    while (np < n) np <<= 1;
-    for (int i = tid; i < np; i += 256)
-      s_key[i] = i < n ? (((unsigned long long) (unsigned) mem[b + i]) << 32) | mm[b + i] : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= np; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < np; i += 256) {
-          const int p = i ^ j;
-          if (p > i) {
-            const unsigned long long x = s_key[i], y = s_key[p];
-            if ((x > y) == ((i & k) == 0)) {
-              s_key[i] = y;
-              s_key[p] = x;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    for (int i = tid; i < n; i += 256) {
-      const unsigned long long v = s_key[i];
-      mem[b + i] = (int) (v >> 32);
-      mm[b + i] = (unsigned) (v & 0xFFFFFFFFull);
-    }
-    __syncthreads();
-  }
-}
-
-// Pass 2: each row (8 lanes) walks its tile's masks in union order and keeps the entries with its bit
-__global__ __launch_bounds__(256) void tile32_fill_kernel(const int cap, const int *__restrict__ tile_nu,
-                                                          const unsigned *__restrict__ tmask,
-                                                          const long long *__restrict__ off,
-                                                          const int *__restrict__ split,
-                                                          unsigned short *__restrict__ lj16)
-{
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int gq = tid / kL32, sq = tid % kL32, glane0 = lane - sq;
-  const int kr = t * MDP_T32 + gq;
-  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1];
-  const unsigned *mm = tmask + (size_t) t * cap;
-  const long long b = off[kr];
-  const int len[2] = {split[kr], (int) (off[kr + 1] - b) - split[kr]}; // padded segment lengths (tile32_scan_kernel)
-  unsigned short *row = lj16 + b;
-  const unsigned long long below = (1ull << sq) - 1ull;
-  for (int seg = 0; seg < 2; seg++) {
-    const int ub = seg ? N0 : 0, ue = seg ? nU : N0;
-    int n = 0;
-    for (int base = ub; base < ue; base += kL32) {
-      const int u = base + sq;
-      const bool k = u < ue && ((mm[u] >> gq) & 1u);
-      const unsigned long long bal = (__ballot(k) >> glane0) & 0xFFull;
-      if (k) row[n + __popcll(bal & below)] = (unsigned short) u;
-      n += __popcll(bal);
-    }
-    for (int q = n + sq; q < len[seg]; q += kL32) row[q] = (unsigned short) nU; // padding: the dummy slot
-    row += len[seg];
-  }
-}
-
-// dynamic pruning of one-atom rows (see tile_prune_kernel)
-__global__ __launch_bounds__(256) void tile32_prune_kernel(const PruneLimits lim, const int nlocal,
-                                                           const double4 *__restrict__ xq, const int cap, const int capL,
-                                                           const int *__restrict__ tu, const int *__restrict__ tile_nu,
-                                                           const long long *__restrict__ lj_off,
-                                                           const int *__restrict__ lj_split,
-                                                           const unsigned short *__restrict__ lj16,
-                                                           unsigned short *__restrict__ lj16_in,
-                                                           int *__restrict__ len_in, int *__restrict__ split_in)
-{
-  constexpr int L = kL32, SK = 3;
-  extern __shared__ double s_pos[]; // [capL][3], then the rows
-  unsigned short *__restrict__ s_rows = reinterpret_cast<unsigned short *>(s_pos + 3 * (size_t) capL);
-  const int tid = threadIdx.x, lane = tid & 63, s = lane % L, glane0 = lane - s;
-  const int t = blockIdx.x;
-  const int kr = t * MDP_T32 + tid / L; // row = atom
-  const int nU = tile_nu[2 * t];
-  const int *__restrict__ mem = tu + (size_t) t * cap;
-  const long long rb = lj_off[(size_t) t * MDP_T32];
-  const int rtot = (int) (lj_off[(size_t) t * MDP_T32 + MDP_T32] - rb); // entries of the whole tile (multiple of 8)
-  {
-    int sidx[SK];
-#pragma unroll
-    for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // (rows are cap >= 2048 long: always in bounds)
-    double4 sv[SK];
-#pragma unroll
-    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(lj16 + rb);
-    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(s_rows);
-    for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
-#pragma unroll
-    for (int k = 0; k < SK; k++) {
-      const int u = tid + 256 * k;
-      if (u < nU) {
-        s_pos[3 * u] = sv[k].x;
-        s_pos[3 * u + 1] = sv[k].y;
-        s_pos[3 * u + 2] = sv[k].z;
-      }
-    }
-    for (int u = tid + 256 * SK; u < nU; u += 256) {
-      const double4 v = xq[mem[u]];
-      s_pos[3 * u] = v.x;
-      s_pos[3 * u + 1] = v.y;
-      s_pos[3 * u + 2] = v.z;
-    }
-  }
-  const long long b = lj_off[kr];
-  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kr + 1] - b));
-  const int split = __builtin_amdgcn_readfirstlane(lj_split[kr]);
-  unsigned short *__restrict__ row = s_rows + (int) (b - rb);
-  bool real = kr < nlocal;
-  const double4 xa = xq[real ? kr : nlocal - 1];
-  int ta = (int) xa.w;
-  if (ta < 0) { // type mapped to NULL: takes part in nothing
-    real = false;
-    ta = 0;
-  }
-  __syncthreads();
-  const unsigned long long below = (1ull << s) - 1ull;
-  int pseg[2];
-  int base = 0;
-#pragma unroll
-  for (int seg = 0; seg < 2; seg++) {
-    const int kb = seg ? split : 0, ke = seg ? cnt : split;
-    const double lim_c = lim.rsq[ta * 2 + seg];
-    int n = 0;
-    for (int k = kb; k < ke; k += L) { // (segments are whole 8-lane steps, equally long for the rows of a wave)
-      const int li = (int) row[k + s];
-      bool keep = false;
-      if (li < nU) {
-        const double dx = xa.x - s_pos[3 * li], dy = xa.y - s_pos[3 * li + 1], dz = xa.z - s_pos[3 * li + 2];
-        keep = real && dx * dx + dy * dy + dz * dz <= lim_c;
-      }
-      const unsigned long long gb = (__ballot(keep) >> glane0) & 0xFFull;
-      // (the read of this trip is complete for the whole wave before any lane writes: same instruction stream)
-      if (keep) row[base + n + __popcll(gb & below)] = (unsigned short) li;
-      n += __popcll(gb);
-    }
-    int p = (n + L - 1) & ~(L - 1);
-#pragma unroll
-    for (int o = L; o < 64; o <<= 1) p = max(p, __shfl_xor(p, o, 64));
-    for (int q = n + s; q < p; q += L) row[base + q] = (unsigned short) nU; // padding: the dummy slot
-    pseg[seg] = p;
-    base += p;
-  }
-  if (s == 0) {
-    split_in[kr] = pseg[0];
-    len_in[kr] = pseg[0] + pseg[1];
-  }
-  __syncthreads();
-  {
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(s_rows);
-    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(lj16_in + rb);
-    for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
-  }
-}
-
-// Lennard-Jones + REBO slot gather over one-atom rows: see rebo_lj_tile_kernel for the structure (union staged in
-// LDS once, 16-bit rows, wave-uniform padded segments, index prefetch two trips ahead, cubic spline only flagged)
-template <bool EV, bool GATHER, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void rebo_lj_tile32_kernel(
-    const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first,
-    const double4 *__restrict__ xq, const int cap, const int capL, const int skip_above,
-    const int *__restrict__ tu, const int *__restrict__ tile_nu, const long long *__restrict__ lj_off,
-    const int *__restrict__ lj_len /* row lengths of the pruned rows, or null: the rows as built */,
-    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, const int *__restrict__ cand_off,
-    const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const int *__restrict__ rev16,
-    const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
-    double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag, const int accumulate)
-{
-  constexpr int L = kL32, SK = 3;
-  extern __shared__ double s_pos[]; // [capL][3]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int s = lane % L;
-  const int bx = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int t = order ? order[first + bx] : first + bx;
-  const int ia = t * MDP_T32 + tid / L; // row = atom (every tile has 32 rows; absent atoms: all-dummy rows)
-
-  // first round of loads: everything that depends on the tile number alone
-  const int nU_all = tile_nu[2 * t];
-  const bool live = nU_all <= skip_above;
-  const int nU = live ? nU_all : 0;
-  const bool have = ia < nlocal && live;
-  const int *__restrict__ mem = tu + (size_t) t * cap;
-  int sidx[SK];
-#pragma unroll
-  for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k]; // rows are cap >= 2048 long: always in bounds
-  const long long b = lj_off[ia];
-  // segment lengths are equal for the eight rows of a wave by construction (tile32_scan_kernel): scalars
-  const int cnt = __builtin_amdgcn_readfirstlane(live ? (lj_len ? lj_len[ia] : (int) (lj_off[ia + 1] - b)) : 0);
-  const int split = __builtin_amdgcn_readfirstlane(live ? lj_split[ia] : 0);
-  const unsigned short *__restrict__ row = lj16 + b;
-  const int ia_c = have ? ia : (nlocal > 0 ? nlocal - 1 : 0);
-  double4 xa = xq[ia_c];
-  // second round: the coordinates of the union, the head of both row segments ...
-  {
-    double4 sv[SK];
-#pragma unroll
-    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
-#pragma unroll
-    for (int k = 0; k < SK; k++) {
-      const int u = tid + 256 * k;
-      if (u < nU) {
-        s_pos[3 * u] = sv[k].x;
-        s_pos[3 * u + 1] = sv[k].y;
-        s_pos[3 * u + 2] = sv[k].z;
-      }
-    }
-  }
-  for (int u = tid + 256 * SK; u < nU; u += 256) {
-    const double4 v = xq[mem[u]];
-    s_pos[3 * u] = v.x;
-    s_pos[3 * u + 1] = v.y;
-    s_pos[3 * u + 2] = v.z;
-  }
-  if (tid == 0) { // slot nU: what the padding entries of the rows point at -- outside every window
-    s_pos[3 * nU] = 1.0e30;
-    s_pos[3 * nU + 1] = 0.0;
-    s_pos[3 * nU + 2] = 0.0;
-  }
-  int jh[2][3]; // first 3 entries per lane of the Mo segment and of the S segment
-#pragma unroll
-  for (int seg = 0; seg < 2; seg++) {
-#pragma unroll
-    for (int u = 0; u < 3; u++) jh[seg][u] = (int) row[(seg ? split : 0) + u * L + s];
-  }
-  // ... and the REBO slot forces of this atom: own centre (-sum of its slot forces) plus what the neighbour centres
-  // push onto it through the reverse slots; 8 lanes cover 16 slots, two each, every load unconditional
-  double gx = 0, gy = 0, gz = 0, ge = 0;
-  if (GATHER) {
-    const int t0 = s, t1 = s + L;
-    const unsigned long long g_act = have ? amask[ia_c] : 0ull;
-    const int r0 = rev16[(size_t) ia_c * 16 + t0], r1 = rev16[(size_t) ia_c * 16 + t1];
-    const double4 own = reinterpret_cast<const double4 *>(fown)[ia_c]; // the centre's own share
-    const bool ok0 = ((g_act >> t0) & 1ull) && r0 >= 0, ok1 = ((g_act >> t1) & 1ull) && r1 >= 0;
-    const double4 a0 = reinterpret_cast<const double4 *>(fnbr)[ok0 ? r0 : 0];
-    const double4 a1 = reinterpret_cast<const double4 *>(fnbr)[ok1 ? r1 : 0];
-    if (have && s == 0) {
-      gx = own.x;
-      gy = own.y;
-      gz = own.z;
-      ge = own.w;
-    }
-    gx += (ok0 ? a0.x : 0.0) + (ok1 ? a1.x : 0.0);
-    gy += (ok0 ? a0.y : 0.0) + (ok1 ? a1.y : 0.0);
-    gz += (ok0 ? a0.z : 0.0) + (ok1 ? a1.z : 0.0);
-    ge += (ok0 ? a0.w : 0.0) + (ok1 ? a1.w : 0.0);
-    if (g_act >> 16) { // rare: more than 16 candidates, the rest through the row itself
-      const int g_off = cand_off[ia_c];
-      const int g_nc = cand_off[ia_c + 1] - g_off;
-      for (int tt = 16 + s; tt < g_nc; tt += L) {
-        if (!((g_act >> tt) & 1ull)) continue;
-        const int ra = rev[g_off + tt];
-        if (ra >= 0) {
-          const double4 oj = reinterpret_cast<const double4 *>(fnbr)[ra];
-          gx += oj.x;
-          gy += oj.y;
-          gz += oj.z;
-          ge += oj.w;
-        }
-      }
-    }
-  }
-
-  int ta = (int) xa.w;
-  bool real = have;
-  if (ta < 0) { // type mapped to NULL: takes part in nothing
-    real = false;
-    ta = 0;
-  }
-  if (!real) xa.x = -1.0e30; // padding / NULL atom: outside every window
-  double fx[1] = {gx}, fy[1] = {gy}, fz[1] = {gz}, ee[1] = {0.0};
-  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-  __syncthreads();
-
-  unsigned long long cub = 0;
-  auto segment = [&](auto segc) {
-    constexpr int SEG = decltype(segc)::value;
-    const int kb = SEG ? split : 0, ke = SEG ? cnt : split;
-    const LJPar q = lj_select(P, ta, SEG);
-    int je, jo;
-    double4 xe, xo;
-    const unsigned short *__restrict__ rp = row + kb + s; // this lane's column of the segment
-    {
-      const double *p = s_pos + 3 * jh[SEG][0]; // iteration 0
-      xe = make_double4(p[0], p[1], p[2], 0.0);
-      jo = jh[SEG][1]; // iteration 1
-      je = jh[SEG][2]; // iteration 2
-    }
-#pragma unroll 1
-    for (int k0 = kb; k0 < ke; k0 += 2 * L) {
-      {
-        const double *p = s_pos + 3 * jo;
-        xo = make_double4(p[0], p[1], p[2], 0.0);
-      }
-      jo = (int) rp[3 * L];
-      lj_pair_fast<EV>(q, xa, xe, fx[0], fy[0], fz[0], ee[0], vflag, v0, v1, v2, v3, v4, v5, cub);
-      {
-        const double *p = s_pos + 3 * je;
-        xe = make_double4(p[0], p[1], p[2], 0.0);
-      }
-      je = (int) rp[4 * L];
-      rp += 2 * L;
-      if (k0 + L < ke) lj_pair_fast<EV>(q, xa, xo, fx[0], fy[0], fz[0], ee[0], vflag, v0, v1, v2, v3, v4, v5, cub);
-    }
-  };
-  segment(std::integral_constant<int, 0>{});
-  segment(std::integral_constant<int, 1>{});
-
-  // rare: some pair sat on the cubic inner spline -- walk the row again and replace those pairs
-  if (cub) {
-    for (int k = s; k < cnt; k += L) {
-      const int li = row[k], seg = k < split ? 0 : 1;
-      if (li == nU || !real) continue; // padding
-      const double xjx = s_pos[3 * li], xjy = s_pos[3 * li + 1], xjz = s_pos[3 * li + 2];
-      const int pt = ta * 2 + seg;
-      const double dx = xa.x - xjx, dy = xa.y - xjy, dz = xa.z - xjz;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq >= P.lj_rsq_lo[pt] && rsq <= P.lj_rsq_hi[pt] && rsq < P.lj_rsq_sw[pt]) {
-        double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        lj_cubic_fix(P.lj1[pt], P.lj2[pt], P.lj3[pt], P.lj4[pt], P.rcLJmin[pt], P.ljc2[pt], P.ljc3[pt], dx, dy, dz, rsq, o);
-        fx[0] += o[0];
-        fy[0] += o[1];
-        fz[0] += o[2];
-        if (EV) {
-          ee[0] += o[3];
-          if (vflag) {
-            v0 += o[4];
-            v1 += o[5];
-            v2 += o[6];
-            v3 += o[7];
-            v4 += o[8];
-            v5 += o[9];
-          }
-        }
-      }
-    }
-  }
-
-  const double e_lj = real ? ee[0] : 0.0;
-  if (GATHER) ee[0] += ge; // per-atom REBO energy rides along after the LJ total has been taken
-  lj_store<1, L>(have, ia, s, lane, nlocal, e_lj, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
-                 accumulate);
 }
 
 // does the tile's union reach a remote ghost?  Such tiles wait for the halo.
@@ -3109,31 +2492,25 @@ int mdp_rebomos_repack(mdp_ctx *c)
   int cl = MDP_CLUSTER;
   if (const char *e = getenv("MDP_CLUSTER")) cl = atoi(e);
   if (cl != 1 && cl != 2 && cl != 4) cl = MDP_CLUSTER;
-  // Lennard-Jones list layout: tiles of 16 two-atom rows (default); MDP_LJ_ROWS=32: tiles of 32 one-atom rows
-  // (25 % fewer pair evaluations, but every LDS read and row index then serves one atom instead of two: measured
-  // 1.35 against 1.28 ms at 3.98 M atoms); MDP_LJ_TILE=0: per-cluster lists of global indices (the
-  // fallback when a union outgrows LDS)
-  bool rows32 = false;
-  if (const char *e = getenv("MDP_LJ_ROWS")) rows32 = atoi(e) == 32 && cl == MDP_CLUSTER;
-  if (const char *e = getenv("MDP_LJ_TILE")) rows32 = rows32 && atoi(e) != 0;
-  bool want16 = !rows32 && cl == 2;
+  // Lennard-Jones list layout: tiles of 16 two-atom rows; MDP_LJ_TILE=0: per-cluster lists of global indices (the
+  // fallback when a union outgrows LDS).  (Tiles of 32 one-atom rows evaluate 25 % fewer pairs and measured slower,
+  // 1.35 against 1.28 ms at 3.98 M atoms -- every LDS read and row index then serves one atom: DESIGN.md section 4.)
+  bool want16 = cl == 2;
   if (const char *e = getenv("MDP_LJ_TILE")) want16 = want16 && atoi(e) != 0;
-  if (rows32) cl = 1;
   c->cluster = cl;
-  int nclus = (nlocal + cl - 1) / cl;
+  const int nclus = (nlocal + cl - 1) / cl;
   c->nclus = nclus;
-  const int nrow_max = ((nlocal + MDP_T32 - 1) / MDP_T32) * MDP_T32 + MDP_TILE; // whole tiles of rows in either layout
+  const int nrow_max = ((nclus + MDP_TILE - 1) / MDP_TILE) * MDP_TILE + MDP_TILE; // whole tiles of rows
   MDP_HIP(c, c->lj_split.reserve(nrow_max + 1));
   MDP_HIP(c, c->lj_cnt.reserve(nrow_max + 1));
   MDP_HIP(c, c->lj_off.reserve(nrow_max + 2));
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
-  // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost (default) or, with
-  // MDP_HALO_OVERLAP=lj, behind the Lennard-Jones tiles that reach none (the round-1 scheme, kept for comparison)
-  const bool remote_any = c->md && c->remote_start < nall;
-  const char *eov = getenv("MDP_HALO_OVERLAP");
-  const bool centre_split = remote_any && !(eov && !strcmp(eov, "lj"));
+  // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost.  (Round 1 split the
+  // Lennard-Jones tiles instead, which needs the slot gather as a kernel of its own: 0.495 against 0.462 ms per
+  // step of an 8-GPU sub-domain)
+  const bool centre_split = c->md && c->remote_start < nall;
   c->centre_split = centre_split;
   MDP_HIP(c, c->class_list.reserve((size_t) (centre_split ? MDP_NCLASS : MDP_NCLASS_HALF) * nall + 8));
   MDP_HIP(c, c->class_count.reserve(MDP_NCLASS));
@@ -3166,51 +2543,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
   // Lennard-Jones lists: tile lists for the default cluster size, unless switched off or a union outgrows LDS
-  c->tile_rows = 16;
-  if (rows32 && nlocal > 0) {
-    const int nt32 = (nlocal + MDP_T32 - 1) / MDP_T32;
-    int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
-    MDP_HIP(c, c->tile_flag.reserve(4));
-    MDP_HIP(c, c->tile_nu.reserve((size_t) 2 * nt32 + 2));
-    bool ok = false;
-    for (;;) {
-      MDP_HIP(c, c->tu.reserve((size_t) nt32 * cap));
-      MDP_HIP(c, c->tmask32.reserve((size_t) nt32 * cap));
-      MDP_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * 3, st));
-      const size_t lds = (size_t) 20 * cap; // 4 wave segments of cap/2 (int + unsigned) + cap unsigned
-      if (lds > 48 * 1024)
-        MDP_HIP(c, hipFuncSetAttribute((const void *) tile32_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      tile32_scan_kernel<<<nt32, 256, lds, st>>>(c->grid, c->rebomos, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, cap,
-                                                 c->tu.p, c->tmask32.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p,
-                                                 c->tile_flag.p);
-      MDP_HIP(c, hipGetLastError());
-      int tf[3] = {0, 0, 0};
-      MDP_TRY(mdp_read_one(c, c->tile_flag.p, sizeof(int) * 3, tf));
-      if (!tf[0]) {
-        c->tile_cap = cap;
-        c->tile_maxu = tf[1];
-        c->tile_rowmax = tf[2];
-        ok = true;
-        break;
-      }
-      cap *= 2; // a union outgrew the segment: retry larger, give up beyond what LDS can stage
-      if (cap > 4096) break;
-    }
-    if (ok)
-      c->tile_rows = 32;
-    else { // two-atom rows would meet the same unions: straight to the per-cluster lists
-      rows32 = false;
-      want16 = false;
-      cl = MDP_CLUSTER;
-      c->cluster = cl;
-      nclus = (nlocal + cl - 1) / cl;
-      c->nclus = nclus;
-    }
-  }
-  // (when the one-atom rows did not fit, two-atom rows would not either)
-  bool tiled = rows32 ? nlocal > 0 : (want16 && nclus > 0);
-  const int ntile = rows32 ? (nlocal + MDP_T32 - 1) / MDP_T32 : (nclus + MDP_TILE - 1) / MDP_TILE;
-  if (tiled && !rows32) {
+  bool tiled = want16 && nclus > 0;
+  const int ntile = (nclus + MDP_TILE - 1) / MDP_TILE;
+  if (tiled) {
     int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
     MDP_HIP(c, c->tile_flag.reserve(4));
     MDP_HIP(c, c->tile_nu.reserve((size_t) 2 * ntile + 2));
@@ -3272,7 +2607,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
     else MDP_CB(4, false, nullptr, nullptr);
   }
   MDP_HIP(c, hipGetLastError());
-  const int nrow = tiled ? ntile * (rows32 ? MDP_T32 : MDP_TILE) : nclus;
+  const int nrow = tiled ? ntile * MDP_TILE : nclus;
   MDP_TRY(mdp_scan_exclusive_i64(c, c->lj_cnt.p, c->lj_off.p, nrow));
   int cand_total = 0;
   long long lj_total = 0;
@@ -3299,9 +2634,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p);
   if (tiled) MDP_TRY(tile_sort_launch(c, ntile));
-  if (tiled && rows32)
-    tile32_fill_kernel<<<ntile, 256, 0, st>>>(c->tile_cap, c->tile_nu.p, c->tmask32.p, c->lj_off.p, c->lj_split.p, c->lj16.p);
-  else if (tiled)
+  if (tiled)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
                                             c->lj16.p);
   c->prune_valid = false; // (new rows: the pruned copy is made at the next compute that wants it)
@@ -3315,10 +2648,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   }
 #undef MDP_CB
   MDP_HIP(c, hipGetLastError());
-  // launch classes of the units (tiles, or clusters without tile lists): interior/boundary for the halo
-  // overlap (only with remote ghosts), small/large union for the LDS allocation of the tile kernel
+  // launch classes of the units (tiles, or clusters without tile lists): small/large union for the LDS allocation
+  // of the tile kernel
   const int nunit = tiled ? ntile : nclus;
-  c->split_halo = false;
   c->lj_ordered = false;
   for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
   // the tile kernel is latency-bound (measured: t = 0.65 ms + 3.96 ms / resident workgroups per CU), so the
@@ -3326,21 +2658,12 @@ int mdp_rebomos_repack(mdp_ctx *c)
   int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
   if (const char *e = getenv("MDP_TILE_SMALL")) kSmallUnion = atoi(e) > 0 ? atoi(e) : kSmallUnion; // (tests)
   c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
-  const bool remote = remote_any && !centre_split; // Lennard-Jones units classified interior / boundary
-  if (nunit > 0 && (remote || (tiled && c->tile_maxu > kSmallUnion))) {
+  if (nunit > 0 && tiled && c->tile_maxu > kSmallUnion) {
     MDP_HIP(c, c->cl_flag.reserve((size_t) 6 * (nunit + 1)));
     MDP_HIP(c, c->cl_pos.reserve((size_t) 4 * (nunit + 2)));
     MDP_HIP(c, c->cl_order.reserve(nunit + 1));
-    int *flag4 = c->cl_flag.p, *is_int = c->cl_flag.p + (size_t) 4 * (nunit + 1), *is_bnd = is_int + (nunit + 1);
-    if (remote) {
-      if (tiled)
-        tile_boundary_kernel<<<(ntile + 3) / 4, 256, 0, st>>>(ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
-                                                              c->tu.p, is_int, is_bnd);
-      else
-        cluster_boundary_kernel<<<(nclus + 15) / 16, 256, 0, st>>>(nclus, c->remote_start, c->lj_off.p, c->lj.p,
-                                                                   is_int, is_bnd);
-    }
-    unit_class_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, remote ? is_bnd : nullptr,
+    int *flag4 = c->cl_flag.p;
+    unit_class_kernel<<<(nunit + 255) / 256, 256, 0, st>>>(nunit, nullptr,
                                                            tiled ? c->tile_nu.p : nullptr, kSmallUnion, flag4);
     MDP_HIP(c, hipGetLastError());
     int total[4] = {0, 0, 0, 0};
@@ -3356,7 +2679,6 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                                            c->lj_class_base[2], c->lj_class_base[3], c->cl_order.p);
     MDP_HIP(c, hipGetLastError());
     c->lj_ordered = true;
-    c->split_halo = remote;
   }
   if (nall)
     classify_kernel<<<(nall + 255) / 256, 256, 0, st>>>(c->rebomos, nall, nlocal, c->xq.p, c->cand_off.p, c->cand.p,
@@ -3478,7 +2800,6 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   c->ntile = ntile;
   c->lj_total = total;
   c->tile_rows_cl = cl;
-  c->tile_rows = 16;
   c->prune_valid = false; // (new rows)
   c->prune_stale = false;
   c->prune_epoch++;
@@ -3581,7 +2902,7 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
 int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
 {
   hipStream_t st = c->stream;
-  const int nrow = c->ntile * (c->tile_rows == 32 ? MDP_T32 : MDP_TILE);
+  const int nrow = c->ntile * MDP_TILE;
   MDP_HIP(c, c->lj_len_in.reserve(nrow + 1));
   MDP_HIP(c, c->lj_split_in.reserve(nrow + 1));
   MDP_HIP(c, c->xhold_prune.reserve((size_t) 3 * c->nall + 3));
@@ -3608,13 +2929,7 @@ int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
                                                        c->tile_nu.p, c->lj_off.p, c->lj_split.p, c->lj16.p,            \
                                                        c->lj16_in.p, c->lj_len_in.p, c->lj_split_in.p);               \
   } while (0)
-  if (c->tile_rows == 32) {
-    if (lds > 48 * 1024)
-      MDP_HIP(c, hipFuncSetAttribute((const void *) tile32_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    tile32_prune_kernel<<<c->ntile, 256, lds, st>>>(lim, c->nlocal, c->xq.p, c->tile_cap, capL, c->tu.p, c->tile_nu.p,
-                                                    c->lj_off.p, c->lj_split.p, c->lj16.p, c->lj16_in.p, c->lj_len_in.p,
-                                                    c->lj_split_in.p);
-  } else if (c->tile_rows_cl == 1)
+  if (c->tile_rows_cl == 1)
     MDP_TP(1);
   else
     MDP_TP(2);
@@ -3648,7 +2963,9 @@ void mdp_prune_adapt(mdp_ctx *c, const double buf_max, const bool fired)
 
 // A style without a displacement check of its own (aeam) keeps the pruned rows current with this: reads the
 // deferred flag of the previous compute's check, prunes (again) when needed, launches this compute's check.
-// Call before the first kernel that walks the rows; positions (ghosts included) must be current.
+// Call before the first kernel that walks the rows; positions (ghosts included) must be current -- unless
+// may_prune is false: then a pruning that is due is only reported (*due; nothing is launched, the caller comes back
+// once the halo has arrived) and the check may read remote ghosts where the previous step left them (kPruneMargin).
 __global__ __launch_bounds__(256) void moved_prune_kernel(const int nall, const double4 *__restrict__ xq,
                                                           const double *__restrict__ xprune, const double ptrigsq,
                                                           const double phardsq, int *__restrict__ flag)
@@ -3665,8 +2982,9 @@ __global__ __launch_bounds__(256) void moved_prune_kernel(const int nall, const 
   if (__any(ptoofar) && (threadIdx.x & 63) == 0) flag[3] = 1;
 }
 
-int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin)
+int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin, const bool may_prune, bool *due)
 {
+  if (due) *due = false;
   const char *ep = getenv("MDP_PRUNE");
   const int prune_on = ep ? atoi(ep) : 1;
   if (!prune_on || !c->md || c->ntile <= 0 || c->tile_rows_cl != 2) {
@@ -3688,6 +3006,10 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin)
     return MDP_OK;
   }
   if (!c->prune_valid || c->prune_stale) {
+    if (!may_prune) {
+      if (due) *due = true;
+      return MDP_OK;
+    }
     double lim[4];
     for (int k = 0; k < 4; k++) lim[k] = (cut[k] + c->prune_buf) * (cut[k] + c->prune_buf);
     MDP_TRY(mdp_tile_prune(c, lim));
@@ -3709,7 +3031,7 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin)
 }
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
-// one launch class of the Lennard-Jones units (see unit_class_kernel): 0/1 interior, 2/3 boundary; odd = large unions
+// one launch class of the Lennard-Jones units (see unit_class_kernel): 0 small unions, 1 large unions (2, 3: unused)
 static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, bool accumulate)
 {
   int first = c->lj_class_base[klass], count = c->lj_class_base[klass + 1] - first;
@@ -3717,7 +3039,7 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
   hipStream_t st = c->stream;
   const int *order = c->lj_ordered ? c->cl_order.p : nullptr;
   int skip_above = 1 << 30;
-  if (c->lj_tiled && order && !c->split_halo && klass == 0) { // natural order, large tiles predicated away
+  if (c->lj_tiled && order && klass == 0) { // natural order, large tiles predicated away
     order = nullptr;
     first = 0;
     count = c->ntile;
@@ -3741,21 +3063,9 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
         c->fnbr.p,                                                                                                  \
         c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                \
   } while (0)
-#define MDP_LJT32(EVV, GV, WV)                                                                                      \
-  do {                                                                                                              \
-    if (lds > 48 * 1024)                                                                                            \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile32_kernel<EVV, GV, WV>,                             \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                       \
-    rebo_lj_tile32_kernel<EVV, GV, WV><<<count, 256, lds, st>>>(                                                    \
-        c->rebomos, c->nlocal, order, first, c->xq.p, c->tile_cap, capL, skip_above, c->tu.p, c->tile_nu.p,        \
-        c->lj_off.p, pruned ? c->lj_len_in.p : nullptr, pruned ? c->lj_split_in.p : c->lj_split.p,                  \
-        pruned ? c->lj16_in.p : c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p, c->fnbr.p, c->fown.p,   \
-        c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                           \
-  } while (0)
 #define MDP_LJT(EVV, GV, WV)                                                                                        \
   do {                                                                                                              \
-    if (c->tile_rows == 32) MDP_LJT32(EVV, GV, WV);                                                                 \
-    else if (c->cluster == 1) MDP_LJT_(EVV, GV, WV, 1);                                                             \
+    if (c->cluster == 1) MDP_LJT_(EVV, GV, WV, 1);                                                                  \
     else MDP_LJT_(EVV, GV, WV, 2);                                                                                  \
   } while (0)
     // the force-only variants fit 5 waves per SIMD (<= 102 VGPRs); with small unions LDS allows 5 workgroups too
@@ -3764,7 +3074,6 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
     else if (gather) MDP_LJT(false, true, 5);
     else MDP_LJT(false, false, 5);
 #undef MDP_LJT
-#undef MDP_LJT32
 #undef MDP_LJT_
     return MDP_OK;
   }
@@ -3835,8 +3144,7 @@ static int launch_centres_vatom(mdp_ctx *c, int eflag, int vflag)
 }
 
 // First half of compute(): everything that does not need this step's REMOTE ghost positions -- the list
-// upkeep and the REBO centres whose candidate sets reach no remote ghost (or, MDP_HALO_OVERLAP=lj, the
-// Lennard-Jones work of the interior tiles).  Runs while the halo exchange is in flight.
+// upkeep and the REBO centres whose candidate sets reach no remote ghost.  Runs while the halo exchange is in flight.
 int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
 {
   c->computes_since_build++;
@@ -3856,15 +3164,12 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vslot.reserve((size_t) 6 * c->cand_total + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, c->stream));
   }
-  if (c->split_halo)
-    for (int k = 0; k < 2; k++) MDP_TRY(launch_lj(c, k, /*gather=*/false, eflag, vflag, /*accumulate=*/false));
   if (c->centre_split && !(vflag & MDP_VFLAG_ATOM)) MDP_TRY(launch_centres(c, eflag, vflag, /*interior*/ 1));
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
 
 // Second half: the remaining REBO centres, then the fused Lennard-Jones + slot-gather kernel over all tiles
-// (MDP_HALO_OVERLAP=lj: all centres, boundary tiles, and the slot gather as a kernel of its own).
 int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
 {
   hipStream_t st = c->stream;
@@ -3874,10 +3179,10 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
   else
     MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
   mdp_time_mark(c, 1);
-  if (c->split_halo || va) {
+  if (va) {
     mdp_time_mark(c, 2);
     c->prune_valid = false; // (these paths walk the rows as built)
-    for (int k = c->split_halo ? 2 : 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
+    for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
     if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
                                                                    c->fnbr.p, c->fown.p, c->f.p, c->eatom.p, eflag,
@@ -3885,9 +3190,9 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
       if (va) {
         const int grid = (c->nlocal + 31) / 32;
         const unsigned short *lj16 = c->lj_tiled ? c->lj16.p : nullptr;
-        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, c->tile_rows);
-        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, c->tile_rows);
-        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, c->tile_rows);
+        if (c->cluster == 1) rebo_lj_vatom_kernel<1><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, MDP_TILE);
+        else if (c->cluster == 4) rebo_lj_vatom_kernel<4><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, MDP_TILE);
+        else rebo_lj_vatom_kernel<2><<<grid, 256, 0, st>>>(c->rebomos, c->nlocal, c->xq.p, c->lj_off.p, c->lj.p, lj16, c->tu.p, c->tile_cap, c->tile_nu.p, c->vatom.p, MDP_TILE);
       }
     }
   } else {

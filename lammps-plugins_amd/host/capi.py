@@ -64,6 +64,7 @@ EXPORTS = [
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
     "mdp_dd_comm_allreduce", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
+    "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
 ]
 
 
@@ -154,14 +155,6 @@ class AeamFile:
                 self.h = C.c_void_p()
         except Exception:
             pass
-
-
-def rebomos_params_from_oracle(P) -> RebomosParams:
-    """copy the (identically laid out) leading fields of the oracle's parameter struct"""
-    out = RebomosParams()
-    for name, _ in RebomosParams._fields_:
-        setattr(out, name, getattr(P, name))
-    return out
 
 
 class _SerialLib:
@@ -356,6 +349,16 @@ class Context:
     def md_aeam_force(self, eflag=0, vflag=0):
         self._ck(self.L.mdp_md_aeam_force(self.h, C.c_int(eflag), C.c_int(vflag)))
 
+    def md_aeam_force_begin(self, eflag=0, vflag=0):
+        self._ck(self.L.mdp_md_aeam_force_begin(self.h, C.c_int(eflag), C.c_int(vflag)))
+
+    def md_aeam_state(self):
+        """phases of the current aeam compute done so far, tiles that reach no remote ghost, tiles, whether ghost
+        forces can be non-zero (see mdpair_hip.h)"""
+        out = (C.c_int * 4)()
+        self._ck(self.L.mdp_md_aeam_state(self.h, out))
+        return dict(phase=int(out[0]), interior_tiles=int(out[1]), tiles=int(out[2]), ghost_forces=bool(out[3]))
+
     def md_thermo(self):
         out = (C.c_double * 9)()
         self._ck(self.L.mdp_md_thermo(self.h, out))
@@ -497,6 +500,12 @@ class Context:
 
     def dd_comm_reverse(self):
         self._ck(self.L.mdp_dd_comm_reverse(self.h))
+
+    def dd_comm_aeam_exchange_begin(self, with_reverse=True):
+        self._ck(self.L.mdp_dd_comm_aeam_exchange_begin(self.h, C.c_int(1 if with_reverse else 0)))
+
+    def dd_comm_aeam_exchange_end(self):
+        self._ck(self.L.mdp_dd_comm_aeam_exchange_end(self.h))
 
     def dd_comm_allreduce(self, values, op=0):
         v = np.ascontiguousarray(values, dtype=np.float64).copy()

@@ -155,6 +155,7 @@ class DeviceDomain:
         self.send3 = self.recv3 = self.send1 = self.recv1 = None
         self.builds = 0
         self.dangerous = 0
+        self.aeam_overlapped = 0       # multi-GPU aeam steps whose exchanges travelled behind the interior tiles
         self._final_pending = False
         self.reneighbor()
 
@@ -194,12 +195,19 @@ class DeviceDomain:
             self.recv3 = torch.empty(max(nr, 1) * 3, **f64)
             self.send1 = torch.empty(max(ns, 1), **f64)
             self.recv1 = torch.empty(max(nr, 1), **f64)
+            if self.style == capi.STYLE_AEAM:   # the reverse exchange of a step travels beside the fp exchange
+                self.rsend3 = torch.empty(max(nr, 1) * 3, **f64)
+                self.rrecv3 = torch.empty(max(ns, 1) * 3, **f64)
             self._keep = (send, recv)   # until the stream has consumed them
         info = ctx.dd_info()
         self.nlocal, self.nself, self.nsend, self.nrecv = info["nlocal"], info["nself"], info["nsend"], info["nrecv"]
         self.nghost = self.nself + self.nrecv
         self.builds += 1
         self.fresh_ghosts = True
+        if self.style == capi.STYLE_AEAM and tr is not None:
+            # ghost forces are non-zero only when some rank has an angular centre next to a remote ghost: the reverse
+            # exchange is skipped by all ranks alike otherwise (decided once per reneighboring)
+            self.ghost_forces = tr.any(ctx.md_aeam_state()["ghost_forces"])
 
     @property
     def tags_local(self):
@@ -260,6 +268,52 @@ class DeviceDomain:
             self.ctx.md_final_integrate()
             self._final_pending = False
 
+    def _aeam_step_compute(self, eflag, vflag, fresh):
+        """Pair::compute of a multi-GPU aeam step in four phases (mdpair_hip.h): the position exchange travels behind
+        the density of the interior tiles, the style's fp exchange (pair_aeam.cpp:307) and the reverse exchange of the
+        three-body forces on ghosts behind the pair forces of the interior tiles."""
+        ctx, tr = self.ctx, self.tr
+        work = None if fresh else self.forward_positions(async_op=True)
+        ctx.md_compute_begin(eflag, vflag)                       # A: density, interior tiles
+        if not fresh:
+            if self.native:
+                ctx.dd_comm_forward_end()
+            else:
+                if work not in (None, "native"):
+                    work.wait()
+                ctx.dd_forward_unpack(self.recv3.data_ptr())
+        ctx.md_aeam_density(eflag)                               # B: the rest of passes 1 + 2 (+ three-body forces)
+        if not ctx.md_aeam_state()["phase"] & 4:                 # phase A did not run (pruning due, CSR lists, ...)
+            self.forward_fp()
+            ctx.md_aeam_force(eflag, vflag)
+            self.reverse_forces()
+            return
+        rev = self.ghost_forces
+        self.aeam_overlapped += 1
+        if self.native:
+            ctx.dd_comm_aeam_exchange_begin(rev)                 # fp out, ghost forces back: one group of sends
+            ctx.md_aeam_force_begin(eflag, vflag)                # C: pair forces, interior tiles
+            ctx.dd_comm_aeam_exchange_end()
+            ctx.md_aeam_force(eflag, vflag)                      # D: the rest
+            return
+        ctx.md_fold_self_ghost_f()
+        ctx.dd_forward_scalar_pack(self.send1.data_ptr())
+        if rev:
+            ctx.dd_reverse_pack(self.rsend3.data_ptr())
+        _, w1 = tr.exchange(self.send1, self.send_counts, self.recv_counts, 1, recv=self.recv1, async_op=True)
+        w3 = None
+        if rev:
+            _, w3 = tr.exchange(self.rsend3, self.recv_counts, self.send_counts, 3, recv=self.rrecv3, async_op=True)
+        ctx.md_aeam_force_begin(eflag, vflag)                    # C
+        if w1 is not None:
+            w1.wait()
+        ctx.dd_forward_scalar_unpack(self.recv1.data_ptr())
+        ctx.md_aeam_force(eflag, vflag)                          # D
+        if rev:
+            if w3 is not None:
+                w3.wait()
+            ctx.dd_reverse_unpack(self.rrecv3.data_ptr())
+
     def step(self, eflag=0, vflag=0, rebuild=False, defer_final=False):
         """one velocity-Verlet step, Verlet::run order: initial_integrate, [reneighbor], forward comm, force,
         final_integrate.  REBO-MoS on several GPUs hides the ghost exchange behind the interior Lennard-Jones work.
@@ -294,9 +348,7 @@ class DeviceDomain:
                     ctx.dd_forward_unpack(self.recv3.data_ptr())
             ctx.md_compute_end(eflag, vflag)
         else:
-            if not fresh:
-                self.forward_positions()
-            self.compute(eflag, vflag)
+            self._aeam_step_compute(eflag, vflag, fresh)
         if defer_final:
             self._final_pending = True
         else:

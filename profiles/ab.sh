@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the bench line under two environments, alternating, on the GPU box.
-# usage: profiles/ab.sh "<VAR=a ...>" "<VAR=b ...>" [bench args...]      e.g. profiles/ab.sh MDP_LJ_ROWS=16 MDP_LJ_ROWS=32
+# usage: profiles/ab.sh "<VAR=a ...>" "<VAR=b ...>" [bench args...]      e.g. profiles/ab.sh MDP_PRUNE=1 MDP_PRUNE=0
 set -u
 A=$1; B=$2; shift 2
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/ab

@@ -22,6 +22,16 @@ class RebomosParams(C.Structure):
         ("cut3rebo", C.c_double)]
 
 
+def product_rebomos_params(P: "RebomosParams"):
+    """the product's parameter struct (host/capi.RebomosParams) filled from the oracle's identically laid out
+    leading fields -- for tests that feed both sides the same numbers"""
+    from lammps_plugins_amd.host import capi
+    out = capi.RebomosParams()
+    for name, _ in capi.RebomosParams._fields_:
+        setattr(out, name, getattr(P, name))
+    return out
+
+
 MAXEL = 8
 
 

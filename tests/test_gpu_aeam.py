@@ -195,7 +195,7 @@ def test_resident_force_only_step_matches_oracle(oracle, T, pot, frac, amp):
     {"MDP_AEAM_PERSIST": "0"},                                  # gather tile kernels (spline rows from global memory)
     {"MDP_AEAM_PERSIST": "1"},                                  # persistent density kernel, table window in LDS
     {"MDP_AEAM_PERSIST": "1", "MDP_AEAM_PT_NSUB": "4"},         # narrower window, more sub-blocks
-    {"MDP_AEAM_PERSIST": "1", "MDP_AEAM_PT_NSUB": "2", "MDP_AEAM_PERSIST_FORCE": "1"},   # the two persistent force passes as well
+    {"MDP_AEAM_PERSIST": "1", "MDP_AEAM_PT_NSUB": "2"},         # widest window, two sub-blocks
     {},                                                         # the library's own choice
 ])
 def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
@@ -203,7 +203,7 @@ def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     segments and different-element visits (global-memory rows) into every tile, the compression puts pairs
     below the LDS window of the persistent kernels (rows read from global memory in their cold pass), and the
     energy/virial step runs the tallying variants.  All against the CPU oracle."""
-    for k in ("MDP_AEAM_PERSIST", "MDP_AEAM_PT_NSUB", "MDP_AEAM_PERSIST_FORCE"):
+    for k in ("MDP_AEAM_PERSIST", "MDP_AEAM_PT_NSUB"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

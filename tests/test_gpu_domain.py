@@ -98,7 +98,7 @@ def test_atoms_outside_the_box_are_remapped(oracle):
     ctx.close()
 
 
-def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None, defer=False):
+def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None, defer=False, self_remote=False):
     """NVE run on `world` bricks (threads), forced reneighboring every `rebuild_every` steps; returns per-tag
     x, v and the thermo of the last step, plus per-rank counts"""
 
@@ -115,7 +115,7 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None,
             cutghost = float(af.cut_table(tabs).max()) + skin
             ctx._af = (af, tabs)
         tr = make_tr(ctx) if world > 1 else None
-        d = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr)
+        d = resident.DeviceDomain(ctx, style, s, cutghost, skin, map_, v0=v0, transport=tr, self_remote=self_remote)
         counts0 = (d.nlocal, d.nself, d.nrecv)
         d.compute(1, 1)
         th0 = d.thermo()
@@ -127,9 +127,11 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None,
                 left += ctx.dd_info()["left_last"]
         th = d.thermo()
         tags, a = _by_tag(d, ("x", "v", "f"))
+        aeam = ctx.md_aeam_state() if style == capi.STYLE_AEAM else None
+        prunes = ctx.md_prune_stats()
         ctx.close()
         return dict(tags=tags, x=a["x"], v=a["v"], f=a["f"], th0=th0, th=th, counts0=counts0, left=left,
-                    builds=d.builds)
+                    builds=d.builds, aeam=aeam, overlapped=d.aeam_overlapped, prunes=prunes)
 
     if world == 1:
         res = [rank_fn(0, None)]
@@ -144,7 +146,7 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None,
         seen[idx] += 1
     assert np.all(seen == 1)                      # every atom owned exactly once
     return dict(x=x, v=v, f=f, th0=res[0]["th0"], th=res[0]["th"], counts0=[r["counts0"] for r in res],
-                left=sum(r["left"] for r in res), builds=res[0]["builds"])
+                left=sum(r["left"] for r in res), builds=res[0]["builds"], ranks=res)
 
 
 def test_four_bricks_match_the_reference_4_rank_log(log):
@@ -211,6 +213,84 @@ def test_aeam_bricks_with_halo_of_fp_and_ghost_forces(oracle):
         assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
 
 
+@pytest.mark.parametrize("world,temp,drift", [(2, 863.0, 0.0), (8, 600.0, 1.0), (4, 863.0, 1.0)])
+def test_aeam_exchanges_behind_the_interior_tiles(oracle, world, temp, drift):
+    """A system large enough for bricks with an interior (16^3 fcc cells, 16 384 atoms, 64.7 A): the shell atoms of a
+    brick are stored behind the interior ones, so the tiles that reach no remote ghost are a leading range; their
+    density runs while the positions travel, their pair forces while fp and the three-body forces on ghosts travel
+    (mdp_md_compute_begin / mdp_md_aeam_force_begin).  Forces equal the oracle's, the trajectory -- with migrations,
+    prunings that force a step back onto the blocking path, thermo steps -- equals the one-brick run."""
+    T = oracle.aeam_pot(POT_AEAM)
+    s = S.jitter(S.fcc_cell(4.045, 16, frac_type2=0.03, seed=5), 0.05, seed=6)
+    s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+    v0 = S.gaussian_velocities(s, temp, seed=7) + drift * np.array([40.0, 25.0, -30.0])
+    xw = S.wrap(s.box, s.x)
+    o = mdref.AeamCPU(oracle, T, S.System(s.box, xw, s.type, s.tag, s.mass)).compute(xw)
+    st = _run(world, s, v0, 0, 0, style=capi.STYLE_AEAM)
+    assert np.abs(st["f"] - o["f_owned"]).max() < 1e-9
+    assert st["th0"]["pe"] == pytest.approx(o["eng"], rel=1e-11)
+    steps, every = 30, 6
+    one = _run(1, s, v0, steps, every, style=capi.STYLE_AEAM)
+    many = _run(world, s, v0, steps, every, style=capi.STYLE_AEAM, defer=True)
+    for r in many["ranks"]:
+        a = r["aeam"]
+        assert 0 < a["interior_tiles"] < a["tiles"]          # every brick has an interior and a shell
+        assert a["ghost_forces"]                             # 3 % angular atoms: some sit in the shell
+        assert 0 < r["overlapped"] <= steps                  # steps on the phased path ...
+        if drift or temp > 700:
+            assert r["prunes"]["prunings"] > 1               # ... and prunings (those steps take the blocking path)
+    frac = sum(r["aeam"]["interior_tiles"] for r in many["ranks"]) / sum(r["aeam"]["tiles"] for r in many["ranks"])
+    assert frac > (0.4 if world == 2 else 0.08)              # (64.7 A / 2 per brick, shell 7.5 A on both sides)
+    if drift:
+        assert many["left"] > 20
+    dx = many["x"] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(many["v"] - one["v"]).max() < 1e-7
+    assert np.abs(many["f"] - one["f"]).max() < 1e-7
+    assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+    assert many["th"]["ke"] == pytest.approx(one["th"]["ke"], rel=1e-9)
+    assert np.allclose(many["th"]["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
+
+
+def test_aeam_phases_on_one_rank_with_every_image_remote(oracle):
+    """the same phases on ONE brick whose periodic images are all treated as remote ghosts (`self_remote`, thread
+    transport with one rank): shell = everything within the ghost cutoff of the box faces"""
+    s = S.jitter(S.fcc_cell(4.045, 12, frac_type2=0.03, seed=15), 0.05, seed=16)
+    s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+    v0 = S.gaussian_velocities(s, 863.0, seed=17)
+    one = _run(1, s, v0, 20, 5, style=capi.STYLE_AEAM)
+
+    def rank_fn(r, make_tr):
+        ctx = capi.Context(0)
+        af = capi.AeamFile(POT_AEAM)
+        tabs = af.build()
+        ctx.aeam_set_tables(tabs)
+        ctx._af = (af, tabs)
+        cutghost = float(af.cut_table(tabs).max()) + 1.0
+        d = resident.DeviceDomain(ctx, capi.STYLE_AEAM, s, cutghost, 1.0, None, v0=v0, transport=make_tr(ctx),
+                                  self_remote=True)
+        assert d.nself == 0 and d.nrecv > 0
+        d.compute(1, 1)
+        for step in range(1, 21):
+            d.step(1 if step == 20 else 0, 1 if step == 20 else 0, rebuild=step % 5 == 0, defer_final=step != 20)
+        th = d.thermo()
+        tags, a = _by_tag(d, ("x", "f"))
+        state, n = ctx.md_aeam_state(), d.aeam_overlapped
+        ctx.close()
+        return tags, a, th, state, n
+
+    (tags, a, th, state, n), = resident.run_ranks(1, rank_fn)
+    assert 0 < state["interior_tiles"] < state["tiles"] and n > 0
+    order = np.argsort(tags)
+    dx = a["x"][order] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(a["f"][order] - one["f"]).max() < 1e-7
+    assert th["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+    assert np.allclose(th["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
+
+
 def test_aeam_bricks_with_five_atom_types(oracle, tmp_path):
     """the same on 2 and 4 bricks with a five-element file (tile kernels with per-entry types; types of remote ghosts
     arrive with the border exchange), the steps run with the final half-kick deferred into the next step's kernel"""
@@ -274,7 +354,7 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
         v0 = S.gaussian_velocities(s, 300.0, seed=3) + np.array([80.0, -30.0, 20.0])
         st = capi.STYLE_REBOMOS
     else:
-        s = S.jitter(S.fcc_cell(4.045, 7, frac_type2=0.05, seed=9), 0.04, seed=10)
+        s = S.jitter(S.fcc_cell(4.045, 12, frac_type2=0.05, seed=9), 0.04, seed=10)   # 48.5 A: a brick with an interior
         s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
         v0 = S.gaussian_velocities(s, 600.0, seed=4) + np.array([50.0, 35.0, -40.0])
         st = capi.STYLE_AEAM
@@ -304,6 +384,8 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
         tags, a = _by_tag(d, ("x", "f"))
         order = np.argsort(tags)
         ghosts = d.nself + d.nrecv
+        if native and st == capi.STYLE_AEAM:   # fp and ghost forces travelled in one group behind the interior force tiles
+            assert d.aeam_overlapped > 0 and 0 < ctx.md_aeam_state()["interior_tiles"]
         ctx.close()
         return th0, th, a["x"][order], a["f"][order], ghosts
 
@@ -320,16 +402,12 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
     assert np.abs(nf - pf).max() < 1e-7
 
 
-@pytest.mark.parametrize("style", ["rebomos", "aeam", "rebomos-rows32"])
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
 def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch):
     """Dynamic pruning of the tile rows (tile_prune_kernel): a hot run with a narrow buffer prunes every few steps;
     positions and velocities after 60 steps must agree with the run that walks the rows as built to rounding (the
     dropped entries contribute exactly zero; the kept ones land on other lanes, so partial sums differ in the last
     bit), and no pruning may come late."""
-    monkeypatch.delenv("MDP_LJ_ROWS", raising=False)
-    if style == "rebomos-rows32":          # tiles of 32 one-atom rows: their own builder, pruning and compute kernels
-        monkeypatch.setenv("MDP_LJ_ROWS", "32")
-        style = "rebomos"
     if style == "rebomos":
         s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 1))
         temp, skin, map_ = 600.0, 2.0, MAP

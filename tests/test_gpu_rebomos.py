@@ -12,6 +12,7 @@ import pytest
 from conftest import GOLDEN, POT_REBOMOS
 from lammps_plugins_amd.host import capi, system as S
 import mdref
+import oracle_bindings
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def P(oracle):
 @pytest.fixture(scope="module")
 def ctx(P):
     c = capi.Context(0)
-    c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
+    c.rebomos_set_params(oracle_bindings.product_rebomos_params(P))
     yield c
     c.close()
 
@@ -218,7 +219,7 @@ def test_unsorted_host_atoms(oracle, P, device_sort):
     os.environ["MDP_HOST_SORT"] = "1" if device_sort else "0"
     try:
         c = capi.Context(0)
-        c.rebomos_set_params(capi.rebomos_params_from_oracle(P))
+        c.rebomos_set_params(oracle_bindings.product_rebomos_params(P))
         g = _gpu_compute(c, eng, s.x, vflag=5)
         info = c.rebomos_list_info()
         # a second step through the positions-only path, after moving the atoms a little

@@ -131,15 +131,11 @@ def test_tile_lists_against_the_per_cluster_path_and_large_union_classes():
     f0, e0, th0, i0 = _forces(s, {"MDP_LJ_TILE": "0"})
     f1, e1, th1, i1 = _forces(s, {"MDP_LJ_TILE": "1"})
     f2, e2, th2, i2 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_ORDER": "morton", "MDP_TILE_SMALL": "700"})
-    # tiles of 32 one-atom rows (MDP_LJ_ROWS=32, the measured alternative layout), both launch classes
-    f3, e3, th3, i3 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_LJ_ROWS": "32"})
-    f4, e4, th4, i4 = _forces(s, {"MDP_LJ_TILE": "1", "MDP_LJ_ROWS": "32", "MDP_ORDER": "morton", "MDP_TILE_SMALL": "700"})
-    assert i0["tiled"] == 0 and i1["tiled"] == 1 and i2["tiled"] == 1 and i3["tiled"] == 1
+    assert i0["tiled"] == 0 and i1["tiled"] == 1 and i2["tiled"] == 1
     assert i1["union_max"] < i1["union_stride"]
     assert 0 < i2["large_tiles"] < i2["tiles"]          # both launch classes populated
-    assert i3["clusters"] == s.n and i1["clusters"] == (s.n + 1) // 2 and i3["tiles"] == (s.n + 31) // 32
-    assert 0 < i4["large_tiles"] < i4["tiles"]
-    for f, e, th in ((f1, e1, th1), (f2, e2, th2), (f3, e3, th3), (f4, e4, th4)):
+    assert i1["clusters"] == (s.n + 1) // 2
+    for f, e, th in ((f1, e1, th1), (f2, e2, th2)):
         assert np.abs(f - f0).max() < 1e-10
         assert np.abs(e - e0).max() < 1e-10
         assert th["pe"] == pytest.approx(th0["pe"], rel=1e-12)
