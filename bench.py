@@ -60,15 +60,59 @@ def launch_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} ...")
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    # the rank tree gets its own process group: whatever ends the parent -- a signal, the deadline below, an
+    # exception -- ends the ranks too (first SIGTERM, then SIGKILL), so no rank is left holding a GPU
+    import signal
+    import threading
+    deadline = float(os.environ.get("MDP_BENCH_DEADLINE_S", "3000"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+
+    def stop_ranks(sig=signal.SIGTERM):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, frame):
+        log(f"[bench] signal {signum}: stopping the ranks")
+        stop_ranks()
+        raise SystemExit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    timed_out = []
+
+    def on_deadline():
+        timed_out.append(True)
+        log(f"[bench] the ranks did not finish within {deadline:.0f} s (MDP_BENCH_DEADLINE_S): stopping them")
+        stop_ranks()
+        time.sleep(10)
+        stop_ranks(signal.SIGKILL)
+
+    timer = threading.Timer(deadline, on_deadline)
+    timer.daemon = True
+    timer.start()
     line = None
-    for out in p.stdout:
-        out = out.rstrip("\n")
-        if out.startswith("{") and '"metric"' in out:
-            line = out
-        elif out:
-            log(out)
-    rc = p.wait()
+    try:
+        for out in p.stdout:
+            out = out.rstrip("\n")
+            if out.startswith("{") and '"metric"' in out:
+                line = out
+            elif out:
+                log(out)
+        rc = p.wait()
+    finally:
+        timer.cancel()
+        if p.poll() is None:
+            stop_ranks()
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                stop_ranks(signal.SIGKILL)
+                p.wait()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if timed_out:
+        return 1
     if rc != 0:
         log(f"[bench] the rank processes failed (exit code {rc}); no result")
         return rc if rc > 0 else 1
@@ -241,7 +285,8 @@ def pmc_entry(workload, replicate, world):
         return None, "no PMC entry for this configuration"
     if ent.get("kernel_source_sha") != kernel_source_sha():
         return None, "PMC entry is stale (kernel sources changed since it was measured)"
-    return ent, ent.get("note", "FETCH_SIZE x2 + WRITE_SIZE, path kernels of one step")
+    return ent, "stored PMC figure (profiles/pmc_traffic.json, measured on these kernel sources; not re-measured in this run): " + \
+        ent.get("note", "FETCH_SIZE x2 + WRITE_SIZE, path kernels of one step")
 
 
 # ------------------------------------------------------------------------------------------------ one measured job
@@ -374,10 +419,16 @@ def run_job(E, job, par):
         single = {lj: kms[2]}                       # phases that are ONE launch: candidates for `dominant_kernel`
     else:
         dens = "aeam_tile_density_kernel" if os.environ.get("MDP_AEAM_PERSIST", "") == "0" else "aeam_ptile_kernel"
+        # (each phase is timed between its own pair of events: no exchange and no host gap lies inside one)
         phases = {dens + " (one launch)": kms[0], "aeam_density_ang_kernel": kms[1], "aeam_embed_kernel": kms[2],
-                  "aeam_tile_force_kernel (one launch, after force_clear)": kms[3], "aeam_force_ang_kernel": kms[4]}
+                  "aeam_tile_force_kernel (one launch)": kms[3], "aeam_force_ang_kernel": kms[4]}
         single = {dens: kms[0], "aeam_density_ang_kernel": kms[1], "aeam_embed_kernel": kms[2],
                   "aeam_tile_force_kernel": kms[3], "aeam_force_ang_kernel": kms[4]}
+        if dist is not None:   # several GPUs: the tiles that reach no remote ghost run behind the exchanges
+            phases[dens + ", interior tiles (position exchange in flight)"] = kms[5]
+            phases["aeam_tile_force_kernel, interior tiles (fp / ghost-force exchange in flight)"] = kms[6]
+            single[dens + " (interior tiles)"] = kms[5]
+            single["aeam_tile_force_kernel (interior tiles)"] = kms[6]
     # algorithmic bytes of ONE pass of the path over this rank's atoms: SURVEY 8(d) per-atom figure x atoms.
     # `achieved` / `frac` use the time of ALL kernels of the path (the contract figure is per atom-step of the
     # whole compute(), not of its longest kernel); the largest single launch is reported beside it with ITS counter bytes.
@@ -444,6 +495,13 @@ def run_job(E, job, par):
                               "frac": round(flops_path / FP64_PEAK_TFLOPS, 5),
                               "whole_step_frac": round(flops_step / FP64_PEAK_TFLOPS, 5)}},
     }
+    if dist is not None and wl == "aeam":
+        st = ctx.md_aeam_state()
+        out["config"].update(aeam_tiles_rank0=st["tiles"], aeam_interior_tiles_rank0=st["interior_tiles"],
+                             aeam_ghost_force_exchange=bool(getattr(dom, "ghost_forces", False)),
+                             aeam_steps_with_exchanges_behind_interior_tiles_rank0=int(dom.aeam_overlapped),
+                             aeam_step="position exchange behind the density of the interior tiles; fp forward and "
+                                       "ghost-force reverse exchange behind the pair forces of the interior tiles")
     if dist is not None:
         # per-rank shape of the decomposition (log.rebomos-bulk.4:72-75 prints the same per-rank counts)
         mine = torch.tensor([dom.nlocal, dom.nself, dom.nrecv, dom.nsend], dtype=torch.int64, device="cpu" if stage_host else dev)

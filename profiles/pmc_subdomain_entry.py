@@ -7,8 +7,11 @@ usage: pmc_subdomain_entry.py <dir with pmc_fetch/ pmc_write/> <key e.g. rebomos
 import collections, csv, glob, json, os, re, sys
 
 root, key, sha, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-PATH = ("rebo_centre_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_tile32_kernel",
-        "rebo_lj_gather_kernel", "rebo_gather_kernel")
+AEAM = key.startswith("aeam")
+PATH = ("aeam_ptile_kernel", "aeam_tile_density_kernel", "aeam_density_ang_kernel", "aeam_embed_kernel",
+        "aeam_tile_force_kernel", "aeam_force_ang_kernel", "aeam_density_kernel", "aeam_force_kernel") if AEAM else \
+       ("rebo_centre_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_gather_kernel",
+        "rebo_gather_kernel")
 
 
 def short(k):
@@ -25,7 +28,18 @@ def per_step(sub, counter):
             if r["Counter_Name"] == counter:
                 rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
     rows.sort()
-    lj = [d for d, k, _ in rows if k.startswith("rebo_lj_tile") and "<false" in k]
+    # one dispatch per step that closes the path: the force-only Lennard-Jones kernel / aeam's last force-tile launch
+    if AEAM:
+        emb = [d for d, k, _ in rows if k.startswith("aeam_embed_kernel")]
+        frc = [d for d, k, _ in rows if k.startswith("aeam_tile_force_kernel")]
+        import bisect
+        lj = []
+        for e, nxt in zip(emb, emb[1:] + [1 << 62]):
+            i = bisect.bisect_left(frc, nxt) - 1
+            if i >= 0 and frc[i] > e:
+                lj.append(frc[i])
+    else:
+        lj = [d for d, k, _ in rows if k.startswith("rebo_lj_tile") and "<false" in k]
     if len(lj) <= steps:
         return {}
     start = lj[-steps - 1]                      # everything after the Lennard-Jones kernel of the step before the window

@@ -16,6 +16,15 @@ run rebo2 2 --replicate 10 10 10 --temp 300 --steps 40 --warmup 5
 run rebo4 4 --replicate 10 10 10 --temp 300 --steps 40 --warmup 5 --no-cpu-baseline
 run aeam1 1 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 5 --no-cpu-baseline
 run aeam4 4 --workload aeam --replicate 30 30 30 --temp 863 --steps 60 --warmup 5 --no-cpu-baseline
+# BASELINE.json configs[4] (16.1 M atoms) on 1, 2 and 4 bricks: the same trajectory (PE/atom and T after the same
+# number of steps), every multi-rank step on the phased path (exchanges behind the interior tiles)
+if [ "${MDP_REHEARSE_16M:-1}" != "0" ]; then
+for n in 1 2 4; do
+  run aeam16m_$n $n --workload aeam --replicate 159 159 159 --temp 863 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary
+  python3 -c "
+import json;d=json.load(open('$O/aeam16m_$n.json'));c=d['config'];print('   phased steps', c.get('aeam_steps_with_exchanges_behind_interior_tiles_rank0'), 'interior tiles', c.get('aeam_interior_tiles_rank0'), 'of', c.get('aeam_tiles_rank0'), 'ghost forces', c.get('aeam_ghost_force_exchange'))"
+done
+fi
 # what must NOT produce a result: more RCCL ranks than GPUs
 timeout -k 10 200 python3 bench.py --gpus 2 --replicate 4 4 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/refuse.json 2> $O/refuse.err; echo "refuse rc=$? (non-zero expected), stdout bytes: $(wc -c < $O/refuse.json)"
 # the N>1 code path of bench.py over RCCL itself with ONE rank: every periodic self-image travels through the transport
@@ -24,5 +33,11 @@ for tr in torch native; do
   MDP_BENCH_SELF_REMOTE=1 MDP_BENCH_TRANSPORT=$tr timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --replicate 12 12 12 --temp 300 --steps 60 --warmup 5 --no-cpu-baseline > $O/self_$tr.json 2> $O/self_$tr.err
   echo "self_$tr rc=$? stdout lines: $(wc -l < $O/self_$tr.json)"; python3 -c "
 import json;d=json.load(open('$O/self_$tr.json'));c=d['config'];print('  ', d['value'], d['ms_per_step'], c['transport'], c['pe_per_atom_end_eV'], c['temp_end_K'])"
+  # aeam: position exchange, fp forward and ghost-force reverse exchanges through RCCL to the rank itself, against the
+  # plain one-GPU run of the same system (aeam_plain below)
+  MDP_BENCH_SELF_REMOTE=1 MDP_BENCH_TRANSPORT=$tr timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10 --no-cpu-baseline > $O/self_aeam_$tr.json 2> $O/self_aeam_$tr.err
+  echo "self_aeam_$tr rc=$? stdout lines: $(wc -l < $O/self_aeam_$tr.json)"; python3 -c "
+import json;d=json.load(open('$O/self_aeam_$tr.json'));c=d['config'];print('  ', d['value'], d['ms_per_step'], c['transport'], c['pe_per_atom_end_eV'], c['temp_end_K'], 'phased steps', c.get('aeam_steps_with_exchanges_behind_interior_tiles_rank0'), 'interior', c.get('aeam_interior_tiles_rank0'), 'of', c.get('aeam_tiles_rank0'))"
 done
+run aeam_plain 1 --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10 --no-cpu-baseline --no-secondary
 
