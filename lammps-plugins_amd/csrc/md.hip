@@ -202,14 +202,25 @@ __global__ void ang_select_kernel(const int nlocal, const int min_type, const do
 // same operations in the same order as the two kernels, so the trajectory is bit-identical.  CHECK: `neigh_modify
 // check yes` of the new positions against the positions of the last reneighboring in the same pass (what
 // dd_moved_kernel does in a pass of its own): flag[0] = some atom beyond the trigger, flag[1] = beyond half the skin.
+// SC: the style-level checks and the accumulator reset of the compute that follows, in the same pass (MdpStyleCheck).
 template <bool FINAL, bool CHECK>
 __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
                                    const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
                                    const double *__restrict__ xhold, const double trigsq, const double hardsq,
-                                   int *__restrict__ flag)
+                                   int *__restrict__ flag, const MdpStyleCheck SC)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  bool t = false, h = false;
+  bool t = false, h = false, sa = false, sah = false, sp = false, sph = false;
+  if (SC.acc) { // what acc_zero_kernel does
+    for (int k = i; k < SC.nacc; k += gridDim.x * 256) SC.acc[k] = 0.0;
+    if (i == 0) {
+      const int f0 = SC.flags[0];
+      if (f0) SC.flags[4] |= f0;
+      SC.flags[0] = 0;
+      if (SC.ovf) SC.ovf[0] = 0;
+    } else if (i < 4)
+      SC.flags[i] = 0;
+  }
   if (i < nlocal) {
     const double s = dtf / rmass[i];
     const double fx = f[3 * (size_t) i], fy = f[3 * (size_t) i + 1], fz = f[3 * (size_t) i + 2];
@@ -236,10 +247,28 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
       t = d2 > trigsq;
       h = d2 > hardsq;
     }
+    if (SC.xa) {
+      const double dx = x.x - SC.xa[3 * (size_t) i], dy = x.y - SC.xa[3 * (size_t) i + 1], dz = x.z - SC.xa[3 * (size_t) i + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      sa = d2 > SC.trig_a;
+      sah = d2 > SC.hard_a;
+    }
+    if (SC.xp) {
+      const double dx = x.x - SC.xp[3 * (size_t) i], dy = x.y - SC.xp[3 * (size_t) i + 1], dz = x.z - SC.xp[3 * (size_t) i + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      sp = d2 > SC.trig_p;
+      sph = d2 > SC.hard_p;
+    }
   }
   if (CHECK) { // (pinned host words zeroed by the host before the launch: plain idempotent stores)
     if (__ballot(t) && (threadIdx.x & 63) == 0) flag[0] = 1;
     if (__ballot(h) && (threadIdx.x & 63) == 0) flag[1] = 1;
+  }
+  if (SC.flag && (threadIdx.x & 63) == 0) {
+    if (__ballot(sa)) SC.flag[0] = 1;
+    if (__ballot(sah)) SC.flag[1] = 1;
+    if (__ballot(sp)) SC.flag[2] = 1;
+    if (__ballot(sph)) SC.flag[3] = 1;
   }
 }
 
@@ -339,15 +368,38 @@ __global__ void pack_x_kernel(int n, const int *__restrict__ sendlist, const dou
   buf[3 * (size_t) k + 2] = x.z + (shift ? shift[3 * (size_t) k + 2] : 0.0);
 }
 
-__global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf, double4 *__restrict__ xq)
+// SC: the style-level displacement checks of the arriving remote ghosts (MdpStyleCheck; flag words [4..7])
+__global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf, double4 *__restrict__ xq,
+                                const MdpStyleCheck SC)
 {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  double4 x = xq[first + k];
-  x.x = buf[3 * (size_t) k];
-  x.y = buf[3 * (size_t) k + 1];
-  x.z = buf[3 * (size_t) k + 2];
-  xq[first + k] = x;
+  bool sa = false, sah = false, sp = false, sph = false;
+  if (k < n) {
+    const size_t i = (size_t) first + k;
+    double4 x = xq[i];
+    x.x = buf[3 * (size_t) k];
+    x.y = buf[3 * (size_t) k + 1];
+    x.z = buf[3 * (size_t) k + 2];
+    xq[i] = x;
+    if (SC.xa) {
+      const double dx = x.x - SC.xa[3 * i], dy = x.y - SC.xa[3 * i + 1], dz = x.z - SC.xa[3 * i + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      sa = d2 > SC.trig_a;
+      sah = d2 > SC.hard_a;
+    }
+    if (SC.xp) {
+      const double dx = x.x - SC.xp[3 * i], dy = x.y - SC.xp[3 * i + 1], dz = x.z - SC.xp[3 * i + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      sp = d2 > SC.trig_p;
+      sph = d2 > SC.hard_p;
+    }
+  }
+  if (SC.flag && (threadIdx.x & 63) == 0) {
+    if (__ballot(sa)) SC.flag[4] = 1;
+    if (__ballot(sah)) SC.flag[5] = 1;
+    if (__ballot(sp)) SC.flag[6] = 1;
+    if (__ballot(sph)) SC.flag[7] = 1;
+  }
 }
 
 __global__ void pack_scalar_kernel(int n, const int *__restrict__ sendlist, const double *__restrict__ a,
@@ -636,6 +688,83 @@ int mdp_md_build_neighbors_impl(mdp_ctx *c)
   return mdp_aeam_prepare(c);
 }
 
+// ---- style-level displacement checks fused into the integrate kernel and the halo unpack (MdpStyleCheck) -----------
+void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc)
+{
+  sc = MdpStyleCheck();
+  c->sflag_set ^= 1;
+  const int set = c->sflag_set;
+  int *h = (int *) (c->h_pinned + 32) + 8 * set; // (the kernels that wrote this set ran two steps ago)
+  for (int k = 0; k < 8; k++) h[k] = 0;
+  MdpStyleCheckMeta &m = c->sflag_meta[set];
+  m = MdpStyleCheckMeta();
+  const double scale = mdp_margin_scale(c);
+  if (c->cfg.style == 1 && c->rebo_packed && !c->check_now && c->xhold_all.p && c->skin_inner > 0.0) {
+    double trig = 0.5 * c->skin_inner - kStaleMargin * scale;
+    if (trig < 0.25 * c->skin_inner) trig = 0.25 * c->skin_inner;
+    const double hard = 0.5 * c->skin_inner;
+    sc.xa = c->xhold_all.p;
+    sc.trig_a = trig * trig;
+    sc.hard_a = hard * hard;
+    m.has_style = true;
+    m.build_epoch = c->style_builds;
+  }
+  if (c->prune_valid && c->xhold_prune.p && !c->check_now) {
+    double ptrig = 0.5 * c->prune_buf - kPruneMargin * scale;
+    if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
+    const double phard = 0.5 * c->prune_buf;
+    sc.xp = c->xhold_prune.p;
+    sc.trig_p = ptrig * ptrig;
+    sc.hard_p = phard * phard;
+    m.has_prune = true;
+    m.prune_epoch = c->prune_epoch;
+  }
+  sc.flag = (m.has_style || m.has_prune) ? h : nullptr;
+  if (c->neigh_set && c->acc.p && c->flags.p) { // the compute that follows finds its accumulators reset
+    sc.acc = c->acc.p;
+    sc.nacc = MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS);
+    sc.flags = c->flags.p;
+    sc.ovf = c->ovf.p;
+  }
+  c->sflag_chk = sc;
+  c->sflag_armed = sc.flag != nullptr;
+  if (!c->sflag_armed) c->sflag_pending = false;
+}
+
+int mdp_sflag_commit(mdp_ctx *c)
+{
+  if (!c->sflag_armed) return MDP_OK;
+  if (!c->ev_sflag) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_sflag, hipEventDisableTiming));
+  MDP_HIP(c, hipEventRecord(c->ev_sflag, c->stream));
+  c->sflag_pending = true;
+  c->sflag_read_set = c->sflag_set;
+  return MDP_OK;
+}
+
+// the words of the step before (their last writer was queued a whole compute ago).  *far / *toofar: the style lists'
+// trigger / half their skin, valid only if no list build happened since the check was armed; the pruning part is
+// applied here (prune_stale, dangerous_prunes).
+int mdp_sflag_collect(mdp_ctx *c, bool *far, bool *toofar)
+{
+  if (far) *far = false;
+  if (toofar) *toofar = false;
+  if (!c->sflag_pending) return MDP_OK;
+  MDP_HIP(c, hipEventSynchronize(c->ev_sflag));
+  c->sflag_pending = false;
+  const int set = c->sflag_read_set;
+  const int *h = (const int *) (c->h_pinned + 32) + 8 * set;
+  const MdpStyleCheckMeta &m = c->sflag_meta[set];
+  if (m.has_style && m.build_epoch == c->style_builds) {
+    if (far) *far = (h[0] | h[4]) != 0;
+    if (toofar) *toofar = (h[1] | h[5]) != 0;
+  }
+  if (m.has_prune && m.prune_epoch == c->prune_epoch && c->prune_valid) {
+    if (h[2] | h[6]) c->prune_stale = true;
+    if (h[3] | h[7]) c->dangerous_prunes++;
+  }
+  return MDP_OK;
+}
+
 // launches the integrate kernel of the next step (with_final: after the pending final half-kick of the finished one)
 // and the refresh of the periodic self-images; flag != null: the displacement check of the new positions in the same
 // pass (see mdp_md_integrate_check in domain.hip)
@@ -644,9 +773,11 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
   if (c->nlocal) {
     const int g = nblk(c->nlocal);
+    MdpStyleCheck sc;
+    mdp_sflag_arm(c, sc);
 #define MDP_ADV(FV, CV)                                                                                               \
   nve_advance_kernel<FV, CV><<<g, 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p, c->xq.p, \
-                                                      c->xhold.p, trigsq, hardsq, flag)
+                                                      c->xhold.p, trigsq, hardsq, flag, sc)
     if (with_final) {
       if (flag) MDP_ADV(true, true);
       else MDP_ADV(true, false);
@@ -655,6 +786,9 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
       else MDP_ADV(false, false);
     }
 #undef MDP_ADV
+    c->acc_prezeroed = sc.acc != nullptr;
+    // the flag words are complete behind this kernel unless remote ghosts arrive later in the step (mdp_md_unpack_x)
+    if (!(c->remote_start < c->nall)) MDP_TRY(mdp_sflag_commit(c));
   }
   // periodic self-images come first in the ghost range; remote ghosts are refreshed by the halo exchange
   const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
@@ -850,7 +984,7 @@ int mdp_md_upload_x(mdp_ctx *c, const double *x)
   c->prune_valid = false;
   c->prune_stale = false;
   c->prune_epoch++;
-  c->prune_check_pending = false;
+  c->sflag_pending = false;
   c->check_now = true;
   return MDP_OK;
 }
@@ -1024,8 +1158,15 @@ int mdp_md_pack_x(mdp_ctx *c, int n, const int *d_sendlist, const double *d_shif
 int mdp_md_unpack_x(mdp_ctx *c, int first_ghost, int n, const double *d_buf)
 {
   if (!c || n < 0 || first_ghost < 0 || first_ghost + n > c->nghost) return MDP_EINVAL;
-  if (n) unpack_x_kernel<<<nblk(n), 256, 0, c->stream>>>(n, c->nlocal + first_ghost, d_buf, c->xq.p);
+  // the arriving ghosts are checked against the style's reference positions in the same pass (see MdpStyleCheck)
+  MdpStyleCheck sc;
+  if (c->sflag_armed) {
+    sc = c->sflag_chk;
+    sc.acc = nullptr;
+  }
+  if (n) unpack_x_kernel<<<nblk(n), 256, 0, c->stream>>>(n, c->nlocal + first_ghost, d_buf, c->xq.p, sc);
   MDP_HIP(c, hipGetLastError());
+  if (c->sflag_armed) MDP_TRY(mdp_sflag_commit(c));
   return MDP_OK;
 }
 

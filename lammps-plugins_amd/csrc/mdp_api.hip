@@ -250,6 +250,10 @@ int mdp_acc_begin(mdp_ctx *c, bool any)
 {
   // one small kernel instead of three memsets: at half a million atoms per GPU the gaps around copy-engine
   // operations were 13 % of a step
+  if (c->acc_prezeroed) { // the integrate kernel of this step did it (mdp_sflag_arm)
+    c->acc_prezeroed = false;
+    return MDP_OK;
+  }
   const int n = any ? MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS) : MDP_ACC_STRIDE;
   acc_zero_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->acc.p, n, c->flags.p, c->ovf.p);
   MDP_HIP(c, hipGetLastError());
@@ -752,7 +756,7 @@ int mdp_destroy(mdp_ctx *c)
   c->sort_keys_b.release();
   c->sort_vals_b.release();
   c->nb_cnt.release();
-  if (c->ev_stale_made) (void) hipEventDestroy(c->ev_stale);
+  if (c->ev_sflag) (void) hipEventDestroy(c->ev_sflag);
   if (c->h_pinned) (void) hipHostFree(c->h_pinned);
   if (c->h_small) (void) hipHostFree(c->h_small);
   c->h_small = nullptr;

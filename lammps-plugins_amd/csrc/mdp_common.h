@@ -81,6 +81,31 @@ struct RebomosDev {
   double ljlist_cutsq[4];              // (rcLJmax+skin)^2 : trimmed LJ list
 };
 
+// The style-level displacement checks of a resident run (has an atom moved half the inner skin since the style's lists
+// were built / half the pruning buffer since the rows were pruned?) ride in kernels that touch the positions anyway:
+// owned atoms in the integrate kernel, remote ghosts in the halo unpack; periodic self-images move with their owners.
+// Flag words are pinned host memory, two sets used alternately (the words of step n are read during step n+1, after
+// the integrate kernel of step n+1 was queued): [0] beyond the list trigger [1] beyond half the inner skin [2] beyond
+// the pruning trigger [3] beyond half the buffer; [4..7] the same for remote ghosts.
+struct MdpStyleCheck {
+  const double *xa = nullptr, *xp = nullptr; // positions at the style-list build / at the last row pruning, [nall][3]
+  double trig_a = 0, hard_a = 0, trig_p = 0, hard_p = 0; // squared distances
+  int *flag = nullptr;
+  // accumulators reset by the same kernel (mdp_acc_begin of the compute that follows): acc[0..nacc), flags, ovf[0]
+  double *acc = nullptr;
+  int nacc = 0;
+  int *flags = nullptr, *ovf = nullptr;
+};
+struct MdpStyleCheckMeta {
+  bool has_style = false, has_prune = false;
+  long long build_epoch = -1;
+  int prune_epoch = -1;
+};
+// The deferred triggers are read one compute late, so they fire early by these margins (Angstrom; two steps of motion
+// for the pruned rows: in a multi-GPU run the owned atoms are checked before the halo of the same step arrives)
+constexpr double kStaleMargin = 0.1;
+constexpr double kPruneMargin = 0.07;
+
 // uniform Cartesian bin grid over the bounding box of owned+ghost atoms
 struct MdpGrid {
   double lo[3], inv[3];
@@ -263,10 +288,8 @@ struct mdp_ctx {
   DevBuf<double> xhold_prune;     // [nall][3] positions at the last pruning
   bool prune_valid = false, prune_stale = false;
   double prune_buf = 0.3;
-  int prune_epoch = 0, prune_check_epoch = -1, prune_copied_epoch = -1, prunes = 0, dangerous_prunes = 0;
+  int prune_epoch = 0, prune_copied_epoch = -1, prunes = 0, dangerous_prunes = 0;
   int computes_since_prune = 0;
-  bool prune_check_pending = false; // (styles without a displacement check of their own: mdp_prune_upkeep)
-  hipEvent_t ev_prune = nullptr;
   int tile_rows_cl = 2; // atoms per row of the current tile lists
   DevBuf<int> tile_nu;            // [ntile] members of each union
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
@@ -289,8 +312,13 @@ struct mdp_ctx {
   bool stale_rebuild = false;     // the pending rebuild was asked for by the displacement trigger
   long long style_builds = 0;     // number of style-list builds so far
   long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
-  hipEvent_t ev_stale = nullptr;
-  bool ev_stale_made = false, stale_pending = false;
+  // fused style-level checks (MdpStyleCheck): set armed by the last integrate kernel, event of its last writer
+  int sflag_set = 0, sflag_read_set = 0;
+  bool sflag_armed = false, sflag_pending = false;
+  MdpStyleCheck sflag_chk;
+  MdpStyleCheckMeta sflag_meta[2];
+  hipEvent_t ev_sflag = nullptr;
+  bool acc_prezeroed = false; // the integrate kernel reset the accumulators: the next mdp_acc_begin launches nothing
   bool check_now = false;         // positions were rewritten by the host (mdp_md_upload_x): check the lists before use
   DevBuf<double> fnbr;            // [cand_total][4] force on the slot's neighbour + its share of the pair energy
   DevBuf<double> fown;            // [nall][4] the centre's own share: -(sum of its slot forces), energy
@@ -411,5 +439,8 @@ void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, thre
 int mdp_to_host_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst);   // per-atom arrays, device -> host order
 int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst); // host -> device order
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
+void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc);  // before the integrate kernel: which references, which flag set
+int mdp_sflag_commit(mdp_ctx *c);                   // behind the last kernel that writes this step's flag words
+int mdp_sflag_collect(mdp_ctx *c, bool *far, bool *toofar); // flags of the previous step (waits for their event): style part returned, pruning part applied
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]
 int mdp_flags_check(mdp_ctx *c, const int *hflags5); // overflow bits (last compute | sticky) -> MDP_EOVERFLOW

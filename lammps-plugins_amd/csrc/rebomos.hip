@@ -2730,7 +2730,6 @@ int mdp_rebomos_repack(mdp_ctx *c)
     MDP_HIP(c, hipGetLastError());
   }
   c->rebo_packed = true;
-  c->stale_pending = false;
   c->style_builds++;
   return MDP_OK;
 }
@@ -2813,13 +2812,11 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
 // `neigh_modify check yes`, done by the style for its own lists: has any atom (ghosts included) moved
 // more than half the inner skin since they were built?
 //   host mode     : checked before every compute (the host synchronises each step anyway)
-//   resident mode : the check of step n is read at step n+1 (pinned flag + event), so the CPU never waits
-//                   for the GPU inside the MD loop; the trigger is lowered by kStaleMargin to cover the one
-//                   step of extra motion, and a true violation is counted as a "dangerous build"
-constexpr double kStaleMargin = 0.1; // Angstrom
-constexpr double kPruneMargin = 0.07; // the same for the pruned rows' trigger (their buffer is a fraction of the skin):
-                                      // two steps of motion -- the flag is read one compute later, and in a multi-GPU
-                                      // run the check sees remote ghosts where the previous step left them
+//   resident mode : the check rides in the integrate kernel (owned atoms) and the halo unpack (remote ghosts) of
+//                   step n -- csrc/md.hip, MdpStyleCheck -- and is read at step n+1 (pinned flags + event), so the
+//                   CPU never waits for the GPU inside the MD loop and no kernel of its own reads the positions
+//                   again; the trigger is lowered by kStaleMargin to cover the one step of extra motion, and a true
+//                   violation is counted as a "dangerous build".  (kPruneMargin: the same for the pruned rows.)
 
 static int rebomos_check_launch(mdp_ctx *c, const double trig)
 {
@@ -2834,7 +2831,6 @@ static int rebomos_check_launch(mdp_ctx *c, const double trig)
   double ptrig = 0.5 * c->prune_buf - kPruneMargin * mdp_margin_scale(c);
   if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
   const double phard = 0.5 * c->prune_buf;
-  c->prune_check_epoch = c->prune_epoch;
   moved_kernel<<<grid, 256, 0, st>>>(nall, trig * trig, hard * hard, c->xq.p, c->xhold_all.p, h,
                                      pr ? c->xhold_prune.p : nullptr, ptrig * ptrig, phard * phard);
   MDP_HIP(c, hipGetLastError());
@@ -2847,8 +2843,7 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
   if (!c->nall) return MDP_OK;
   int *h = (int *) (c->h_pinned + 24);
   if (!c->md || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
-    if (c->stale_pending) MDP_HIP(c, hipEventSynchronize(c->ev_stale)); // (a deferred check still writes the flag words)
-    c->stale_pending = false;
+    c->sflag_pending = false; // (words of a check armed before the positions were rewritten)
     c->check_now = false;
     MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
     MDP_HIP(c, hipStreamSynchronize(c->stream));
@@ -2856,28 +2851,10 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
     if (c->prune_valid && h[2]) c->prune_stale = true;
     return MDP_OK;
   }
-  // deferred by one compute
-  if (!c->ev_stale_made) {
-    MDP_HIP(c, hipEventCreateWithFlags(&c->ev_stale, hipEventDisableTiming));
-    c->ev_stale_made = true;
-  }
-  if (c->stale_pending) {
-    MDP_HIP(c, hipEventSynchronize(c->ev_stale)); // recorded a whole step ago
-    stale = h[0] != 0;
-    if (h[1]) c->dangerous_builds++;
-    if (c->prune_check_epoch == c->prune_epoch) { // (a check launched before the last pruning says nothing about it)
-      if (h[2]) c->prune_stale = true;
-      if (h[3]) c->dangerous_prunes++;
-    }
-    c->stale_pending = false;
-  }
-  if (!stale) {
-    double trig = 0.5 * c->skin_inner - kStaleMargin * mdp_margin_scale(c);
-    if (trig < 0.25 * c->skin_inner) trig = 0.25 * c->skin_inner;
-    MDP_TRY(rebomos_check_launch(c, trig));
-    MDP_HIP(c, hipEventRecord(c->ev_stale, c->stream));
-    c->stale_pending = true;
-  }
+  // deferred by one compute: the words the integrate kernel / halo unpack of the previous step wrote
+  bool toofar = false;
+  MDP_TRY(mdp_sflag_collect(c, &stale, &toofar));
+  if (toofar) c->dangerous_builds++;
   return MDP_OK;
 }
 
@@ -2961,27 +2938,11 @@ void mdp_prune_adapt(mdp_ctx *c, const double buf_max, const bool fired)
   else if (c->computes_since_prune > 60 && c->prune_buf - 0.05 >= 0.2 - 1e-9) c->prune_buf -= 0.05;
 }
 
-// A style without a displacement check of its own (aeam) keeps the pruned rows current with this: reads the
-// deferred flag of the previous compute's check, prunes (again) when needed, launches this compute's check.
+// A style without list upkeep of its own (aeam) keeps the pruned rows current with this: reads the flags the
+// integrate kernel and the halo unpack of the previous step left (MdpStyleCheck) and prunes (again) when needed.
 // Call before the first kernel that walks the rows; positions (ghosts included) must be current -- unless
-// may_prune is false: then a pruning that is due is only reported (*due; nothing is launched, the caller comes back
-// once the halo has arrived) and the check may read remote ghosts where the previous step left them (kPruneMargin).
-__global__ __launch_bounds__(256) void moved_prune_kernel(const int nall, const double4 *__restrict__ xq,
-                                                          const double *__restrict__ xprune, const double ptrigsq,
-                                                          const double phardsq, int *__restrict__ flag)
-{
-  bool pfar = false, ptoofar = false;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < nall; i += gridDim.x * 256) {
-    const double4 x = xq[i];
-    const double px = x.x - xprune[3 * (size_t) i], py = x.y - xprune[3 * (size_t) i + 1], pz = x.z - xprune[3 * (size_t) i + 2];
-    const double p2 = px * px + py * py + pz * pz;
-    pfar = pfar || p2 > ptrigsq;
-    ptoofar = ptoofar || p2 > phardsq;
-  }
-  if (__any(pfar) && (threadIdx.x & 63) == 0) flag[2] = 1; // (pinned host memory, zeroed by the host before the launch)
-  if (__any(ptoofar) && (threadIdx.x & 63) == 0) flag[3] = 1;
-}
-
+// may_prune is false: then a pruning that is due is only reported (*due; the caller comes back once the halo has
+// arrived).
 int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin, const bool may_prune, bool *due)
 {
   if (due) *due = false;
@@ -2991,15 +2952,7 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin, const b
     c->prune_valid = false;
     return MDP_OK;
   }
-  int *h = (int *) (c->h_pinned + 24);
-  if (c->prune_check_pending) {
-    MDP_HIP(c, hipEventSynchronize(c->ev_prune)); // recorded a whole compute ago
-    if (c->prune_check_epoch == c->prune_epoch) {
-      if (h[2]) c->prune_stale = true;
-      if (h[3]) c->dangerous_prunes++;
-    }
-    c->prune_check_pending = false;
-  }
+  MDP_TRY(mdp_sflag_collect(c, nullptr, nullptr)); // the previous step's check (integrate kernel, halo unpack)
   mdp_prune_adapt(c, skin - 0.2, c->prune_valid && c->prune_stale);
   if (!(c->prune_buf < skin)) {
     c->prune_valid = false;
@@ -3015,18 +2968,6 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin, const b
     MDP_TRY(mdp_tile_prune(c, lim));
   }
   c->computes_since_prune++;
-  if (!c->ev_prune) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_prune, hipEventDisableTiming));
-  double ptrig = 0.5 * c->prune_buf - kPruneMargin * mdp_margin_scale(c);
-  if (ptrig < 0.25 * c->prune_buf) ptrig = 0.25 * c->prune_buf;
-  const double phard = 0.5 * c->prune_buf;
-  h[2] = h[3] = 0;
-  const int nall = c->nall;
-  const int grid = (nall + 255) / 256 < 2048 ? (nall + 255) / 256 : 2048;
-  moved_prune_kernel<<<grid, 256, 0, c->stream>>>(nall, c->xq.p, c->xhold_prune.p, ptrig * ptrig, phard * phard, h);
-  MDP_HIP(c, hipGetLastError());
-  MDP_HIP(c, hipEventRecord(c->ev_prune, c->stream));
-  c->prune_check_epoch = c->prune_epoch;
-  c->prune_check_pending = true;
   return MDP_OK;
 }
 
