@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MDP_ABI_VERSION 2
+#define MDP_ABI_VERSION 3
 
 enum {
   MDP_OK = 0,
@@ -215,6 +215,11 @@ int mdp_md_final_integrate(mdp_ctx *ctx);   /* v += dt/2 f/m */
  * nothing (no thermo output, no dump at that step): it skips mdp_md_final_integrate there and opens the next step
  * with this call instead of mdp_md_initial_integrate. */
 int mdp_md_final_initial_integrate(mdp_ctx *ctx);
+/* the host's declaration that it skips mdp_md_final_integrate for the step just computed and will open the next step
+ * with mdp_md_final_initial_integrate / mdp_md_integrate_check(with_final).  Until then the velocities on the device
+ * are half-step velocities: mdp_md_thermo and a velocity download complete the kick themselves first (and the
+ * with_final call that follows then applies only the initial half-kick), so nothing reads half-step values unnoticed. */
+int mdp_md_defer_final(mdp_ctx *ctx);
 int mdp_md_compute(mdp_ctx *ctx, int eflag, int vflag); /* force_clear + Pair::compute on the device */
 /* the same in two halves for multi-GPU runs: _begin needs only owned atoms, self-image ghosts and LAST step's
  * remote ghosts (it runs while this step's halo exchange is in flight: the work whose lists reach no remote
@@ -268,6 +273,11 @@ int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
  * deferred trigger was read; the analogue of LAMMPS' "dangerous builds"), [2]=1 if the kernels currently walk pruned
  * rows, [3]=buffer in units of 1e-6 Angstrom */
 int mdp_md_prune_stats(mdp_ctx *ctx, long long out[4]);
+/* out[0] = skin of the style's own lists in effect (rebomos: the inner skin, adaptive or MDP_INNER_SKIN; aeam: the
+ * host's), [1] = cap on the inner skin, 0 = none (a candidate row outgrew the 64-bit active mask at that skin: the
+ * lists were rebuilt with half of it), [2] = pruning buffer in effect (0: rows as built),
+ * [3] = list builds that came late (an atom was beyond half the inner skin when the deferred trigger was read) */
+int mdp_md_list_state(mdp_ctx *ctx, double out[4]);
 /* shape of the rebomos style's own Lennard-Jones lists after the last build (host and resident mode):
  * out[0]=1 tile lists / 0 per-cluster lists (fallback), [1]=#tiles, [2]=union stride, [3]=largest union,
  * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void dd_self_ghost_kernel(const int nself, con
 // `neigh_modify check yes` on the host-level skin, owned atoms (Neighbor::check_distance): flag[0] = some atom is
 // beyond the trigger distance, flag[1] = some atom is beyond half the skin itself (a build that came too late)
 __global__ __launch_bounds__(256) void dd_moved_kernel(const int n, const double trigsq, const double hardsq,
-                                                       const double4 *__restrict__ xq, const double *__restrict__ xhold,
+                                                       const double4 *__restrict__ xq, const mdp_hold_t *__restrict__ xhold,
                                                        int *__restrict__ flag)
 {
   bool t = false, h = false;
@@ -893,15 +893,20 @@ int mdp_md_download_int(mdp_ctx *c, const char *name, int *out)
   if (!c || !name || !out) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   const int *src = !strcmp(name, "tag") ? c->tag.p : (!strcmp(name, "type") ? c->type.p : nullptr);
+  MDP_HIP(c, hipSetDevice(c->device));
   if (!strcmp(name, "tile_nu")) { // diagnostics: {members of the union, Mo members} of every tile, 2 * ntile <= nlocal ints
     if (2 * c->ntile > c->nlocal) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: tile_nu needs 2 * %d ints", c->ntile);
-    if (c->ntile) MDP_HIP(c, hipMemcpyAsync(out, c->tile_nu.p, sizeof(int) * 2 * c->ntile, hipMemcpyDeviceToHost, c->stream));
-    MDP_HIP(c, hipStreamSynchronize(c->stream));
-    return MDP_OK;
+    src = c->tile_nu.p;
   }
   if (!src) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: unknown array '%s'", name);
-  if (c->nlocal) MDP_HIP(c, hipMemcpyAsync(out, src, sizeof(int) * c->nlocal, hipMemcpyDeviceToHost, c->stream));
-  MDP_HIP(c, hipStreamSynchronize(c->stream));
+  // through the context's pinned buffer, complete on return (no asynchronous copy into the caller's pageable memory)
+  const size_t n = !strcmp(name, "tile_nu") ? (size_t) 2 * c->ntile : (size_t) c->nlocal;
+  if (n) {
+    MDP_TRY(mdp_host_pinned_reserve(c, (n * sizeof(int) + 7) / 8 + 1));
+    MDP_HIP(c, hipMemcpyAsync(c->h_down, src, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    MDP_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_down, sizeof(int) * n);
+  }
   return MDP_OK;
 }
 

@@ -206,7 +206,7 @@ __global__ void ang_select_kernel(const int nlocal, const int min_type, const do
 template <bool FINAL, bool CHECK>
 __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
                                    const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
-                                   const double *__restrict__ xhold, const double trigsq, const double hardsq,
+                                   const mdp_hold_t *__restrict__ xhold, const double trigsq, const double hardsq,
                                    int *__restrict__ flag, const MdpStyleCheck SC)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -322,20 +322,20 @@ __global__ void fold_self_ghost_f_kernel(int nlocal, int nghost, const int *__re
   }
 }
 
-__global__ void hold_kernel(int nlocal, const double4 *__restrict__ xq, double *__restrict__ xhold)
+__global__ void hold_kernel(int nlocal, const double4 *__restrict__ xq, mdp_hold_t *__restrict__ xhold)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nlocal) return;
   const double4 x = xq[i];
-  xhold[3 * (size_t) i] = x.x;
-  xhold[3 * (size_t) i + 1] = x.y;
-  xhold[3 * (size_t) i + 2] = x.z;
+  xhold[3 * (size_t) i] = (mdp_hold_t) x.x;
+  xhold[3 * (size_t) i + 1] = (mdp_hold_t) x.y;
+  xhold[3 * (size_t) i + 2] = (mdp_hold_t) x.z;
 }
 
 // out[7] += KE, out[8] = max(out[8], disp^2)   (acc[7], acc[8])
 __global__ __launch_bounds__(256) void thermo_kernel(int nlocal, double half_mvv2e, const double *__restrict__ rmass,
                                                      const double *__restrict__ v, const double4 *__restrict__ xq,
-                                                     const double *__restrict__ xhold, double *__restrict__ acc)
+                                                     const mdp_hold_t *__restrict__ xhold, double *__restrict__ acc)
 {
   double ke = 0.0, d2 = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nlocal; i += gridDim.x * 256) {
@@ -659,6 +659,11 @@ int mdp_md_setup(mdp_ctx *c, const mdp_md_config *cfg, const double *x, const do
   MDP_HIP(c, hipMemsetAsync(c->fp.p, 0, sizeof(double) * nall, st));
   MDP_HIP(c, hipStreamSynchronize(st));
   c->remote_start = nlocal + (cfg->nghost_self >= 0 && cfg->nghost_self <= nghost ? cfg->nghost_self : nghost);
+  // (ghosts below remote_start are refreshed from -- and, for rebomos, computed through -- their owners)
+  for (int g = 0; g < c->remote_start - nlocal; g++)
+    if (ghost_owner[g] < 0 || ghost_owner[g] >= nlocal)
+      return mdp_fail(c, MDP_EINVAL, "mdp_md_setup: ghost %d is declared a periodic self-image (nghost_self = %d) but has no owner",
+                      g, c->remote_start - nlocal);
   c->md = true;
   return MDP_OK;
 }
@@ -770,6 +775,10 @@ int mdp_sflag_collect(mdp_ctx *c, bool *far, bool *toofar)
 // pass (see mdp_md_integrate_check in domain.hip)
 int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq)
 {
+  // a deferred final half-kick (mdp_md_defer_final) that a thermo / velocity read has completed in the meantime
+  // must not be applied twice
+  if (c->final_deferred_seen && with_final && !c->final_pending) with_final = false;
+  if (with_final) c->final_pending = false;
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
   if (c->nlocal) {
     const int g = nblk(c->nlocal);
@@ -814,10 +823,20 @@ int mdp_md_final_initial_integrate(mdp_ctx *c)
   return mdp_md_advance(c, true, nullptr, 0.0, 0.0);
 }
 
+int mdp_md_defer_final(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  c->final_pending = true;
+  c->final_deferred_seen = true;
+  return MDP_OK;
+}
+
 int mdp_md_final_integrate(mdp_ctx *c)
 {
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  c->final_pending = false;
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
   if (c->nlocal) nve_final_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, dtf, c->rmass.p, c->f.p, c->v.p);
   MDP_HIP(c, hipGetLastError());
@@ -912,6 +931,7 @@ int mdp_md_thermo(mdp_ctx *c, double out[9])
 {
   if (!c || !out) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  if (c->final_pending) MDP_TRY(mdp_md_final_integrate(c)); // KE is that of full-step velocities
   hipStream_t st = c->stream;
   MDP_HIP(c, hipMemsetAsync(c->acc.p + 7, 0, sizeof(double) * 2, st));
   const int grid = c->nlocal > 0 ? (nblk(c->nlocal) < 1024 ? nblk(c->nlocal) : 1024) : 0;
@@ -935,6 +955,7 @@ int mdp_md_download(mdp_ctx *c, double *x, double *v, double *f, double *eatom)
 {
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  if (v && c->final_pending) MDP_TRY(mdp_md_final_integrate(c)); // full-step velocities
   hipStream_t st = c->stream;
   const int n = c->nlocal;
   if (x && n) {
@@ -1133,6 +1154,16 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
     out[6] += (long long) h[4] + h[5] + h[6] + h[7]; // 12- and 16-lane groups
   }
   out[7] = c->cfg.style == 1 ? c->style_builds : c->h_ang_count;
+  return MDP_OK;
+}
+
+int mdp_md_list_state(mdp_ctx *c, double out[4])
+{
+  if (!c || !out) return MDP_EINVAL;
+  out[0] = c->cfg.style == 1 ? c->skin_inner : c->cfg.skin;
+  out[1] = c->skin_inner_cap < 1.0e8 ? c->skin_inner_cap : 0.0;
+  out[2] = c->prune_valid ? c->prune_buf : 0.0;
+  out[3] = (double) c->dangerous_builds;
   return MDP_OK;
 }
 

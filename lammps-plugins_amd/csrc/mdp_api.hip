@@ -321,6 +321,9 @@ static bool host_register(mdp_ctx *c, const void *ptr, size_t bytes)
 // workers are started once per process and sleep on a condition variable between calls: starting and joining
 // eight threads for each of the fifteen 12-16 MB pieces of a step cost about as much as moving the bytes.
 // One parallel section at a time; a second caller (another context's thread) runs its pieces itself.
+// fork(): the library is not usable in a child forked after first use (neither is the HIP runtime under it); the pool at
+// least never touches the mutexes, condition variables and thread handles it inherited -- whatever state the parent's
+// threads left them in -- and runs the pieces of a call serially there.
 namespace {
 class HostWorkers
 {
@@ -334,7 +337,7 @@ class HostWorkers
   // fn(k) for k = 0 .. n-1, the caller taking part
   template <typename F> void run(const unsigned n, const F &fn)
   {
-    if (n <= 1 || nthreads <= 1 || !busy.try_lock()) {
+    if (n <= 1 || nthreads <= 1 || (owner != 0 && getpid() != owner) || !busy.try_lock()) {
       for (unsigned k = 0; k < n; k++) fn(k);
       return;
     }
@@ -369,26 +372,21 @@ class HostWorkers
   }
   ~HostWorkers()
   {
+    if (owner != 0 && getpid() != owner) return; // forked child: the handles are the parent's (and `th` is leaked on purpose)
     {
       std::lock_guard<std::mutex> g(mu);
       stop = true;
     }
     cv.notify_all();
-    for (auto &t : th) {
-      if (getpid() == owner) t.join();
-      else t.detach(); // (a forked child inherits the objects, not the threads)
-    }
+    for (auto &t : *th) t.join();
+    delete th;
   }
-  void start() // (mu held)
+  void start() // (mu held; never in a forked child: run() has sent it down the serial path)
   {
-    if (!th.empty() && getpid() == owner) return;
-    if (!th.empty()) { // forked child: the workers stayed with the parent
-      for (auto &t : th) t.detach();
-      th.clear();
-    }
+    if (!th->empty()) return;
     owner = getpid();
     for (unsigned t = 1; t < nthreads; t++)
-      th.emplace_back([this] {
+      th->emplace_back([this] {
         unsigned long seen = 0;
         for (;;) {
           {
@@ -421,7 +419,7 @@ class HostWorkers
   }
   std::mutex busy, mu;
   std::condition_variable cv, cv_done;
-  std::vector<std::thread> th;
+  std::vector<std::thread> *th = new std::vector<std::thread>(); // (on the heap: a forked child must not destroy the handles)
   const std::function<void(unsigned)> *job = nullptr;
   unsigned nthreads = 1, njobs = 0, next = 0, done = 0;
   unsigned long gen = 0;

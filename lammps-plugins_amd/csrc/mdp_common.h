@@ -87,8 +87,12 @@ struct RebomosDev {
 // Flag words are pinned host memory, two sets used alternately (the words of step n are read during step n+1, after
 // the integrate kernel of step n+1 was queued): [0] beyond the list trigger [1] beyond half the inner skin [2] beyond
 // the pruning trigger [3] beyond half the buffer; [4..7] the same for remote ghosts.
+// Reference positions of the displacement checks (at the last reneighboring, style-list build, row pruning): single
+// precision -- the triggers have margins of 0.07-0.1 A, a float resolves 6e-5 A at |x| = 1000 A -- which takes 36 of
+// the 216 bytes per atom out of the integrate kernel.
+typedef float mdp_hold_t;
 struct MdpStyleCheck {
-  const double *xa = nullptr, *xp = nullptr; // positions at the style-list build / at the last row pruning, [nall][3]
+  const mdp_hold_t *xa = nullptr, *xp = nullptr; // positions at the style-list build / at the last row pruning, [nall][3]
   double trig_a = 0, hard_a = 0, trig_p = 0, hard_p = 0; // squared distances
   int *flag = nullptr;
   // accumulators reset by the same kernel (mdp_acc_begin of the compute that follows): acc[0..nacc), flags, ovf[0]
@@ -285,7 +289,7 @@ struct mdp_ctx {
   // until an atom has moved prune_buf/2 since (second trigger of moved_kernel), then they are pruned again
   DevBuf<unsigned short> lj16_in; // pruned rows, at the offsets of the rows as built
   DevBuf<int> lj_len_in, lj_split_in; // their lengths and splits
-  DevBuf<double> xhold_prune;     // [nall][3] positions at the last pruning
+  DevBuf<mdp_hold_t> xhold_prune; // [nall][3] positions at the last pruning
   bool prune_valid = false, prune_stale = false;
   double prune_buf = 0.3;
   int prune_epoch = 0, prune_copied_epoch = -1, prunes = 0, dangerous_prunes = 0;
@@ -304,7 +308,7 @@ struct mdp_ctx {
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride
   DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
-  DevBuf<double> xhold_all;       // [nall][3] positions when the style lists were built
+  DevBuf<mdp_hold_t> xhold_all;   // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
   double skin_inner_auto = 1.0;   // adaptive default of it (grows when the displacement trigger fires too often)
   double skin_inner_cap = 1.0e9;  // a skin at which a candidate row outgrew the 64-bit active mask (dense systems)
@@ -318,6 +322,8 @@ struct mdp_ctx {
   MdpStyleCheck sflag_chk;
   MdpStyleCheckMeta sflag_meta[2];
   hipEvent_t ev_sflag = nullptr;
+  bool final_pending = false;      // the host deferred the final half-kick of the finished step (mdp_md_defer_final)
+  bool final_deferred_seen = false; // the host uses mdp_md_defer_final at all (older hosts: with_final is authoritative)
   bool acc_prezeroed = false; // the integrate kernel reset the accumulators: the next mdp_acc_begin launches nothing
   bool check_now = false;         // positions were rewritten by the host (mdp_md_upload_x): check the lists before use
   DevBuf<double> fnbr;            // [cand_total][4] force on the slot's neighbour + its share of the pair energy
@@ -349,7 +355,7 @@ struct mdp_ctx {
   bool md = false;
   mdp_md_config cfg;
   DevBuf<double> v;          // [nlocal][3]
-  DevBuf<double> xhold;      // [nlocal][3] positions at last build
+  DevBuf<mdp_hold_t> xhold;  // [nlocal][3] positions at last build
   DevBuf<double> rmass;      // [nlocal]
   DevBuf<int> ghost_owner;   // [nghost]
   DevBuf<double> ghost_shift;// [nghost][3]

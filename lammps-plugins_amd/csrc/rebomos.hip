@@ -293,17 +293,29 @@ __device__ __forceinline__ void centre_tally(const CentreOut &o, double *__restr
 
 // phase A for one candidate: distance test against rcmax (pair_rebomos.cpp:337), ballot compaction into
 // the centre's LDS slots in candidate order.  Returns nothing; updates n / active / nsum.
+// A candidate a hair outside rcmax (rsq within 1e-14 relative) gets an explicit ZERO slot record.  The gather of an
+// owned atom next to a periodic image of a centre reads the slot the centre ITSELF keeps for the atom's image
+// (rev_kernel: image centres are not computed at all), and decides with its own distance test, whose operands are
+// rounded differently: fl(x_a - fl(x_o + s)) against fl(x_o - fl(x_a - s)).  When the two tests disagree the pair
+// sits at rcmax to the last bits, where the switching function -- and with it every term of the record -- is zero.
 template <int G, int CAP, int REC>
 __device__ __forceinline__ void centre_take(const RebomosDev &P, const int tc, const double4 xc, const bool valid,
                                             const int t, const double4 xj, const int s, const int glane0,
                                             const int base, double *rec, int *je, int &n,
-                                            unsigned long long &active, double &nsum)
+                                            unsigned long long &active, double &nsum, double4 *__restrict__ slot4,
+                                            double *__restrict__ vslot)
 {
   const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
   const double dx = xc.x - xj.x, dy = xc.y - xj.y, dz = xc.z - xj.z;
   const double rsq = dx * dx + dy * dy + dz * dz;
   const int tj = (int) xj.w;
-  const bool pred = valid && rsq < P.rcmaxsq[tc * 2 + tj];
+  const double rc2 = P.rcmaxsq[tc * 2 + tj];
+  const bool pred = valid && rsq < rc2;
+  if (valid && !pred && rsq < rc2 * (1.0 + 1.0e-14)) { // (practically never taken)
+    slot4[t] = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (vslot)
+      for (int k = 0; k < 6; k++) vslot[6 * (size_t) t + k] = 0.0;
+  }
   const unsigned long long bal = __ballot(pred);
   const unsigned long long gb = (bal >> glane0) & gmask;
   const int pos = n + __popcll(gb & ((1ull << s) - 1ull));
@@ -398,7 +410,8 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
     for (int u = 0; u < C::UA; u++) xj[u] = xq[jp[u] >= 0 ? jp[u] : c];
 #pragma unroll
     for (int u = 0; u < C::UA; u++)
-      centre_take<G, C::CAP, kRecF>(P, tc, xc, jp[u] >= 0, u * G + s, xj[u], s, glane0, u * G, rec, je, n, active, nsum);
+      centre_take<G, C::CAP, kRecF>(P, tc, xc, jp[u] >= 0, u * G + s, xj[u], s, glane0, u * G, rec, je, n, active, nsum,
+                                    reinterpret_cast<double4 *>(fnbr) + off, nullptr);
   }
   const int ncw = wave_max_int(nc);
   for (int base = W; base < ncw; base += W) { // rows longer than the packed part (rare)
@@ -414,7 +427,8 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
 #pragma unroll
     for (int u = 0; u < C::UA; u++) {
       const int t = base + u * G + s;
-      centre_take<G, C::CAP, kRecF>(P, tc, xc, t < nc, t, xj[u], s, glane0, base + u * G, rec, je, n, active, nsum);
+      centre_take<G, C::CAP, kRecF>(P, tc, xc, t < nc, t, xj[u], s, glane0, base + u * G, rec, je, n, active, nsum,
+                                    reinterpret_cast<double4 *>(fnbr) + off, nullptr);
     }
   }
   if (have && s == 0) amask[c] = active;
@@ -600,7 +614,8 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
       const int t = base + s;
       const int j = t < nc ? cand[off + t] : c;
       const double4 xj = xq[j];
-      centre_take<G, CAP, kRec>(P, tc, xc, t < nc, t, xj, s, glane0, base, rec, je, n, active, nsum);
+      centre_take<G, CAP, kRec>(P, tc, xc, t < nc, t, xj, s, glane0, base, rec, je, n, active, nsum,
+                                reinterpret_cast<double4 *>(fnbr) + off, VATOM ? vslot + 6 * (size_t) off : nullptr);
     }
     if (n > CAP) {
       if (s == 0) atomicOr(&flags[0], 1);
@@ -2131,7 +2146,8 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
                                                          const double4 *__restrict__ xq, const int *__restrict__ perm,
                                                          const int *__restrict__ cell_start, int *__restrict__ cnt,
                                                          const int *__restrict__ off, int *__restrict__ cand,
-                                                         int *__restrict__ is_centre)
+                                                         int *__restrict__ is_centre,
+                                                         const int mark_from /* ghosts below it are periodic images of owned atoms: no centres (rev_kernel) */)
 {
   const int lane = threadIdx.x & 63;
   const int s = lane % RP_L;
@@ -2190,7 +2206,7 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
         const unsigned long long bk = (__ballot(keep) >> glane0) & 0xFFFFull;
         if (keep) {
           if (MODE == 2) row[n + __popcll(bk & below)] = j;
-          if (MODE == 0 && j >= nlocal) is_centre[j] = 1;
+          if (MODE == 0 && j >= mark_from) is_centre[j] = 1;
         }
         n += __popcll(bk);
       }
@@ -2199,22 +2215,22 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
 }
 
 // positions at list-build time (all atoms, ghosts included) and the displacement trigger
-__global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, double *__restrict__ xhold)
+__global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, mdp_hold_t *__restrict__ xhold)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nall) return;
   const double4 x = xq[i];
-  xhold[3 * (size_t) i] = x.x;
-  xhold[3 * (size_t) i + 1] = x.y;
-  xhold[3 * (size_t) i + 2] = x.z;
+  xhold[3 * (size_t) i] = (mdp_hold_t) x.x;
+  xhold[3 * (size_t) i + 1] = (mdp_hold_t) x.y;
+  xhold[3 * (size_t) i + 2] = (mdp_hold_t) x.z;
 }
 
 // flag[0]: someone moved beyond the trigger; flag[1]: beyond the hard limit (half the inner skin)
 // flag[2], flag[3]: the same against the positions of the last pruning of the rows (xprune, may be null)
 __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double trigsq, const double hardsq,
                                                     const double4 *__restrict__ xq,
-                                                    const double *__restrict__ xhold, int *__restrict__ flag,
-                                                    const double *__restrict__ xprune, const double ptrigsq,
+                                                    const mdp_hold_t *__restrict__ xhold, int *__restrict__ flag,
+                                                    const mdp_hold_t *__restrict__ xprune, const double ptrigsq,
                                                     const double phardsq)
 {
   bool far = false, toofar = false, pfar = false, ptoofar = false;
@@ -2246,9 +2262,17 @@ __global__ __launch_bounds__(256) void moved_kernel(const int nall, const double
 // rev[slot of j in cand(a)] = absolute slot of a in cand(j), for owned a (static between list builds)
 // rev16: the first 16 reverse slots of every owned atom at a fixed stride (-1 beyond the row), so that the
 // gather reaches a slot record in two dependent loads instead of three (no row offset to fetch first)
+// A neighbour j that is a periodic image of an owned atom o (nlocal <= j < self_end; resident runs know owner and
+// shift) is no centre of its own: the force its cluster would put on a is the force o's cluster puts on the image
+// a' = a - shift_j (translation invariance), which o's centre stores under a' anyway.  The reverse slot of (a, j) is
+// therefore o's slot of a', found by tag and position.  A pair for which it is not found sits at the outer edge of the
+// list skin on one side only (distances rounded differently) and cannot become active before the next list build.
 __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *__restrict__ cand_off,
                                                   const int *__restrict__ cand, int *__restrict__ rev,
-                                                  int *__restrict__ rev16, int *__restrict__ flags)
+                                                  int *__restrict__ rev16, int *__restrict__ flags,
+                                                  const int self_end, const double4 *__restrict__ xq,
+                                                  const int *__restrict__ tag, const int *__restrict__ ghost_owner,
+                                                  const double *__restrict__ ghost_shift)
 {
   const int s = threadIdx.x % RP_L;
   const long long a64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
@@ -2258,13 +2282,32 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
   if (nc > 64 && s == 0) atomicOr(&flags[1], 1); // the active mask holds 64 candidates
   for (int t = s; t < nc; t += RP_L) {
     const int j = cand[off + t];
-    const int oj = cand_off[j], nj = cand_off[j + 1] - oj;
     int r = -1;
-    for (int u = 0; u < nj; u++)
-      if (cand[oj + u] == a) {
-        r = oj + u;
-        break;
+    if (j >= nlocal && j < self_end) { // a periodic image: its owner's slot of MY image
+      const int o = ghost_owner[j - nlocal];
+      const double *sh = ghost_shift + 3 * (size_t) (j - nlocal);
+      const double4 xa = xq[a];
+      const double px = xa.x - sh[0], py = xa.y - sh[1], pz = xa.z - sh[2];
+      const int ta = tag[a];
+      const int oo = cand_off[o], no = cand_off[o + 1] - oo;
+      for (int u = 0; u < no; u++) {
+        const int k = cand[oo + u];
+        if (tag[k] != ta) continue;
+        const double4 xk = xq[k];
+        const double ex = xk.x - px, ey = xk.y - py, ez = xk.z - pz;
+        if (ex * ex + ey * ey + ez * ez < 1.0e-6) {
+          r = oo + u;
+          break;
+        }
       }
+    } else {
+      const int oj = cand_off[j], nj = cand_off[j + 1] - oj;
+      for (int u = 0; u < nj; u++)
+        if (cand[oj + u] == a) {
+          r = oj + u;
+          break;
+        }
+    }
     rev[off + t] = r;
     if (t < 16) rev16[(size_t) a * 16 + t] = r;
   }
@@ -2530,16 +2573,22 @@ int mdp_rebomos_repack(mdp_ctx *c)
   candcut = sqrt(candcut);
   MDP_TRY(mdp_bin_atoms(c, ljcut, c->bbox_lo, c->bbox_hi));
   const int Rc = candcut <= 0.5 * ljcut ? 1 : 2; // cells are >= ljcut/2 wide
+  // Resident runs know which ghosts are periodic images of owned atoms (owner, shift): those are no centres of their
+  // own, the gather of their owned neighbours reads the owner centre's slots instead (rev_kernel).  MDP_IMAGE_CENTRES=1
+  // computes them as before (A/B switch).
+  static const bool image_centres = getenv("MDP_IMAGE_CENTRES") && atoi(getenv("MDP_IMAGE_CENTRES")) != 0;
+  const int self_end = (c->md && !image_centres && c->ghost_owner.p && c->tag.p && c->remote_start > nlocal)
+                           ? (c->remote_start < nall ? c->remote_start : nall) : nlocal;
   const int per_block = 256 / RP_L;
   const int nghost = nall - nlocal;
   if (nlocal)
     cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        nullptr, c->is_center.p);
+        nullptr, c->is_center.p, self_end);
   if (nghost)
     cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        nullptr, c->is_center.p);
+        nullptr, c->is_center.p, self_end);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
   // Lennard-Jones lists: tile lists for the default cluster size, unless switched off or a union outgrows LDS
@@ -2632,7 +2681,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (nall)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
-        c->cand.p, c->is_center.p);
+        c->cand.p, c->is_center.p, self_end);
   if (tiled) MDP_TRY(tile_sort_launch(c, ntile));
   if (tiled)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
@@ -2687,7 +2736,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
-                                                                     c->rev16.p, c->flags.p);
+                                                                     c->rev16.p, c->flags.p, self_end, c->xq.p, c->tag.p,
+                                                                     c->ghost_owner.p, c->ghost_shift.p);
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
@@ -2702,6 +2752,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
     // would still be short) are rebuilt with half the skin, down to 0.2 A: then only 65 atoms inside rcmax
     // itself (3.8 A: six times the density of MoS2) stop the run, with the reference's words.
     if (c->skin_inner > 0.2 + 1e-9 && !getenv("MDP_INNER_SKIN")) {
+      fprintf(stderr, "[mdp] rebomos: a candidate row (atoms within rcmax + inner skin) outgrew 64 entries at an inner skin "
+                      "of %.2f A; the style's lists are rebuilt with %.2f A and keep that cap (mdp_md_list_state)\n",
+              c->skin_inner, 0.5 * c->skin_inner > 0.2 ? 0.5 * c->skin_inner : 0.2);
       c->skin_inner_cap = c->skin_inner;
       c->skin_inner_auto = 0.5 * c->skin_inner > 0.2 ? 0.5 * c->skin_inner : 0.2;
       c->stale_rebuild = false;

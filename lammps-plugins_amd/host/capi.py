@@ -64,7 +64,7 @@ EXPORTS = [
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
     "mdp_dd_comm_allreduce", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
-    "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
+    "mdp_md_defer_final", "mdp_md_list_state", "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
 ]
 
 
@@ -330,6 +330,14 @@ class Context:
 
     def md_final_integrate(self):
         self._ck(self.L.mdp_md_final_integrate(self.h))
+
+    def md_defer_final(self):
+        self._ck(self.L.mdp_md_defer_final(self.h))
+
+    def md_list_state(self):
+        out = (C.c_double * 4)()
+        self._ck(self.L.mdp_md_list_state(self.h, out))
+        return dict(skin=out[0], inner_skin_cap=out[1], prune_buffer=out[2], late_builds=int(out[3]))
 
     def md_final_initial_integrate(self):
         self._ck(self.L.mdp_md_final_initial_integrate(self.h))

@@ -351,6 +351,7 @@ class DeviceDomain:
             self._aeam_step_compute(eflag, vflag, fresh)
         if defer_final:
             self._final_pending = True
+            ctx.md_defer_final()        # (the library completes the kick itself if velocities are read before the next step)
         else:
             ctx.md_final_integrate()
 
@@ -374,6 +375,7 @@ class DeviceDomain:
 
     def needs_rebuild(self, margin: float = 0.0) -> bool:
         """blocking check, collective over the ranks: some owned atom moved more than skin/2 - margin"""
+        self.flush()
         t = self.ctx.md_thermo()
         need = t["maxdisp2"] > max(0.5 * self.skin - margin, 0.25 * self.skin) ** 2
         if t["maxdisp2"] > (0.5 * self.skin) ** 2:

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/mdpair_hip.h but not exported"
     assert sorted(capi.EXPORTS) == declared
-    assert L.mdp_abi_version() == 2
+    assert L.mdp_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -207,3 +207,31 @@ def test_deferred_final_integrate_gives_the_same_trajectory(style):
     for ta, tb in zip(a[3], b[3]):
         assert ta["ke"] == pytest.approx(tb["ke"], rel=1e-13)   # (sums through atomics: not ordered)
         assert ta["pe"] == pytest.approx(tb["pe"], rel=1e-13)
+
+
+def test_deferred_final_kick_is_completed_when_velocities_are_read():
+    """A host that defers the final half-kick (mdp_md_defer_final) and then reads KE or velocities straight through
+    the C-ABI gets full-step values: the library completes the kick itself, and the with_final call that opens the
+    next step then applies only the initial half-kick (no double kick)."""
+    p = capi.read_rebomos_file(POT_REBOMOS)
+    s = S.replicate(S.rebomos_bulk_cell(), (2, 2, 1))
+    v0 = S.gaussian_velocities(s, 600.0, seed=9)
+    out = {}
+    for defer in (False, True):
+        ctx = capi.Context(0)
+        ctx.rebomos_set_params(p)
+        d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1], v0=v0)
+        d.compute(0, 0)
+        for _ in range(5):
+            d.step(0, 0, defer_final=defer)
+        ke_mid = ctx.md_thermo()["ke"]                       # NOT d.thermo(): no flush on the Python side
+        v_mid = ctx.md_download(d.nlocal, want=("v",))["v"]
+        for _ in range(5):
+            d.step(0, 0, defer_final=defer)                  # (Python still believes a kick is pending: with_final = 1)
+        d.flush()
+        got = ctx.md_download(d.nlocal, want=("x", "v"))
+        out[defer] = (ke_mid, v_mid, got["x"], got["v"])
+        ctx.close()
+    assert out[True][0] == pytest.approx(out[False][0], rel=1e-14)
+    for k in (1, 2, 3):
+        assert np.array_equal(out[True][k], out[False][k])
