@@ -108,8 +108,9 @@ int mdp_aeam_set_tables(mdp_ctx *ctx, const mdp_aeam_tables *t);
  * interpolate (:876-942).  map[1..ntypes] = element index of each atom type, -1 for NULL. */
 typedef struct mdp_aeam_file mdp_aeam_file;
 int mdp_aeam_file_read(const char *path, mdp_aeam_file **out, char *err, int errlen);
-int mdp_aeam_file_info(const mdp_aeam_file *f, int *nelements, int *nnonangular, int *nangular,
-                       double *mass /* [8]: one per element, at most 8 elements */, char *names, int nameslen);
+/* mass[mass_cap]: one per element (a file may define up to 64; call with mass = NULL to learn nelements first) */
+int mdp_aeam_file_info(const mdp_aeam_file *f, int *nelements, int *nnonangular, int *nangular, double *mass,
+                       int mass_cap, char *names, int nameslen);
 int mdp_aeam_file_build(mdp_aeam_file *f, int ntypes, const int *map, mdp_aeam_tables *out); /* out points into f */
 void mdp_aeam_file_free(mdp_aeam_file *f);
 

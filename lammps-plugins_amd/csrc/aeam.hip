@@ -69,32 +69,59 @@ __device__ __forceinline__ int spline_index(double r, double rdr, int nr, double
 
 // per-pair-type parameters of one centre type against every neighbour type, kept in registers
 // (selected with compares on the neighbour's type: no per-lane loads from the parameter block)
-template <int NT> struct PairPar {
-  double cut[NT], rdr[NT];
-  int nr[NT], trho[NT], tz2r[NT];
-};
-
-template <int NT> __device__ __forceinline__ PairPar<NT> load_pairpar(const AeamDev &A, const int ti, const bool transposed)
-{
-  PairPar<NT> q;
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const int pt = transposed ? t * A.ntypes + ti : ti * A.ntypes + t;
-    q.cut[t] = A.cut[pt];
-    q.rdr[t] = A.rdr[pt];
-    q.nr[t] = A.nr[pt];
-    q.trho[t] = A.t2rhor[pt];
-    q.tz2r[t] = A.t2z2r[pt];
-  }
-  return q;
-}
-
 template <int NT, typename T> __device__ __forceinline__ T pick(const T (&a)[NT], const int t)
 {
   T v = a[0];
 #pragma unroll
   for (int k = 1; k < NT; k++) v = (t == k) ? a[k] : v;
   return v;
+}
+
+template <int NT> struct PairPar {
+  double cut[NT], rdr[NT];
+  int nr[NT], trho[NT], tz2r[NT];
+  __device__ __forceinline__ double cut_(const int t) const { return pick<NT>(cut, t); }
+  __device__ __forceinline__ double rdr_(const int t) const { return pick<NT>(rdr, t); }
+  __device__ __forceinline__ int nr_(const int t) const { return pick<NT>(nr, t); }
+  __device__ __forceinline__ int trho_(const int t) const { return pick<NT>(trho, t); }
+  __device__ __forceinline__ int tz2r_(const int t) const { return pick<NT>(tz2r, t); }
+};
+// NT = 0: any number of atom types (more than MDP_AEAM_MAXT: the reference sizes everything from the file,
+// pair_aeam.cpp:752-872) -- the parameters of a pair are read from the block in device memory, per neighbour
+template <> struct PairPar<0> {
+  const double *gc, *gr;
+  const int *gn, *gt, *gz;
+  int base, stride;
+  __device__ __forceinline__ double cut_(const int t) const { return gc[base + t * stride]; }
+  __device__ __forceinline__ double rdr_(const int t) const { return gr[base + t * stride]; }
+  __device__ __forceinline__ int nr_(const int t) const { return gn[base + t * stride]; }
+  __device__ __forceinline__ int trho_(const int t) const { return gt[base + t * stride]; }
+  __device__ __forceinline__ int tz2r_(const int t) const { return gz[base + t * stride]; }
+};
+
+template <int NT> __device__ __forceinline__ PairPar<NT> load_pairpar(const AeamDev &A, const int ti, const bool transposed)
+{
+  PairPar<NT> q;
+  if constexpr (NT == 0) {
+    q.gc = A.g_cut;
+    q.gr = A.g_rdr;
+    q.gn = A.g_nr;
+    q.gt = A.g_t2rhor;
+    q.gz = A.g_t2z2r;
+    q.base = transposed ? ti : ti * A.ntypes;
+    q.stride = transposed ? A.ntypes : 1;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int pt = transposed ? t * A.ntypes + ti : ti * A.ntypes + t;
+      q.cut[t] = A.cut[pt];
+      q.rdr[t] = A.rdr[pt];
+      q.nr[t] = A.nr[pt];
+      q.trho[t] = A.t2rhor[pt];
+      q.tz2r[t] = A.t2z2r[pt];
+    }
+  }
+  return q;
 }
 
 // ---- pass 1, metal centres (pair_aeam.cpp:174-205) ---------------------------------------------------
@@ -133,10 +160,10 @@ __global__ __launch_bounds__(256) void aeam_density_kernel(const AeamDev A, cons
         const double dx = xj[u].x - xi.x, dy = xj[u].y - xi.y, dz = xj[u].z - xi.z;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const int tj = (int) xj[u].w;
-        if (r <= pick<NT>(q.cut, tj)) { // CutDec applies only when BOTH are angular (pair_aeam.cpp:187-190)
+        if (r <= q.cut_(tj)) { // CutDec applies only when BOTH are angular (pair_aeam.cpp:187-190)
           double p;
-          const int m = spline_index(r, pick<NT>(q.rdr, tj), pick<NT>(q.nr, tj), p);
-          acc += v4_val(A.rhor_v4[(size_t) pick<NT>(q.trho, tj) * nm1 + m], p);
+          const int m = spline_index(r, q.rdr_(tj), q.nr_(tj), p);
+          acc += v4_val(A.rhor_v4[(size_t) q.trho_(tj) * nm1 + m], p);
         }
       }
     }
@@ -918,13 +945,14 @@ __device__ __forceinline__ int ang_stage(const AeamDev &A, const double4 *__rest
       rsq = dx * dx + dy * dy + dz * dz;
       r = sqrt(rsq);
       const int tj = (int) xj.w;
-      const int pt = ti * A.ntypes + tj;
+      const int pt = ti * A.ntypes + tj; // (per-lane pair type: the parameter block in device memory)
       const double cdec = (tj >= A.nnonangular) ? kCutDec : 0.0; // i is angular here
-      inj1 = r <= A.cut[pt] - cdec;
-      keep = PASS3 ? (r <= A.cut[pt]) : (inj1 != 0); // pass 3's j loop has no CutDec (pair_aeam.cpp:350)
+      const double cut_pt = A.g_cut[pt];
+      inj1 = r <= cut_pt - cdec;
+      keep = PASS3 ? (r <= cut_pt) : (inj1 != 0); // pass 3's j loop has no CutDec (pair_aeam.cpp:350)
       if (keep) {
         double p;
-        const double *c = spline_row(A.rhor, A.t2rhor[pt], A.nrmax + 1, r, A.rdr[pt], A.nr[pt], p);
+        const double *c = spline_row(A.rhor, A.g_t2rhor[pt], A.nrmax + 1, r, A.g_rdr[pt], A.g_nr[pt], p);
         fv = sp_val(c, p);
         dfv = sp_der(c, p);
       }
@@ -1005,13 +1033,14 @@ __global__ __launch_bounds__(256) void aeam_embed_kernel(const AeamDev A, const 
     const bool metal = ti < A.nnonangular;
     const double rh = rho[i];
     const double u = metal ? rh : sqrt(rh); // pow(rho, ni), ni = 1 or 1/2
-    double p = u * A.rdrho[ti] + 1.0;
+    const int nrho_t = A.g_nrho[ti];
+    double p = u * A.g_rdrho[ti] + 1.0;
     int m = (int) p;
-    m = m < A.nrho[ti] - 1 ? m : A.nrho[ti] - 1;
+    m = m < nrho_t - 1 ? m : nrho_t - 1;
     m = m > 1 ? m : 1;
     p -= m;
     p = p < 1.0 ? p : 1.0;
-    const double *c = A.frho + ((size_t) A.t2frho[ti] * (A.nrhomax + 1) + m) * 7;
+    const double *c = A.frho + ((size_t) A.g_t2frho[ti] * (A.nrhomax + 1) + m) * 7;
     const double fprime = sp_der(c, p);
     // Fptmp = ni rho^(ni-1) if rho > minrho else 0 (pair_aeam.cpp:329-332); the product is all
     // pass 3 ever uses (Feam :373, FFij/FFik/FFjk :450-452)
@@ -1083,16 +1112,16 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
         const double dx = xj[u].x - xa.x, dy = xj[u].y - xa.y, dz = xj[u].z - xa.z;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const int tj = (int) xj[u].w;
-        const bool in_a = r <= pick<NT>(qA.cut, tj), in_j = r <= pick<NT>(qJ.cut, tj);
+        const bool in_a = r <= qA.cut_(tj), in_j = r <= qJ.cut_(tj);
         if (!(in_a || in_j)) continue;
         const double recip = 1.0 / r;
         double fpair_a = 0.0, fpair_j = 0.0, dfa_shared = 0.0;
         if (in_a) { // the visit (i=a, j)
           double p;
-          const int m = spline_index(r, pick<NT>(qA.rdr, tj), pick<NT>(qA.nr, tj), p);
-          const double dfij = d4_der(A.rhor_d4[(size_t) pick<NT>(qA.trho, tj) * nm1 + m], p);
+          const int m = spline_index(r, qA.rdr_(tj), qA.nr_(tj), p);
+          const double dfij = d4_der(A.rhor_d4[(size_t) qA.trho_(tj) * nm1 + m], p);
           dfa_shared = dfij;
-          const size_t zrow = (size_t) pick<NT>(qA.tz2r, tj) * nm1 + m; // same row m1 (pair_aeam.cpp:367)
+          const size_t zrow = (size_t) qA.tz2r_(tj) * nm1 + m; // same row m1 (pair_aeam.cpp:367)
           const double phip = d4_der(A.z2r_d4[zrow], p);
           fpair_a = -qa * dfij * recip + 0.5 * (-phip * recip);
           if (EV) e += 0.5 * v4_val(A.z2r_v4[zrow], p); // credited to i only (pair_aeam.cpp:386-390)
@@ -1104,9 +1133,9 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
             fpair_j = fpair_a + (qa - qj) * dfa_shared * recip;
           } else {
             double p;
-            const int m = spline_index(r, pick<NT>(qJ.rdr, tj), pick<NT>(qJ.nr, tj), p);
-            const double dfja = d4_der(A.rhor_d4[(size_t) pick<NT>(qJ.trho, tj) * nm1 + m], p);
-            const double phip = d4_der(A.z2r_d4[(size_t) pick<NT>(qJ.tz2r, tj) * nm1 + m], p);
+            const int m = spline_index(r, qJ.rdr_(tj), qJ.nr_(tj), p);
+            const double dfja = d4_der(A.rhor_d4[(size_t) qJ.trho_(tj) * nm1 + m], p);
+            const double phip = d4_der(A.z2r_d4[(size_t) qJ.tz2r_(tj) * nm1 + m], p);
             fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
           }
         }
@@ -1396,7 +1425,7 @@ static void aeam_class_cuts(const mdp_ctx *c, double out[4])
   for (int k = 0; k < 4; k++) out[k] = 0.0;
   for (int ti = 0; ti < nt; ti++)
     for (int tj = 0; tj < nt; tj++) {
-      const double a = c->aeam.cut[ti * nt + tj], b = c->aeam.cut[tj * nt + ti];
+      const double a = c->aeam_hcut[ti * nt + tj], b = c->aeam_hcut[tj * nt + ti];
       const double m = a > b ? a : b;
       const int k = (ti > 1 ? 1 : ti) * 2 + (tj > 1 ? 1 : tj);
       if (m > out[k]) out[k] = m;
@@ -1419,7 +1448,8 @@ int mdp_aeam_prepare(mdp_ctx *c)
   c->aeam_ang_remote = false;
   c->aeam_phase = 0;
   const char *e = getenv("MDP_AEAM_TILE");
-  if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0)) {
+  // (tile kernels: up to MDP_AEAM_MAXT types -- their parameter block lives in the kernel arguments / in LDS)
+  if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0) && c->aeam.ntypes <= MDP_AEAM_MAXT) {
     double cutsq[4];
     aeam_class_cuts(c, cutsq); // either visit of the pair may need it
     for (int k = 0; k < 4; k++) cutsq[k] = (cutsq[k] + c->cfg.skin) * (cutsq[k] + c->cfg.skin);
@@ -1724,7 +1754,9 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
       case 2: aeam_density_kernel<AE_L, 2><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
       case 3: aeam_density_kernel<AE_L, 3><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
       case 4: aeam_density_kernel<AE_L, 4><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
-      default: aeam_density_kernel<AE_L, MDP_AEAM_MAXT><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      case 5: case 6: case 7: case 8:
+        aeam_density_kernel<AE_L, MDP_AEAM_MAXT><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
+      default: aeam_density_kernel<AE_L, 0><<<grid, 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->rho.p); break;
     }
   }
   mdp_span_end(c, 0);
@@ -1796,7 +1828,8 @@ int mdp_aeam_run_force(mdp_ctx *c, int eflag, int vflag)
       case 2: if (ev) MDP_AF(2, true); else MDP_AF(2, false); break;
       case 3: if (ev) MDP_AF(3, true); else MDP_AF(3, false); break;
       case 4: if (ev) MDP_AF(4, true); else MDP_AF(4, false); break;
-      default: if (ev) MDP_AF(MDP_AEAM_MAXT, true); else MDP_AF(MDP_AEAM_MAXT, false); break;
+      case 5: case 6: case 7: case 8: if (ev) MDP_AF(MDP_AEAM_MAXT, true); else MDP_AF(MDP_AEAM_MAXT, false); break;
+      default: if (ev) MDP_AF(0, true); else MDP_AF(0, false); break; // more than MDP_AEAM_MAXT types
     }
 #undef MDP_AF
   }
@@ -1816,9 +1849,10 @@ extern "C" {
 int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
 {
   if (!c || !t) return MDP_EINVAL;
-  if (t->ntypes < 1 || t->ntypes > MDP_AEAM_MAXT || t->nelements < 1 || t->nelements > MDP_AEAM_MAXT ||
+  if (t->ntypes < 1 || t->ntypes > MDP_AEAM_MAXTYPES || t->nelements < 1 || t->nelements > MDP_AEAM_MAXTYPES ||
       t->ntypes > t->nelements)
-    return mdp_fail(c, MDP_EINVAL, "aeam: 1..%d atom types/elements supported, ntypes <= nelements", MDP_AEAM_MAXT);
+    return mdp_fail(c, MDP_EINVAL, "aeam: 1..%d atom types/elements, ntypes <= nelements (the rho(r) tables are numbered by "
+                                   "type pair inside an array sized by element pairs, pair_aeam.cpp:816-821)", MDP_AEAM_MAXTYPES);
   MDP_HIP(c, hipSetDevice(c->device));
   AeamDev &A = c->aeam;
   memset(&A, 0, sizeof A);
@@ -1827,21 +1861,50 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
   A.nnonangular = t->nnonangular;
   A.nrhomax = t->nrhomax;
   A.nrmax = t->nrmax;
-  const int nt = t->ntypes, ne = t->nelements;
+  const int nt = t->ntypes, ne = t->nelements, np = nt * nt;
+  const bool small = nt <= MDP_AEAM_MAXT; // the parameter block also rides in the kernel arguments
+  std::vector<double> pd((size_t) 2 * np + nt);       // cut | rdr | rdrho
+  std::vector<int> pi((size_t) 3 * np + 2 * nt);      // nr | t2rhor | t2z2r | nrho | t2frho
   for (int a = 0; a < nt; a++) {
     // element of type a+1 is a (coeff() insists on file order, pair_aeam.cpp:568-572)
-    A.rdrho[a] = 1 / t->drho[a];
-    A.nrho[a] = t->nrho[a];
-    A.t2frho[a] = t->type2frho[a + 1];
+    pd[(size_t) 2 * np + a] = 1 / t->drho[a];
+    pi[(size_t) 3 * np + a] = t->nrho[a];
+    pi[(size_t) 3 * np + nt + a] = t->type2frho[a + 1];
+    if (small) {
+      A.rdrho[a] = 1 / t->drho[a];
+      A.nrho[a] = t->nrho[a];
+      A.t2frho[a] = t->type2frho[a + 1];
+    }
     for (int b = 0; b < nt; b++) {
       const int k = a * nt + b;
-      A.cut[k] = t->cut[a * ne + b];
-      A.rdr[k] = 1 / t->dr[a * ne + b];
-      A.nr[k] = t->nr[a * ne + b];
-      A.t2rhor[k] = t->type2rhor[(size_t) (a + 1) * (nt + 1) + (b + 1)];
-      A.t2z2r[k] = t->type2z2r[(size_t) (a + 1) * (nt + 1) + (b + 1)];
+      pd[k] = t->cut[a * ne + b];
+      pd[(size_t) np + k] = 1 / t->dr[a * ne + b];
+      pi[k] = t->nr[a * ne + b];
+      pi[(size_t) np + k] = t->type2rhor[(size_t) (a + 1) * (nt + 1) + (b + 1)];
+      pi[(size_t) 2 * np + k] = t->type2z2r[(size_t) (a + 1) * (nt + 1) + (b + 1)];
+      if (small) {
+        A.cut[k] = pd[k];
+        A.rdr[k] = pd[(size_t) np + k];
+        A.nr[k] = pi[k];
+        A.t2rhor[k] = pi[(size_t) np + k];
+        A.t2z2r[k] = pi[(size_t) 2 * np + k];
+      }
     }
   }
+  c->aeam_hcut.assign(pd.begin(), pd.begin() + np);
+  MDP_HIP(c, c->aeam_par_d.reserve(pd.size() + 1));
+  MDP_HIP(c, c->aeam_par_i.reserve(pi.size() + 1));
+  MDP_HIP(c, hipMemcpyAsync(c->aeam_par_d.p, pd.data(), pd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipMemcpyAsync(c->aeam_par_i.p, pi.data(), pi.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipStreamSynchronize(c->stream)); // (pd / pi go out of scope)
+  A.g_cut = c->aeam_par_d.p;
+  A.g_rdr = c->aeam_par_d.p + np;
+  A.g_rdrho = c->aeam_par_d.p + 2 * (size_t) np;
+  A.g_nr = c->aeam_par_i.p;
+  A.g_t2rhor = c->aeam_par_i.p + np;
+  A.g_t2z2r = c->aeam_par_i.p + 2 * (size_t) np;
+  A.g_nrho = c->aeam_par_i.p + 3 * (size_t) np;
+  A.g_t2frho = c->aeam_par_i.p + 3 * (size_t) np + nt;
   const size_t nf = (size_t) t->nfrho * (t->nrhomax + 1) * 7, nr = (size_t) t->nrhor * (t->nrmax + 1) * 7,
                nz = (size_t) t->nz2r * (t->nrmax + 1) * 7;
   MDP_HIP(c, c->aeam_frho.reserve(nf));
@@ -1879,16 +1942,8 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     // per pair type: {rho' coefficients | phi' coefficients} in one 64-byte record (tile force kernel)
     const int npair = A.ntypes * A.ntypes, nm1 = A.nrmax + 1;
     MDP_HIP(c, c->aeam_pair_d8.reserve((size_t) npair * nm1 * 6 + 8));
-    constexpr int kPairs = MDP_AEAM_MAXT * MDP_AEAM_MAXT;
-    MDP_HIP(c, c->aeam_maps.reserve(2 * kPairs));
-    int h_map[2 * kPairs];
-    for (int k = 0; k < kPairs; k++) {
-      h_map[k] = A.t2rhor[k];
-      h_map[kPairs + k] = A.t2z2r[k];
-    }
-    MDP_TRY(mdp_write_small(c, c->aeam_maps.p, h_map, sizeof(h_map)));
     pair_der_kernel<<<(int) (((size_t) npair * nm1 + 255) / 256), 256, 0, c->stream>>>(
-        npair, nm1, c->aeam_maps.p, c->aeam_maps.p + kPairs, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
+        npair, nm1, A.g_t2rhor, A.g_t2z2r, c->aeam_rhor.p, c->aeam_z2r.p, c->aeam_pair_d8.p);
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipStreamSynchronize(c->stream));
     A.pair_d6 = reinterpret_cast<const double2 *>(c->aeam_pair_d8.p);

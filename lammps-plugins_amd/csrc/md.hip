@@ -18,6 +18,7 @@ namespace {
 struct CutTables {
   double owned[MDP_AEAM_MAXT * MDP_AEAM_MAXT]; // cutneighsq[ei*ne+ej]  element/type pair
   double ghost[MDP_AEAM_MAXT * MDP_AEAM_MAXT]; // 0 => no ghost lists
+  const double *g_owned;                       // the owned table in device memory when ne > MDP_AEAM_MAXT (else null)
   int ne;           // table stride
   int min_type;     // owned atoms of a lower type get an empty row (AEAM with tile lists: only angular centres read the CSR list)
 };
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void nbuild_kernel(const Grid g, const CutTabl
   const int i = perm[t];
   const double4 xi = xq[i];
   const int ti = (int) xi.w;
-  const double *tab = (i < nlocal) ? ct.owned : ct.ghost;
+  const double *tab = (i < nlocal) ? (ct.g_owned ? ct.g_owned : ct.owned) : ct.ghost;
   if ((i >= nlocal && ct.ghost[0] <= 0.0) || (i < nlocal && ti < ct.min_type)) {
     if (!FILL) cnt[i] = 0;
     return;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void host_list_count_kernel(const Grid g, cons
             const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
             const double rsq = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
             const int tj = xj.w >= 0.0 ? (int) xj.w : 0;
-            n += (rsq <= ct.owned[(int) xi.w * ct.ne + tj] && j != i && xj.w >= 0.0) ? 1u : 0u;
+            n += (rsq <= (ct.g_owned ? ct.g_owned : ct.owned)[(int) xi.w * ct.ne + tj] && j != i && xj.w >= 0.0) ? 1u : 0u;
           }
         }
     }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void nbuild_list_kernel(const Grid g, const Cu
           const double4 xj = xq[j];
           const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
           const double rsq = dx * dx + dy * dy + dz * dz;
-          hit = rsq <= ct.owned[ti * ct.ne + (int) xj.w] && j != i;
+          hit = rsq <= (ct.g_owned ? ct.g_owned : ct.owned)[ti * ct.ne + (int) xj.w] && j != i;
         }
         const unsigned long long bal = __ballot(hit);
         if (FILL && hit) row[n + __popcll(bal & ((1ull << lane) - 1ull))] = j;
@@ -453,6 +454,31 @@ inline int nblk(long long n) { return (int) ((n + 255) / 256); }
 } // namespace
 
 // ---- neighbor-list cutoffs the style's init_one() would hand the host ----------------------------
+// aeam: squared list cutoffs (cut[ti][tj] + skin)^2 per type pair (pair_aeam.cpp:618-620), in the kernel arguments up
+// to MDP_AEAM_MAXT types, in device memory beyond
+static int aeam_cut_table(mdp_ctx *c, CutTables &ct, const double skin, double &maxcut)
+{
+  const int nt = c->aeam.ntypes;
+  ct.ne = nt;
+  ct.g_owned = nullptr;
+  std::vector<double> h((size_t) nt * nt);
+  for (int a = 0; a < nt; a++)
+    for (int b = 0; b < nt; b++) {
+      const double cc = c->aeam_hcut[a * nt + b] + skin;
+      h[(size_t) a * nt + b] = cc * cc;
+      if (cc > maxcut) maxcut = cc;
+    }
+  if (nt <= MDP_AEAM_MAXT) {
+    for (int k = 0; k < nt * nt; k++) ct.owned[k] = h[k];
+    return MDP_OK;
+  }
+  MDP_HIP(c, c->cut_tab.reserve(h.size() + 1));
+  MDP_HIP(c, hipMemcpyAsync(c->cut_tab.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  MDP_HIP(c, hipStreamSynchronize(c->stream));
+  ct.g_owned = c->cut_tab.p;
+  return MDP_OK;
+}
+
 static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
 {
   memset(&ct, 0, sizeof ct);
@@ -478,15 +504,10 @@ static int md_cut_tables(mdp_ctx *c, CutTables &ct, double &maxcut)
     // rows are built -- a quarter of the reneighboring time at 1 M atoms.  A per-atom-virial step (CSR kernels)
     // asks for the full list (c->csr_want_full) and gets it rebuilt on the spot.
     const char *e = getenv("MDP_AEAM_TILE");
-    const bool tiles = (c->md || c->aeam_device_lists) && !(e && atoi(e) == 0);
+    const bool tiles = (c->md || c->aeam_device_lists) && !(e && atoi(e) == 0) && nt <= MDP_AEAM_MAXT;
     ct.min_type = (tiles && !c->csr_want_full && !c->cfg.master_list) ? c->aeam.nnonangular : 0;
     c->csr_full = ct.min_type == 0;
-    for (int a = 0; a < nt; a++)
-      for (int b = 0; b < nt; b++) {
-        const double cc = c->aeam.cut[a * nt + b] + skin;         // pair_aeam.cpp:618-620 (+ skin)
-        ct.owned[a * nt + b] = cc * cc;
-        if (cc > maxcut) maxcut = cc;
-      }
+    MDP_TRY(aeam_cut_table(c, ct, skin, maxcut));
   } else
     return mdp_fail(c, MDP_EINVAL, "unknown style %d", c->cfg.style);
   return MDP_OK;
@@ -1100,15 +1121,8 @@ int mdp_aeam_check_host_list(mdp_ctx *c, int inum, const int *ilist, const int *
   }
   CutTables ct;
   memset(&ct, 0, sizeof ct);
-  const int nt = c->aeam.ntypes;
-  ct.ne = nt;
   double maxcut = 0.0;
-  for (int a = 0; a < nt; a++)
-    for (int b = 0; b < nt; b++) {
-      const double cc = c->aeam.cut[a * nt + b] + skin;
-      ct.owned[a * nt + b] = cc * cc;
-      maxcut = cc > maxcut ? cc : maxcut;
-    }
+  MDP_TRY(aeam_cut_table(c, ct, skin, maxcut));
   return host_list_compare(c, ct, maxcut, host_total, "aeam");
 }
 

@@ -678,6 +678,9 @@ int mdp_destroy(mdp_ctx *c)
   c->aeam_rhor_ys.release();
   c->aeam_z2r_ys.release();
   c->aeam_maps.release();
+  c->aeam_par_d.release();
+  c->aeam_par_i.release();
+  c->cut_tab.release();
   c->xq.release();
   c->xraw.release();
   c->tag.release();

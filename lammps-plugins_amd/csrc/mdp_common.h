@@ -117,16 +117,23 @@ struct MdpGrid {
   int range; // stencil half width in cells: range * cell width >= the cutoff the grid was made for
 };
 
-// atom types / elements an AEAM potential file may define here (the reference sizes everything from the file,
-// pair_aeam.cpp:752-872; the bundled AlSi.aeam has two)
+// The reference sizes everything from the potential file (pair_aeam.cpp:752-872; the bundled AlSi.aeam has two
+// elements), and so does this library.  Up to MDP_AEAM_MAXT atom types the parameters of the type pairs also ride in
+// the kernel arguments (1.8 KB of the 4 KB a launch may carry), where the tile kernels and the templated CSR kernels read
+// them as scalars at fixed offsets; with more types only the block in device memory (g_*) exists and the generic CSR
+// kernels (PairPar<0>) serve every step.
 #define MDP_AEAM_MAXT 8
+#define MDP_AEAM_MAXTYPES 64 // (a sanity bound on what a file may declare, not a table size)
 struct AeamDev {
   int ntypes, nelements, nnonangular, nrhomax, nrmax;
-  // per type pair [(ti-1)*ntypes + (tj-1)], ntypes <= MDP_AEAM_MAXT
+  // per type pair [(ti-1)*ntypes + (tj-1)], filled when ntypes <= MDP_AEAM_MAXT
   double cut[MDP_AEAM_MAXT * MDP_AEAM_MAXT], rdr[MDP_AEAM_MAXT * MDP_AEAM_MAXT];
   int nr[MDP_AEAM_MAXT * MDP_AEAM_MAXT], t2rhor[MDP_AEAM_MAXT * MDP_AEAM_MAXT], t2z2r[MDP_AEAM_MAXT * MDP_AEAM_MAXT];
   double rdrho[MDP_AEAM_MAXT];
   int nrho[MDP_AEAM_MAXT], t2frho[MDP_AEAM_MAXT];
+  // the same in device memory for any number of types: [ntypes*ntypes] / [ntypes]
+  const double *g_cut, *g_rdr, *g_rdrho;
+  const int *g_nr, *g_t2rhor, *g_t2z2r, *g_nrho, *g_t2frho;
   const double *frho, *rhor, *z2r; // device spline tables [table][row][7]
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
   const double2 *rhor_ys, *z2r_ys; // [table][nrmax+1] (value, slope) = columns 6 and 5 of a row: the persistent tile kernels' tables
@@ -223,6 +230,10 @@ struct mdp_ctx {
   int lds_max = 0, num_cu = 0; // device limits (queried once)
   bool ptile_reported[3] = {false, false, false};
   DevBuf<int> aeam_maps;
+  DevBuf<double> aeam_par_d; // cut | rdr | rdrho of the type pairs / types (AeamDev::g_*)
+  DevBuf<int> aeam_par_i;    // nr | t2rhor | t2z2r | nrho | t2frho
+  std::vector<double> aeam_hcut; // host copy of cut[ti*ntypes+tj] (list cutoffs, launch geometry)
+  DevBuf<double> cut_tab;    // squared list cutoffs per type pair for more than MDP_AEAM_MAXT types (md.hip CutTables)
 
   // ---- atoms
   int nlocal = 0, nghost = 0, nall = 0, ntypes = 0;

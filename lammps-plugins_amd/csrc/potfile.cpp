@@ -179,7 +179,7 @@ int mdp_aeam_file_read(const char *path, mdp_aeam_file **out, char *err, int err
     F->nelements = (int) v[0];
     F->nnonangular = (int) v[1];
     F->nangular = (int) v[2];
-    if (F->nelements < 1 || F->nelements > 8) return fail("unsupported number of elements (1..8)");
+    if (F->nelements < 1 || F->nelements > 64) return fail("unsupported number of elements (1..64)");
     for (int i = 0; i < F->nelements; i++) {
       while (*s == ' ' || *s == '\t') ++s;
       const size_t len = strcspn(s, " \t\r\n");
@@ -240,15 +240,15 @@ int mdp_aeam_file_read(const char *path, mdp_aeam_file **out, char *err, int err
   return MDP_OK;
 }
 
-int mdp_aeam_file_info(const mdp_aeam_file *F, int *nelements, int *nnonangular, int *nangular, double *mass4,
-                       char *names, int nameslen)
+int mdp_aeam_file_info(const mdp_aeam_file *F, int *nelements, int *nnonangular, int *nangular, double *mass,
+                       int mass_cap, char *names, int nameslen)
 {
   if (!F) return MDP_EINVAL;
   if (nelements) *nelements = F->nelements;
   if (nnonangular) *nnonangular = F->nnonangular;
   if (nangular) *nangular = F->nangular;
-  if (mass4)
-    for (int i = 0; i < F->nelements; i++) mass4[i] = F->mass[i];
+  if (mass)
+    for (int i = 0; i < F->nelements && i < mass_cap; i++) mass[i] = F->mass[i];
   if (names && nameslen > 0) {
     std::string s;
     for (int i = 0; i < F->nelements; i++) s += (i ? " " : "") + F->elements[i];
@@ -296,7 +296,7 @@ static void spline_rows(int n, double h, const double *y, double *rows)
 // file2array + array2spline for `ntypes` atom types, map[1..ntypes] = element index or -1 (NULL)
 int mdp_aeam_file_build(mdp_aeam_file *F, int ntypes, const int *map, mdp_aeam_tables *out)
 {
-  if (!F || !map || !out || ntypes < 1 || ntypes > 8) return MDP_EINVAL;
+  if (!F || !map || !out || ntypes < 1 || ntypes > 64) return MDP_EINVAL;
   const int ne = F->nelements;
   const size_t fs = (size_t) F->nrhomax + 1, rs = (size_t) F->nrmax + 1;
   F->ntypes = ntypes;

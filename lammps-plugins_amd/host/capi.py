@@ -124,9 +124,10 @@ class AeamFile:
         if rc:
             raise MdpError(rc, err.value.decode())
         ne, nn, na = C.c_int(), C.c_int(), C.c_int()
-        mass = (C.c_double * 8)()
-        names = C.create_string_buffer(128)
-        lib().mdp_aeam_file_info(self.h, C.byref(ne), C.byref(nn), C.byref(na), mass, names, C.c_int(128))
+        mass = (C.c_double * 64)()
+        names = C.create_string_buffer(64 * 16 + 16)
+        lib().mdp_aeam_file_info(self.h, C.byref(ne), C.byref(nn), C.byref(na), mass, C.c_int(64), names,
+                                 C.c_int(64 * 16 + 16))
         self.nelements, self.nnonangular, self.nangular = ne.value, nn.value, na.value
         self.mass = list(mass)[:ne.value]
         self.elements = names.value.decode().split()

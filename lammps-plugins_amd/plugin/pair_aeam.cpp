@@ -120,13 +120,13 @@ void PairAEAM::coeff(int narg, char **arg)
   const std::string path = utils::get_potential_file_path(arg[2]);
   if (mdp_aeam_file_read(path.empty() ? arg[2] : path.c_str(), &potfile, why, (int) sizeof why) != MDP_OK)
     error->one(FLERR, why[0] ? why : "Cannot open AEAM potential file");
-  char names[160] = "";
+  char names[MAXEL * 16 + 16] = "";
   int nnon = 0, nang = 0;
-  mdp_aeam_file_info(potfile, &nelements, &nnon, &nang, element_mass, names, (int) sizeof names);
+  mdp_aeam_file_info(potfile, &nelements, &nnon, &nang, element_mass, MAXEL, names, (int) sizeof names);
   {
     int k = 0;
     char *save = nullptr;
-    for (char *tok = strtok_r(names, " ", &save); tok && k < 8; tok = strtok_r(nullptr, " ", &save), k++) {
+    for (char *tok = strtok_r(names, " ", &save); tok && k < MAXEL; tok = strtok_r(nullptr, " ", &save), k++) {
       strncpy(elements[k], tok, 15);
       elements[k][15] = 0;
     }

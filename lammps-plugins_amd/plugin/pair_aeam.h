@@ -46,8 +46,9 @@ class PairAEAM : public Pair {
   mdp_aeam_tables tables;
   bool tables_built;
   int nelements;
-  char elements[8][16]; // (the device library takes up to 8 elements per potential file)
-  double element_mass[8];
+  static constexpr int MAXEL = 64; // (a bound on what a file may declare; everything else is sized from the file)
+  char elements[MAXEL][16];
+  double element_mass[MAXEL];
   double *cut_el;             // [nelements*nelements], points into potfile
   int nall_uploaded;
   bool device_lists;          // lists built on the device from the positions; the host's list is checked, not read

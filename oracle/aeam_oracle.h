@@ -6,7 +6,7 @@
 extern "C" {
 #endif
 
-#define AEAM_ORACLE_MAXEL 8
+#define AEAM_ORACLE_MAXEL 16
 
 /* mirrors PairAEAM::Setfl (pair_aeam.h:66-76) + the spline arrays (pair_aeam.h:55-62).
  * Spline tables are dense [table][row 0..nmax][7]; row 0 is unused (1-based rows). */

@@ -104,7 +104,7 @@ int main(int argc, char **argv)
     int ne = 0, nn_ = 0, na = 0;
     double mass[8];
     char names[128];
-    mdp_aeam_file_info(F, &ne, &nn_, &na, mass, names, sizeof names);
+    mdp_aeam_file_info(F, &ne, &nn_, &na, mass, 8, names, sizeof names);
     CHECK(ne == T.nelements && nn_ == T.nnonangular && na == T.nangular, "element counts differ");
     const int map[3] = {0, 0, 1};
     mdp_aeam_tables tab;

@@ -32,7 +32,7 @@ def product_rebomos_params(P: "RebomosParams"):
     return out
 
 
-MAXEL = 8
+MAXEL = 16
 
 
 class AeamPot(C.Structure):

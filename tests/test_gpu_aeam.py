@@ -236,21 +236,24 @@ def test_tile_kernel_variants_match_oracle(oracle, T, pot, env, monkeypatch):
     ctx.close()
 
 
-def test_host_mode_with_device_lists_five_types(oracle, tmp_path):
-    """the same drop-in path with five atom types (three metals, two angular): tile lists with per-entry types in
-    host mode, everything against the oracle on the five-element file"""
-    path = str(tmp_path / "five.aeam")
-    _five_element_file(path)
+@pytest.mark.parametrize("nmetal,nang", [(3, 2), (7, 5)])
+def test_host_mode_with_device_lists_more_types(oracle, tmp_path, nmetal, nang):
+    """the same drop-in path with five atom types (three metals, two angular: tile lists with per-entry types in
+    host mode) and with twelve (beyond the kernel-argument parameter block: generic kernels over device-built CSR
+    lists), everything against the oracle on the same file"""
+    path = str(tmp_path / "n.aeam")
+    nt = nmetal + nang
+    aeam_five.write_relabelled_file(path, POT_AEAM, [0] * nmetal + [1] * nang, ["E%d" % k for k in range(nt)])
     af5 = capi.AeamFile(path)
     T5 = oracle.aeam_pot(path)
     s2 = S.jitter(S.fcc_cell(4.045, 5, frac_type2=0.08, seed=99), 0.075, seed=100)
     rng = np.random.default_rng(7)
-    t5 = np.where(s2.type == 1, rng.integers(1, 4, s2.n), rng.integers(4, 6, s2.n)).astype(np.int32)
+    t5 = np.where(s2.type == 1, rng.integers(1, nmetal + 1, s2.n), rng.integers(nmetal + 1, nt + 1, s2.n)).astype(np.int32)
     s5 = S.System(s2.box, s2.x.copy(), t5, s2.tag.copy(), np.array([0.0] + list(af5.mass)))
     eng = mdref.AeamCPU(oracle, T5, s5)
     ctx = capi.Context(0)
     ctx.aeam_set_tables(af5.build())
-    g = _host_mode_device_lists(ctx, eng, s5.x, ntypes=5)
+    g = _host_mode_device_lists(ctx, eng, s5.x, ntypes=nt)
     o = eng.compute(s5.x)
     assert np.abs(g["rho"] - o["rho"][:s5.n]).max() < 1e-11
     assert np.abs(g["f"] - o["f_owned"]).max() < 1e-9
@@ -355,11 +358,13 @@ def test_five_atom_types_hot_run_equals_the_two_type_run(tmp_path):
 
 @pytest.mark.parametrize("cls,names,cluster", [([0], ["Al"], "2"), ([0, 1, 1], ["Al", "Sia", "Sib"], "2"),
                                                ([0, 0, 1], ["Ala", "Alb", "Si"], "1"),
-                                               ([0, 0, 0, 0, 1, 1, 1, 1], list("ABCDEFGH"), "2")])
-def test_other_type_counts_through_the_tile_kernels(oracle, tmp_path, cls, names, cluster, monkeypatch):
+                                               ([0, 0, 0, 0, 1, 1, 1, 1], list("ABCDEFGH"), "2"),
+                                               ([0] * 7 + [1] * 5, ["M%d" % k for k in range(7)] + ["X%d" % k for k in range(5)], "2")])
+def test_other_type_counts(oracle, tmp_path, cls, names, cluster, monkeypatch):
     """one element (pure metal: the second list segment is empty), three (one metal: the per-entry types are all
-    angular) and eight (the maximum): tile kernels on a force-only and a tallying compute against the oracle on the
-    same file"""
+    angular), eight (the most whose parameters ride in the kernel arguments: tile kernels) and twelve (beyond: the
+    reference sizes everything from the file, pair_aeam.cpp:752-872 -- generic kernels that read the parameters of a
+    pair from device memory): a force-only and a tallying compute against the oracle on the same file"""
     monkeypatch.setenv("MDP_AEAM_CLUSTER", cluster)          # (1: one atom per 16-lane group, the other tile layout)
     path = str(tmp_path / "n.aeam")
     aeam_five.write_relabelled_file(path, POT_AEAM, cls, names)

@@ -320,6 +320,37 @@ def test_aeam_bricks_with_five_atom_types(oracle, tmp_path):
         assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
 
 
+def test_aeam_twelve_atom_types_hot_on_two_bricks(oracle, tmp_path):
+    """more atom types than the kernel-argument parameter block holds (12 > 8): the generic kernels on one and on two
+    bricks (types of remote ghosts arrive with the border exchange), 24 hot steps with migrations; forces against the
+    oracle, trajectory against the one-brick run"""
+    import aeam_five
+    path = str(tmp_path / "twelve.aeam")
+    cls = [0] * 7 + [1] * 5
+    aeam_five.write_relabelled_file(path, POT_AEAM, cls, ["M%d" % k for k in range(7)] + ["X%d" % k for k in range(5)])
+    af = capi.AeamFile(path)
+    assert af.nelements == 12 and af.nnonangular == 7
+    T = oracle.aeam_pot(path)
+    s2 = S.jitter(S.fcc_cell(4.045, 8, frac_type2=0.06, seed=3), 0.05, seed=4)
+    rng = np.random.default_rng(12)
+    tn = np.where(s2.type == 1, rng.integers(1, 8, s2.n), rng.integers(8, 13, s2.n)).astype(np.int32)
+    assert len(set(tn.tolist())) == 12
+    s = S.System(s2.box, s2.x.copy(), tn, s2.tag.copy(), np.array([0.0] + list(af.mass)))
+    v0 = S.gaussian_velocities(s, 600.0, seed=2) + np.array([40.0, 25.0, -30.0])
+    xw = S.wrap(s.box, s.x)
+    o = mdref.AeamCPU(oracle, T, S.System(s.box, xw, s.type, s.tag, s.mass)).compute(xw)
+    one = _run(1, s, v0, 24, 3, style=capi.STYLE_AEAM, pot=path)
+    st = _run(2, s, v0, 0, 0, style=capi.STYLE_AEAM, pot=path)
+    assert np.abs(st["f"] - o["f_owned"]).max() < 1e-9
+    assert st["th0"]["pe"] == pytest.approx(o["eng"], rel=1e-11)
+    many = _run(2, s, v0, 24, 3, style=capi.STYLE_AEAM, pot=path, defer=True)
+    assert many["left"] > 5
+    dx = many["x"] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+
+
 def test_deferred_displacement_trigger_fires_once_per_need():
     """mdp_md_moved_async: silent while atoms stay inside skin/2 - margin, fires one call after they leave it,
     and is reset by the reneighboring it asks for"""
