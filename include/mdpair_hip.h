@@ -264,7 +264,8 @@ int mdp_md_download_x_all(mdp_ctx *ctx, double *x_all); /* owned atoms then ghos
 void *mdp_md_ptr(mdp_ctx *ctx, const char *name);
 /* statistics of the last neighbor build: out[0]=total master entries (owned; 0 if not built),
  * [1]=ghost-list entries, [2]=LJ row entries incl. padding (rebomos), [3]=REBO candidate entries, [4]=#centres,
- * [5]=#centres in 4-lane groups, [6]=#centres in 12- and 16-lane groups, [7]=style-list builds so far (rebomos) /
+ * [5]=#centres with at most three neighbours (one lane each), [6]=#centres in 12- and 16-lane groups, [7]=style-list
+ * builds so far (rebomos) /
  * #angular atoms (aeam) */
 int mdp_md_neighbor_stats(mdp_ctx *ctx, long long out[8]);
 /* dynamic pruning of the tile rows in resident runs (between list builds the rows are re-filtered from the current

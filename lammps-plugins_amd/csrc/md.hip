@@ -218,7 +218,8 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
       const int f0 = SC.flags[0];
       if (f0) SC.flags[4] |= f0;
       SC.flags[0] = 0;
-      if (SC.ovf) SC.ovf[0] = 0;
+      if (SC.ovf)
+        for (int k = 0; k < 5; k++) SC.ovf[(size_t) k * SC.ovf_stride] = 0;
     } else if (i < 4)
       SC.flags[i] = 0;
   }
@@ -751,6 +752,7 @@ void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc)
     sc.nacc = MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS);
     sc.flags = c->flags.p;
     sc.ovf = c->ovf.p;
+    sc.ovf_stride = c->ovf_stride;
   }
   c->sflag_chk = sc;
   c->sflag_armed = sc.flag != nullptr;

@@ -197,7 +197,8 @@ __global__ void permute_kernel(int n, int w, const int *__restrict__ perm, const
 // flags[0] (overflow bits of the compute just finished) is folded into the STICKY word flags[4] first: force-only
 // steps of a resident run never read the flags, and a truncated neighbour set must still stop the run at the next
 // host read (mdp_flags_check), as "Neighbor list overflow" stops the reference (pair_rebomos.cpp:350).
-__global__ void acc_zero_kernel(double *__restrict__ acc, const int n, int *__restrict__ flags, int *__restrict__ ovf)
+__global__ void acc_zero_kernel(double *__restrict__ acc, const int n, int *__restrict__ flags, int *__restrict__ ovf,
+                                const int ovf_stride)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) acc[i] = 0.0;
@@ -205,7 +206,8 @@ __global__ void acc_zero_kernel(double *__restrict__ acc, const int n, int *__re
     const int f0 = flags[0];
     if (f0) flags[4] |= f0;
     flags[0] = 0;
-    if (ovf) ovf[0] = 0;
+    if (ovf)
+      for (int k = 0; k < 5; k++) ovf[(size_t) k * ovf_stride] = 0;
   } else if (i < 4)
     flags[i] = 0;
 }
@@ -255,7 +257,7 @@ int mdp_acc_begin(mdp_ctx *c, bool any)
     return MDP_OK;
   }
   const int n = any ? MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS) : MDP_ACC_STRIDE;
-  acc_zero_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->acc.p, n, c->flags.p, c->ovf.p);
+  acc_zero_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->acc.p, n, c->flags.p, c->ovf.p, c->ovf_stride);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -657,6 +659,7 @@ int mdp_create(mdp_ctx **out, int device)
     return MDP_ENOMEM;
   }
   memset(c->map, 0, sizeof c->map);
+  memset(c->h_pinned, 0, 64 * sizeof(double));
   *out = c;
   return MDP_OK;
 }

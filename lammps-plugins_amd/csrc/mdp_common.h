@@ -99,6 +99,7 @@ struct MdpStyleCheck {
   double *acc = nullptr;
   int nacc = 0;
   int *flags = nullptr, *ovf = nullptr;
+  int ovf_stride = 0; // the five overflow counters sit at ovf[k * ovf_stride]
 };
 struct MdpStyleCheckMeta {
   bool has_style = false, has_prune = false;
@@ -318,7 +319,8 @@ struct mdp_ctx {
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)
   DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride
-  DevBuf<int> ovf;                // [1+nall] centres handed to the general kernel this step
+  DevBuf<int> ovf;                // 5 x [1+nall+1]: centres handed on this step -- to the general kernel / by the lane-per-centre kernel
+  int ovf_stride = 0;
   DevBuf<mdp_hold_t> xhold_all;   // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
   double skin_inner_auto = 1.0;   // adaptive default of it (grows when the displacement trigger fires too often)

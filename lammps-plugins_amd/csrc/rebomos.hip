@@ -356,9 +356,13 @@ template <int G> struct CentreCfg {
 // ---- fast centre kernel: G lanes per centre, at most G neighbours (slot m = lane) --------------------
 // A centre whose coordination has outgrown its lane group since the last list build is handed to
 // rebo_centre_general_kernel through the overflow list.
-template <int G>
+// LIST: the centres come from a list filled on the device earlier in the same step (the lane-per-centre kernel's
+// centres that found a fourth neighbour: centres[-1] holds their number), the candidates from the rows themselves.
+// The host sizes the grid from the count it saw a step ago (h_count, a pinned word block 0 refreshes); entries beyond
+// what this grid covers are passed on to the general kernel's list, so no count is ever trusted.
+template <int G, bool LIST = false>
 __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
-    const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
+    const RebomosDev P, const int *__restrict__ centres, const int ncent_arg, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
     double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf, const int eflag, const int vflag,
@@ -377,7 +381,15 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
   const bool lane_ok = gw < C::GPW;
   const int grp_in_block = (tid >> 6) * C::GPW + (lane_ok ? gw : C::GPW - 1);
   const long long gid = (long long) blockIdx.x * (C::WPB * C::GPW) + grp_in_block;
+  const int ncent = LIST ? centres[-1] : ncent_arg;
   const bool have = lane_ok && gid < ncent;
+  if (LIST) {
+    int *h_count = reinterpret_cast<int *>(const_cast<int *>(pk)); // (LIST: `pk` carries the pinned host word instead)
+    if (blockIdx.x == 0 && tid == 0) *h_count = ncent;
+    const long long covered = (long long) gridDim.x * (C::WPB * C::GPW);
+    for (long long e = covered + (long long) blockIdx.x * blockDim.x + tid; e < ncent; e += (long long) gridDim.x * blockDim.x)
+      ovf[1 + atomicAdd(&ovf[0], 1)] = centres[e]; // beyond this grid: the general kernel's list
+  }
 
   double *rec = s_rec + (size_t) grp_in_block * C::STRIDE;
   double *mat = s_mat + (size_t) grp_in_block * C::MSTRIDE;
@@ -388,8 +400,10 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
   // kernel is two dependent loads deep (id | candidates -> coordinates) instead of four.
   constexpr int W = C::UA * G;
   int jp[C::UA];
+  if (!LIST) {
 #pragma unroll
-  for (int u = 0; u < C::UA; u++) jp[u] = have ? pk[(size_t) gid * W + u * G + s] : -1;
+    for (int u = 0; u < C::UA; u++) jp[u] = have ? pk[(size_t) gid * W + u * G + s] : -1;
+  }
   int c = 0, off = 0, nc = 0;
   double4 xc = make_double4(0, 0, 0, 0);
   if (have) {
@@ -397,6 +411,10 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
     off = cand_off[c];
     nc = cand_off[c + 1] - off;
     xc = xq[c];
+  }
+  if (LIST) {
+#pragma unroll
+    for (int u = 0; u < C::UA; u++) jp[u] = (have && u * G + s < nc) ? cand[off + u * G + s] : -1;
   }
 
   // ---- phase A: filter the candidates to the current REBO set (pair_rebomos.cpp:328-344);
@@ -563,6 +581,192 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
   const double ox = group_sum_any<G>(act ? fx : 0.0, s, lane), oy = group_sum_any<G>(act ? fy : 0.0, s, lane), oz = group_sum_any<G>(act ? fz : 0.0, s, lane);
   const double oe = (eflag & MDP_EFLAG_ATOM) ? group_sum_any<G>(eh, s, lane) : 0.0;
   if (owned && s == 0 && !outgrown) reinterpret_cast<double4 *>(fown)[c] = make_double4(-ox, -oy, -oz, oe);
+  centre_tally(o, acc, eflag, vflag);
+}
+
+// ---- centres with at most three neighbours: ONE LANE per centre ------------------------------------------
+// An S atom of MoS2 has three Mo-S bonds and nothing else inside rcmax, and S centres are two thirds of all
+// centres.  In 4-lane groups a wave served 16 of them: ~600 instructions for 48 bonds, most lanes idle in most of
+// them, two dependent load levels in front -- 43 % VALU issue, 61 % of the wave cycles waiting (round-3 counters).
+// Here a lane walks the packed candidates of its centre by itself (16 gathers in flight per lane), keeps the three
+// neighbours in registers (static indexing: the k-th neighbour's atom and slot are picked up with selects, its
+// geometry is then fetched again -- an L1 hit), and evaluates the three pairs straight-line: no LDS, no shuffles,
+// 64 centres per wave.  A centre that finds a fourth neighbour goes to the overflow list like any centre that
+// outgrows its lane group; the classification keeps centres with a candidate near rcmax out of this class.
+__global__ __launch_bounds__(256) void rebo_centre3_kernel(
+    const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
+    const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
+    const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
+    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf3 /* count at [-1] */, const int eflag,
+    const int vflag, const int tc)
+{
+  constexpr int W = CentreCfg<4>::UA * 4; // packed candidates per centre of this class (pack_cand_kernel)
+  static_assert(W == 16, "four int4 per centre");
+  const long long gid = (long long) blockIdx.x * 256 + threadIdx.x;
+  const bool have = gid < ncent;
+  int jp[W];
+  {
+    const int4 *__restrict__ p4 = reinterpret_cast<const int4 *>(pk) + (have ? gid : 0) * (W / 4);
+#pragma unroll
+    for (int q = 0; q < W / 4; q++) {
+      const int4 v = p4[q];
+      jp[4 * q] = have ? v.x : -1;
+      jp[4 * q + 1] = have ? v.y : -1;
+      jp[4 * q + 2] = have ? v.z : -1;
+      jp[4 * q + 3] = have ? v.w : -1;
+    }
+  }
+  int c = 0, off = 0, nc = 0;
+  double4 xc = make_double4(0, 0, 0, 0);
+  if (have) {
+    c = centres[gid];
+    off = cand_off[c];
+    nc = cand_off[c + 1] - off;
+    xc = xq[c];
+  }
+  double4 *__restrict__ slot4 = reinterpret_cast<double4 *>(fnbr) + off;
+  const double rc2_0 = P.rcmaxsq[tc * 2], rc2_1 = P.rcmaxsq[tc * 2 + 1];
+
+  // ---- phase A: which candidates are inside rcmax now (pair_rebomos.cpp:328-344); the first three are kept
+  int n = 0, nj0 = 0, nj1 = 0, nj2 = 0, ts0 = 0, ts1 = 0, ts2 = 0;
+  unsigned long long active = 0ull;
+  auto take = [&](const int t, const int j, const bool valid, const double4 xj) {
+    const double dx = xc.x - xj.x, dy = xc.y - xj.y, dz = xc.z - xj.z;
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    const double rc2 = ((int) xj.w) ? rc2_1 : rc2_0;
+    const bool pred = valid && rsq < rc2;
+    if (valid && !pred && rsq < rc2 * (1.0 + 1.0e-14)) slot4[t] = make_double4(0.0, 0.0, 0.0, 0.0); // (see centre_take)
+    const bool s0 = pred && n == 0, s1 = pred && n == 1, s2 = pred && n == 2;
+    nj0 = s0 ? j : nj0;
+    nj1 = s1 ? j : nj1;
+    nj2 = s2 ? j : nj2;
+    ts0 = s0 ? t : ts0;
+    ts1 = s1 ? t : ts1;
+    ts2 = s2 ? t : ts2;
+    n += pred ? 1 : 0;
+    if (pred && t < 64) active |= 1ull << t;
+  };
+#pragma unroll
+  for (int h = 0; h < 2; h++) { // two batches of eight gathers
+    double4 xj[W / 2];
+#pragma unroll
+    for (int u = 0; u < W / 2; u++) xj[u] = xq[jp[h * (W / 2) + u] >= 0 ? jp[h * (W / 2) + u] : c];
+#pragma unroll
+    for (int u = 0; u < W / 2; u++) take(h * (W / 2) + u, jp[h * (W / 2) + u], jp[h * (W / 2) + u] >= 0, xj[u]);
+  }
+  for (int t = W; __any(t < nc); t++) { // rows longer than the packed part (rare)
+    const bool valid = t < nc;
+    const int j = valid ? cand[off + t] : c;
+    take(t, j, valid, xq[j]);
+  }
+  if (have) amask[c] = active;
+  const bool outgrown = n > 3; // a fourth neighbour: the 8-lane-group kernel takes this centre right after this launch
+  if (outgrown) {
+    ovf3[atomicAdd(&ovf3[-1], 1)] = c;
+    n = 0;
+  }
+
+  // ---- the (at most) three neighbours, in registers
+  int nj[3] = {nj0, nj1, nj2}, ts[3] = {ts0, ts1, ts2};
+  double dx[3], dy[3], dz[3], r[3], w[3], dw[3], ri[3], ux[3], uy[3], uz[3];
+  int tj[3];
+  bool act[3];
+  double Ntot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    act[k] = k < n;
+    const double4 xj = xq[act[k] ? nj[k] : c];
+    tj[k] = act[k] ? (int) xj.w : 0;
+    const double ex = xc.x - xj.x, ey = xc.y - xj.y, ez = xc.z - xj.z;
+    const double rsq = act[k] ? ex * ex + ey * ey + ez * ez : 1.0;
+    const int pt = tc * 2 + tj[k];
+    ri[k] = rsqrt_nr(rsq); // r and 1/r from one reciprocal square root
+    r[k] = rsq * ri[k];
+    double dwk = 0.0;
+    const double wk = sp_switch(r[k], P.rcmin[pt], P.rcinv[pt], dwk);
+    w[k] = act[k] ? wk : 0.0;
+    dw[k] = act[k] ? dwk : 0.0;
+    dx[k] = act[k] ? ex : 0.0;
+    dy[k] = act[k] ? ey : 0.0;
+    dz[k] = act[k] ? ez : 0.0;
+    ux[k] = dx[k] * ri[k];
+    uy[k] = dy[k] * ri[k];
+    uz[k] = dz[k] * ri[k];
+    Ntot += w[k]; // nM + nS (pair_rebomos.cpp:339-342)
+  }
+  double cb[7], cg[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    cb[k] = P.b[tc][k];
+    cg[k] = P.bg[tc][k];
+  }
+  // P(N) and dP/dN, pair_rebomos.h:173-179
+  const double ea = exp(-P.a[tc][2] * Ntot);
+  const double dp = -P.a[tc][0] + P.a[tc][1] * P.a[tc][2] * ea;
+  const double PS = -P.a[tc][0] * (Ntot - 1.0) - P.a[tc][1] * ea + P.a[tc][3];
+
+  // ---- the three unordered pairs (0,1) (0,2) (1,2): cos, G, G' once each (pair_rebomos.cpp:607-630)
+  double cs[3], g[3], dg[3], S[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const int m = e == 2 ? 1 : 0, q = e == 0 ? 1 : 2;
+    double cv = ux[m] * ux[q] + uy[m] * uy[q] + uz[m] * uz[q];
+    cv = fmin(cv, 1.0);
+    cv = fmax(cv, -1.0);
+    cs[e] = cv;
+    double d1;
+    // (wave-uniform test: the blend of the two polynomials only when some centre of the wave has cos >= 1/2)
+    if (__any(cv >= 0.5)) g[e] = gspline(cb, cg, cv, d1); // (wave-uniform: the blend only when some centre needs it)
+    else g[e] = poly6(cb, cv, d1);
+    dg[e] = d1;
+    const bool both = act[m] && act[q];
+    S[m] += both ? w[q] * g[e] : 0.0;
+    S[q] += both ? w[m] * g[e] : 0.0;
+  }
+  double p[3], VA[3], C[3], Csum = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int pt = tc * 2 + tj[k];
+    p[k] = rsqrt_nr(1.0 + S[k] + PS);
+    VA[k] = -w[k] * P.B[pt] * exp(-P.beta[pt] * r[k]);
+    C[k] = (act[k] && w[k] > kTol) ? 0.5 * VA[k] * (-0.5 * p[k] * p[k] * p[k]) : 0.0;
+    Csum += C[k];
+  }
+  // ---- forces on the slots (pair_rebomos.cpp:634-725)
+  double fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}, fz[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const int m = e == 2 ? 1 : 0, q = e == 0 ? 1 : 2;
+    if (!(act[m] && act[q])) continue;
+    // (C_m w_q + C_q w_m) G'(cos) d cos / d x ; d cos/d x_m = -(u_q - cos u_m)/r_m ; force = -gradient
+    const double common = (C[m] * w[q] + C[q] * w[m]) * dg[e];
+    const double cm = common * ri[m], cq = common * ri[q];
+    fx[m] += cm * (ux[q] - cs[e] * ux[m]);
+    fy[m] += cm * (uy[q] - cs[e] * uy[m]);
+    fz[m] += cm * (uz[q] - cs[e] * uz[m]);
+    fx[q] += cq * (ux[m] - cs[e] * ux[q]);
+    fy[q] += cq * (uy[m] - cs[e] * uy[q]);
+    fz[q] += cq * (uz[m] - cs[e] * uz[q]);
+    a1[m] += C[q] * g[e];
+    a1[q] += C[m] * g[e];
+  }
+  CentreOut o = {0, 0, 0, 0, 0, 0, 0};
+  const bool owned = have && c < nlocal;
+  double ox = 0.0, oy = 0.0, oz = 0.0, oe = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (!act[k]) continue;
+    double eh = 0.0;
+    finish_slot(P, tc, ts[k] | (tj[k] << 30), off, dp, owned, eflag, dx[k], dy[k], dz[k], r[k], w[k], dw[k], p[k], ri[k],
+                VA[k], fx[k], fy[k], fz[k], a1[k], Csum, fnbr, eh, o);
+    ox += fx[k];
+    oy += fy[k];
+    oz += fz[k];
+    oe += eh;
+  }
+  // the centre's own share: minus the sum of its slot forces, plus the centre halves of the pair energies
+  if (owned && !outgrown)
+    reinterpret_cast<double4 *>(fown)[c] = make_double4(-ox, -oy, -oz, (eflag & MDP_EFLAG_ATOM) ? oe : 0.0);
   centre_tally(o, acc, eflag, vflag);
 }
 
@@ -2338,8 +2542,10 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
       const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
       n += (dx * dx + dy * dy + dz * dz) < P.rcmaxsq[ti * 2 + (int) xj.w];
     }
-    // smallest lane group that holds the current coordination (one lane per neighbour, some to spare)
-    k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 12) ? 2 : (n <= 14) ? 3 : 4; // groups of 4, 8, 12, 16, 32 lanes
+    // smallest lane group that holds the current coordination (one lane per neighbour, some to spare); class 0 is
+    // the lane-per-centre kernel with room for exactly three neighbours (a centre that finds a fourth before the next
+    // list build -- S-S pairs of MoS2 sit 0.13 A outside rcmax -- is passed to the 8-lane-group kernel in the same step)
+    k = (n <= 3) ? 0 : (n <= 7) ? 1 : (n <= 12) ? 2 : (n <= 14) ? 3 : 4; // 1 / 8 / 12 / 16 / 32 lanes
     k = 2 * k + (ti != 0); // classes are per (lane-group size, element): the element is then uniform per launch
     if (bnd) k += MDP_NCLASS_HALF;
   }
@@ -2549,7 +2755,10 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->lj_off.reserve(nrow_max + 2));
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
-  MDP_HIP(c, c->ovf.reserve((size_t) nall + 2));
+  // overflow lists: [0] the general kernel's, [1..4] the lane-per-centre kernel's per (part, element); each {count, ids...}
+  MDP_HIP(c, c->ovf.reserve((size_t) 5 * (nall + 2)));
+  c->ovf_stride = nall + 2;
+  c->acc_prezeroed = false; // (the counters sit at new places: the next mdp_acc_begin zeroes them itself)
   // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost.  (Round 1 split the
   // Lennard-Jones tiles instead, which needs the slot gather as a kernel of its own: 0.495 against 0.462 ms per
   // step of an 8-GPU sub-domain)
@@ -2927,6 +3136,33 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
   }
 }
 
+// centres with at most three neighbours (class 0 of either element): one lane per centre
+static void launch_centre3(mdp_ctx *c, int eflag, int vflag, int part)
+{
+  for (int elem = 0; elem < 2; elem++) {
+    const int k = elem + part * MDP_NCLASS_HALF;
+    const int n = c->h_class_count[k];
+    if (n <= 0) continue;
+    // its centres with a fourth neighbour (S-S pairs dip below rcmax at 300 K) land on list (part, elem) ...
+    const int q = part * 2 + elem;
+    int *list = c->ovf.p + (size_t) (q + 1) * c->ovf_stride + 1; // (count at list[-1]; zeroed with the accumulators)
+    rebo_centre3_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
+                                                                c->nlocal, c->xq.p, c->cand_off.p, c->cand.p,
+                                                                c->pk_cand.p + c->pk_base[k], c->amask.p, c->fnbr.p,
+                                                                c->fown.p, c->acc.p, list, eflag, vflag, elem);
+    // ... and go through the 8-lane-group kernel at once; grid from the count seen a step ago (+ 25 % + one block),
+    // the kernel itself hands what it does not cover to the general kernel
+    int *h_cnt = (int *) (c->h_pinned + 40) + q;
+    constexpr int per_block = CentreCfg<8>::WPB * CentreCfg<8>::GPW;
+    long long est = (long long) *h_cnt + *h_cnt / 4 + per_block;
+    if (est > n) est = n;
+    const int grid = (int) ((est + per_block - 1) / per_block);
+    rebo_centre_kernel<8, true><<<grid, 64 * CentreCfg<8>::WPB, 0, c->stream>>>(
+        c->rebomos, list, 0, c->nlocal, c->xq.p, c->cand_off.p, c->cand.p, h_cnt, c->amask.p, c->fnbr.p, c->fown.p,
+        c->acc.p, c->ovf.p, eflag, vflag, elem);
+  }
+}
+
 // (Re-)prune the tile rows from the current positions (tile_prune_kernel) and remember those positions.
 // lim_rsq[ti * 2 + tj]: (largest pair distance the kernels act on + buffer)^2.
 int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
@@ -3098,7 +3334,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
   hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
   for (int part = 0; part < 2; part++) {
     if (!((parts >> part) & 1)) continue;
-    launch_centre<4>(c, 0, eflag, vflag, part);
+    launch_centre3(c, eflag, vflag, part);
     launch_centre<8>(c, 1, eflag, vflag, part);
     launch_centre<12>(c, 2, eflag, vflag, part);
     launch_centre<16>(c, 3, eflag, vflag, part);
