@@ -321,6 +321,7 @@ struct mdp_ctx {
   DevBuf<int> rev16;              // [nlocal][16] the first 16 of them at a fixed stride
   DevBuf<int> ovf;                // 5 x [1+nall+1]: centres handed on this step -- to the general kernel / by the lane-per-centre kernel
   int ovf_stride = 0;
+  int ovf3_hot[4] = {0, 0, 0, 0}; // computes left in list mode per (part, element) list of the lane-per-centre kernel
   DevBuf<mdp_hold_t> xhold_all;   // [nall][3] positions when the style lists were built
   double skin_inner = 0.0;        // the style lists' own skin (<= the host's)
   double skin_inner_auto = 1.0;   // adaptive default of it (grows when the displacement trigger fires too often)

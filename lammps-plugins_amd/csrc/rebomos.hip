@@ -593,16 +593,17 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
 // geometry is then fetched again -- an L1 hit), and evaluates the three pairs straight-line: no LDS, no shuffles,
 // 64 centres per wave.  A centre that finds a fourth neighbour goes to the overflow list like any centre that
 // outgrows its lane group; the classification keeps centres with a candidate near rcmax out of this class.
-__global__ __launch_bounds__(256) void rebo_centre3_kernel(
+constexpr int kC3Block = 256; // (64-thread blocks measured the same: the kernel is bound by memory traffic)
+__global__ __launch_bounds__(kC3Block) void rebo_centre3_kernel(
     const RebomosDev P, const int *__restrict__ centres, const int ncent, const int nlocal,
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     const int *__restrict__ pk, unsigned long long *__restrict__ amask, double *__restrict__ fnbr,
-    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf3 /* count at [-1] */, const int eflag,
-    const int vflag, const int tc)
+    double *__restrict__ fown, double *__restrict__ acc, int *__restrict__ ovf3 /* count at [-1] */,
+    int *__restrict__ ovf_general /* or null */, const int eflag, const int vflag, const int tc)
 {
   constexpr int W = CentreCfg<4>::UA * 4; // packed candidates per centre of this class (pack_cand_kernel)
   static_assert(W == 16, "four int4 per centre");
-  const long long gid = (long long) blockIdx.x * 256 + threadIdx.x;
+  const long long gid = (long long) blockIdx.x * kC3Block + threadIdx.x;
   const bool have = gid < ncent;
   int jp[W];
   {
@@ -662,7 +663,9 @@ __global__ __launch_bounds__(256) void rebo_centre3_kernel(
   if (have) amask[c] = active;
   const bool outgrown = n > 3; // a fourth neighbour: the 8-lane-group kernel takes this centre right after this launch
   if (outgrown) {
-    ovf3[atomicAdd(&ovf3[-1], 1)] = c;
+    const int at = atomicAdd(&ovf3[-1], 1); // (counted in either mode: the host watches this number)
+    if (ovf_general) ovf_general[1 + atomicAdd(&ovf_general[0], 1)] = c; // no 8-lane launch behind this one: general kernel
+    else ovf3[at] = c;
     n = 0;
   }
 
@@ -781,9 +784,11 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ fown,
     double *__restrict__ vslot, double *__restrict__ vatom, double *__restrict__ acc, int *__restrict__ flags,
-    const int eflag, const int vflag)
+    const int eflag, const int vflag, int *__restrict__ h_cnt4 = nullptr, const int ovf_stride = 0)
 {
   constexpr int G = 32, CAP = 64, STRIDE = CAP * kRec + 2;
+  // (the last centre kernel of a step: publishes how many centres outgrew the lane-per-centre kernel, per list)
+  if (h_cnt4 && list_count < 0 && blockIdx.x == 0 && threadIdx.x < 4) h_cnt4[threadIdx.x] = list[(size_t) (threadIdx.x + 1) * ovf_stride];
   __shared__ double s_rec[8 * STRIDE];
   __shared__ int s_je[8 * CAP];
   // list_count < 0: overflow list of the fast kernels, {count, ids...}; else an explicit list of centres
@@ -3143,16 +3148,24 @@ static void launch_centre3(mdp_ctx *c, int eflag, int vflag, int part)
     const int k = elem + part * MDP_NCLASS_HALF;
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
-    // its centres with a fourth neighbour (S-S pairs dip below rcmax at 300 K) land on list (part, elem) ...
+    // Its centres with a fourth neighbour (S-S pairs of MoS2 dip below rcmax at 300 K) are counted per (part, elem);
+    // the count of a step is published to a pinned word by the last centre kernel of the step (read here a step or two
+    // late, no synchronisation).  While it is zero -- a cold crystal -- such a centre goes straight to the general
+    // kernel's list; once centres do overflow they are collected on a list of their own ...
     const int q = part * 2 + elem;
     int *list = c->ovf.p + (size_t) (q + 1) * c->ovf_stride + 1; // (count at list[-1]; zeroed with the accumulators)
-    rebo_centre3_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
+    int *h_cnt = (int *) (c->h_pinned + 40) + q;
+    if (*h_cnt > 0) c->ovf3_hot[q] = 64;      // (hysteresis: stay in list mode for 64 computes after the last overflow)
+    else if (c->ovf3_hot[q] > 0) c->ovf3_hot[q]--;
+    const bool list_mode = c->ovf3_hot[q] > 0;
+    rebo_centre3_kernel<<<(n + kC3Block - 1) / kC3Block, kC3Block, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
                                                                 c->nlocal, c->xq.p, c->cand_off.p, c->cand.p,
                                                                 c->pk_cand.p + c->pk_base[k], c->amask.p, c->fnbr.p,
-                                                                c->fown.p, c->acc.p, list, eflag, vflag, elem);
+                                                                c->fown.p, c->acc.p, list, list_mode ? nullptr : c->ovf.p,
+                                                                eflag, vflag, elem);
+    if (!list_mode) continue;
     // ... and go through the 8-lane-group kernel at once; grid from the count seen a step ago (+ 25 % + one block),
     // the kernel itself hands what it does not cover to the general kernel
-    int *h_cnt = (int *) (c->h_pinned + 40) + q;
     constexpr int per_block = CentreCfg<8>::WPB * CentreCfg<8>::GPW;
     long long est = (long long) *h_cnt + *h_cnt / 4 + per_block;
     if (est > n) est = n;
@@ -3351,7 +3364,7 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
                                                             c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
                                                             c->fown.p, nullptr, nullptr, c->acc.p, c->flags.p,
-                                                            eflag, vflag);
+                                                            eflag, vflag, (int *) (c->h_pinned + 40), c->ovf_stride);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
