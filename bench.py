@@ -379,6 +379,7 @@ def run_job(E, job, par):
     sync_all()
     elapsed = time.perf_counter() - t0
     style_builds = ctx.md_neighbor_stats()[7] - style_builds0 if wl == "rebomos" else 0
+    lstate = ctx.md_list_state()
     prune1 = ctx.md_prune_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if stage_host else dev)
@@ -414,7 +415,7 @@ def run_job(E, job, par):
     ms_per_step = elapsed / job["steps"] * 1e3
     if wl == "rebomos":
         lj = "rebo_lj_gather_kernel" if os.environ.get("MDP_LJ_TILE", "1") == "0" else "rebo_lj_tile_kernel"
-        phases = {"rebo_centre_kernel<4|8|12|16|32> (all launches)": kms[0], "tile_prune_kernel (when due)": kms[1],
+        phases = {"rebo_centre3_kernel + rebo_centre_kernel<8|12|16|32> (all launches)": kms[0], "tile_prune_kernel (when due)": kms[1],
                   lj + " (one launch)": kms[2]}
         single = {lj: kms[2]}                       # phases that are ONE launch: candidates for `dominant_kernel`
     else:
@@ -475,6 +476,9 @@ def run_job(E, job, par):
                    "dangerous_builds": int(dom.dangerous),
                    "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
                                   else "adaptive from 1.0") if wl == "rebomos" else None,
+                   "inner_skin_in_effect": round(lstate["skin"], 3) if wl == "rebomos" else None,
+                   "inner_skin_cap": (round(lstate["inner_skin_cap"], 3) or None) if wl == "rebomos" else None,
+                   "late_style_list_builds_rank0": lstate["late_builds"],
                    "style_list_builds_in_timed_region_rank0": int(style_builds),
                    "row_prunings_in_timed_region_rank0": prune1["prunings"] - prune0["prunings"],
                    "row_prunings_late_rank0": prune1["late"] - prune0["late"],

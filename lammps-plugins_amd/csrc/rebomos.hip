@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * CentreCfg<G>::WPB) void rebo_centre_kernel(
   const int gw = lane / G;         // group within the wave (G = 12: the last four lanes form no group)
   const bool lane_ok = gw < C::GPW;
   const int grp_in_block = (tid >> 6) * C::GPW + (lane_ok ? gw : C::GPW - 1);
-  const long long gid = (long long) blockIdx.x * (C::WPB * C::GPW) + grp_in_block;
+  const long long gid = (long long) (LIST ? (int) blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x)) * (C::WPB * C::GPW) + grp_in_block;
   const int ncent = LIST ? centres[-1] : ncent_arg;
   const bool have = lane_ok && gid < ncent;
   if (LIST) {
@@ -603,7 +603,9 @@ __global__ __launch_bounds__(kC3Block) void rebo_centre3_kernel(
 {
   constexpr int W = CentreCfg<4>::UA * 4; // packed candidates per centre of this class (pack_cand_kernel)
   static_assert(W == 16, "four int4 per centre");
-  const long long gid = (long long) blockIdx.x * kC3Block + threadIdx.x;
+  // (blocks are dealt round-robin to the 8 XCDs, each with its own L2: every XCD takes one contiguous stretch of the
+  //  class list -- atoms in curve order -- so that the neighbours its centres gather are shared within ITS L2)
+  const long long gid = (long long) xcd_contiguous(blockIdx.x, gridDim.x) * kC3Block + threadIdx.x;
   const bool have = gid < ncent;
   int jp[W];
   {

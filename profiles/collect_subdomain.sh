@@ -2,7 +2,7 @@
 # timeline and PMC traffic of rank 0's sub-domain for the 2-, 4- and 8-brick decompositions of the headline system
 # (all bricks on one GPU as threads, rank 0 stepping alone at the end).  usage: bash profiles/collect_subdomain.sh r03
 set -u
-R=${1:-r03}; ROOT=$GRAFT_REPO_ROOT; STEPS=30
+R=${1:-r04}; ROOT=$GRAFT_REPO_ROOT; STEPS=30
 cd $ROOT; SHA=$(python3 -c "import bench; print(bench.kernel_source_sha())")
 for N in 8 4 2; do
   OUT=$ROOT/gpurun_out/${R}_subdomain$N; rm -rf $OUT; mkdir -p $OUT

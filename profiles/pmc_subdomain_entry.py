@@ -10,7 +10,7 @@ root, key, sha, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 AEAM = key.startswith("aeam")
 PATH = ("aeam_ptile_kernel", "aeam_tile_density_kernel", "aeam_density_ang_kernel", "aeam_embed_kernel",
         "aeam_tile_force_kernel", "aeam_force_ang_kernel", "aeam_density_kernel", "aeam_force_kernel") if AEAM else \
-       ("rebo_centre_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_gather_kernel",
+       ("rebo_centre_kernel", "rebo_centre3_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_gather_kernel",
         "rebo_gather_kernel")
 
 

@@ -7,7 +7,7 @@ usage: pmc_traffic_entry.py <dir with pmc_fetch/ pmc_write/> <key> <kernel_sourc
 import collections, csv, glob, json, os, re, sys
 
 root, key, sha = sys.argv[1], sys.argv[2], sys.argv[3]
-PATH = ("rebo_centre_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_gather_kernel", "rebo_gather_kernel",
+PATH = ("rebo_centre_kernel", "rebo_centre3_kernel", "rebo_centre_general_kernel", "rebo_lj_tile_kernel", "rebo_lj_gather_kernel", "rebo_gather_kernel",
         "aeam_ptile_kernel", "aeam_tile_density_kernel", "aeam_density_kernel", "aeam_density_ang_kernel", "aeam_embed_kernel",
         "aeam_tile_force_kernel", "aeam_force_kernel", "aeam_force_ang_kernel")
 
