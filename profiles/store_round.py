@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """copy a round's collection (gpurun_out/<round>_*, made by profiles/collect_round.sh on the GPU box) into profiles/
 and refresh the entries of profiles/pmc_traffic.json that bench.py reports as `traffic`.
-usage: python3 profiles/store_round.py r03"""
+usage: python3 profiles/store_round.py r04"""
 import json
 import os
 import shutil
 import sys
 
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -41,4 +41,22 @@ for n in (2, 4, 8):
             if v.get("bytes_per_step", 0) > 0:
                 tab[k] = v
                 print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
+# aeam sub-domains (BASELINE.json configs[4], profiles/collect_subdomain_aeam.sh)
+for n in (2, 4, 8):
+    sd = os.path.join(G, RND + "_aeam_subdomain%d" % n)
+    if os.path.exists(os.path.join(sd, "timeline.txt")):
+        with open(os.path.join(P, RND + "_aeam_subdomain%d_step_timeline.txt" % n), "w") as f:
+            f.write(open(os.path.join(sd, "subdomain.json")).read() + "\n" + open(os.path.join(sd, "timeline.txt")).read())
+    pe = os.path.join(sd, "pmc_entry.json")
+    if os.path.exists(pe) and os.path.getsize(pe) > 10:
+        ent = json.load(open(pe))
+        for k, v in ent.items():
+            if v.get("bytes_per_step", 0) > 0:
+                tab[k] = v
+                print("pmc entry", k, v["bytes_per_step"], v["kernel_source_sha"])
+# counters, rehearsal log, trajectory pin
+for src, dst in ((RND + "_rebomos4m_pmc_sq_tcp_counters.json",) * 2, (RND + "_aeam1m_pmc_sq_tcp_counters.json",) * 2,
+                 (RND + "_trajectory_pin.json",) * 2, (RND + "_rehearse.log", RND + "_rehearse_one_gpu.log")):
+    if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 10:
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 json.dump(tab, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
