@@ -278,8 +278,11 @@ int mdp_md_prune_stats(mdp_ctx *ctx, long long out[4]);
 /* out[0] = skin of the style's own lists in effect (rebomos: the inner skin, adaptive or MDP_INNER_SKIN; aeam: the
  * host's), [1] = cap on the inner skin, 0 = none (a candidate row outgrew the 64-bit active mask at that skin: the
  * lists were rebuilt with half of it), [2] = pruning buffer in effect (0: rows as built),
- * [3] = list builds that came late (an atom was beyond half the inner skin when the deferred trigger was read) */
-int mdp_md_list_state(mdp_ctx *ctx, double out[4]);
+ * [3] = list builds that came late (an atom was beyond half the inner skin when the deferred trigger was read),
+ * [4] = rebomos: centres that outgrew the lane-per-centre kernel (a fourth neighbour) in the last step whose count has
+ * reached the host, [5] = 1 while such centres are collected on a device list and taken by the 8-lane-group kernel
+ * (0: they go to the general kernel's list), [6..7] reserved */
+int mdp_md_list_state(mdp_ctx *ctx, double out[8]);
 /* shape of the rebomos style's own Lennard-Jones lists after the last build (host and resident mode):
  * out[0]=1 tile lists / 0 per-cluster lists (fallback), [1]=#tiles, [2]=union stride, [3]=largest union,
  * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,

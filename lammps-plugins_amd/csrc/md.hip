@@ -1173,13 +1173,19 @@ int mdp_md_neighbor_stats(mdp_ctx *c, long long out[8])
   return MDP_OK;
 }
 
-int mdp_md_list_state(mdp_ctx *c, double out[4])
+int mdp_md_list_state(mdp_ctx *c, double out[8])
 {
   if (!c || !out) return MDP_EINVAL;
+  for (int k = 0; k < 8; k++) out[k] = 0.0;
   out[0] = c->cfg.style == 1 ? c->skin_inner : c->cfg.skin;
   out[1] = c->skin_inner_cap < 1.0e8 ? c->skin_inner_cap : 0.0;
   out[2] = c->prune_valid ? c->prune_buf : 0.0;
   out[3] = (double) c->dangerous_builds;
+  if (c->h_pinned) {
+    const int *h = (const int *) (c->h_pinned + 40);
+    out[4] = (double) h[0] + h[1] + h[2] + h[3];
+  }
+  out[5] = (c->ovf3_hot[0] > 0 || c->ovf3_hot[1] > 0 || c->ovf3_hot[2] > 0 || c->ovf3_hot[3] > 0) ? 1.0 : 0.0;
   return MDP_OK;
 }
 

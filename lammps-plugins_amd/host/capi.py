@@ -336,9 +336,10 @@ class Context:
         self._ck(self.L.mdp_md_defer_final(self.h))
 
     def md_list_state(self):
-        out = (C.c_double * 4)()
+        out = (C.c_double * 8)()
         self._ck(self.L.mdp_md_list_state(self.h, out))
-        return dict(skin=out[0], inner_skin_cap=out[1], prune_buffer=out[2], late_builds=int(out[3]))
+        return dict(skin=out[0], inner_skin_cap=out[1], prune_buffer=out[2], late_builds=int(out[3]),
+                    centre3_overflow=int(out[4]), centre3_list_mode=bool(out[5]))
 
     def md_final_initial_integrate(self):
         self._ck(self.L.mdp_md_final_initial_integrate(self.h))

@@ -235,3 +235,42 @@ def test_deferred_final_kick_is_completed_when_velocities_are_read():
     assert out[True][0] == pytest.approx(out[False][0], rel=1e-14)
     for k in (1, 2, 3):
         assert np.array_equal(out[True][k], out[False][k])
+
+
+def test_lane_per_centre_kernel_hands_fourth_neighbours_on(oracle):
+    """The S centres of MoS2 take one lane each with room for three neighbours (rebo_centre3_kernel).  The lists are built
+    on a slightly compressed, nearly perfect cell (S-S 3.04-3.09 A, just outside rcmax = 3.0 A: every S centre has its
+    three bonds and is classified for that kernel); then the atoms are displaced by ~0.08 A inside the list skin, S-S
+    pairs come inside rcmax and many S centres have four or five neighbours: in the first such compute they reach the
+    general kernel's list, once the host has seen the count they are collected on a device list and taken by the
+    8-lane-group kernel in the same step.  Forces and energies of every compute against the oracle; both routes must
+    have been used."""
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s0 = S.jitter(S.scale(S.replicate(S.rebomos_bulk_cell(), (3, 3, 1)), 0.97), 0.01, seed=77)
+    ctx = capi.Context(0)
+    ctx.rebomos_set_params(capi.read_rebomos_file(POT_REBOMOS))
+    p = capi.read_rebomos_file(POT_REBOMOS)
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s0, 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1])
+    seen_list_mode, seen_general = False, False
+    rng = np.random.default_rng(5)
+    for it in range(5):
+        d.compute(3, 1)
+        th = d.thermo()
+        got = ctx.md_download(d.nlocal, want=("x", "f", "eatom"))
+        st = ctx.md_list_state()
+        order = np.argsort(d.tags_local)
+        x = got["x"][order]
+        o = mdref.RebomosCPU(oracle, P, S.System(s0.box, x, s0.type, s0.tag, s0.mass)).compute(x)
+        assert np.abs(got["f"][order] - o["f_owned"]).max() < 1e-9
+        assert np.abs(got["eatom"][order] - o["eatom_owned"]).max() < 1e-9
+        assert th["pe"] == pytest.approx(o["eng"], rel=1e-10)
+        if it > 1:
+            assert st["centre3_overflow"] > 0           # S centres with a fourth neighbour exist ...
+            seen_list_mode = seen_list_mode or st["centre3_list_mode"]
+        seen_general = seen_general or not st["centre3_list_mode"]
+        if it == 0:
+            x_built = got["x"].copy()
+        # displace the atoms inside the skin (same lists: no atom moves 0.5 A), other neighbour counts every time
+        ctx.md_upload_x(x_built + 0.08 * np.clip(rng.standard_normal(x_built.shape), -2.5, 2.5))
+    assert seen_general and seen_list_mode              # ... and went both ways
+    ctx.close()
