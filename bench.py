@@ -210,8 +210,8 @@ def attach_cpu_baseline(out, workload, seconds):
 
 # ------------------------------------------------------------------------------------------------ host mode
 def host_mode_rate(E, s, workload, pot, skin, cutghost, steps=9):
-    """PCIe-inclusive rate of the drop-in boundary (what a LAMMPS Pair::compute() sees): per step x of owned+ghost
-    atoms goes up (24 B/atom), forces come back (24 B/atom; aeam also fp both ways).  Never `value`."""
+    """PCIe-inclusive rate of the drop-in boundary (what a LAMMPS Pair::compute() on one rank sees): per step x of the
+    owned atoms goes up (24 B/atom), their forces come back (24 B/atom).  Never `value`."""
     import numpy as np
     capi, S = E["capi"], E["S"]
     xw = S.wrap(s.box, s.x)
@@ -222,6 +222,7 @@ def host_mode_rate(E, s, workload, pot, skin, cutghost, steps=9):
     n, nall = s.n, len(xa)
     ctx = capi.Context(0)
     eng, vir = capi.C.c_double(0.0), np.zeros(6)
+    ctx.set_box_host(s.box)          # as the adapters do on one rank (plugin/pair_*.cpp): the images stay on the device
     if workload == "rebomos":
         ctx.rebomos_set_params(pot)
         ctx.set_atoms_host(n, xa, type_all, tag_all, 2, map_=[0, 0, 1])
@@ -236,15 +237,20 @@ def host_mode_rate(E, s, workload, pot, skin, cutghost, steps=9):
         ctx.set_atoms_host(n, xa, type_all, tag_all, 2)
         ctx.set_skin(skin)
         f = np.zeros((nall, 3))
-        fp, fp_all = np.zeros(n), np.zeros(nall)
+        fp = np.zeros(nall)
+        local_halo = ctx.host_ghosts_derived()
 
         def compute():
-            # PairAEAM::compute in the adapter: density half, the style's forward_comm of fp (here: the periodic
-            # images copy their owners' values on the host, as Comm::forward_comm does on one rank), force half
+            # PairAEAM::compute in the adapter (plugin/pair_aeam.cpp): density half, the style's forward_comm of fp,
+            # force half.  On one periodic rank fp and the images' share of the forces stay on the device; otherwise
+            # the images copy their owners' fp on the host, as Comm::forward_comm does
+            if local_halo:
+                ctx._ck(ctx.L.mdp_aeam_density_host(ctx.h, 0, None, None, capi.C.byref(eng), None))
+                ctx._ck(ctx.L.mdp_aeam_force_host(ctx.h, 0, 0, None, capi._dp(f), capi.C.byref(eng), capi._dp(vir), None, None))
+                return
             ctx._ck(ctx.L.mdp_aeam_density_host(ctx.h, 0, capi._dp(fp), None, capi.C.byref(eng), None))
-            fp_all[:n] = fp
-            fp_all[n:] = fp[owner]
-            ctx._ck(ctx.L.mdp_aeam_force_host(ctx.h, 0, 0, capi._dp(fp_all), capi._dp(f), capi.C.byref(eng),
+            fp[n:] = fp[owner]
+            ctx._ck(ctx.L.mdp_aeam_force_host(ctx.h, 0, 0, capi._dp(fp), capi._dp(f), capi.C.byref(eng),
                                               capi._dp(vir), None, None))
 
     compute()
@@ -257,8 +263,10 @@ def host_mode_rate(E, s, workload, pot, skin, cutghost, steps=9):
         ctx.set_positions_host(xa)
         compute()
         times.append(time.perf_counter() - t0)
+    derived = ctx.host_ghosts_derived()
     ctx.close()
-    return float(np.median(times)) * 1e3  # (median: the host threads of a freshly started box take a few steps to settle)
+    # (median: the host threads of a freshly started box take a few steps to settle)
+    return float(np.median(times)) * 1e3, derived
 
 
 def kernel_source_sha():
@@ -609,8 +617,9 @@ def main():
     out["config"]["rccl_ranks"] = rccl_ranks
     if rank == 0 and world == 1 and dist is None and not args.no_host_mode:
         try:
-            hm = host_mode_rate(E, pieces["s"], args.workload, pieces["pot"], pieces["skin"], pieces["cutghost"])
+            hm, img = host_mode_rate(E, pieces["s"], args.workload, pieces["pot"], pieces["skin"], pieces["cutghost"])
             out["host_mode_ms_per_step"] = round(hm, 3)
+            out["host_mode_images_on_device"] = img
             out["host_mode_Matom_steps_per_s"] = round(pieces["s"].n / hm / 1e3, 2)
         except Exception as e:  # noqa: BLE001 -- informational figure
             log(f"[bench] host-mode measurement failed: {e}")
@@ -634,8 +643,9 @@ def main():
             o["note"] = "BASELINE.json configs[2] / SURVEY 8d config #3 as written: 1,000,188 atoms, 863 K, 1000 NVE steps, check every step"
             if not args.no_host_mode:
                 try:
-                    hm = host_mode_rate(E, pieces["s"], "aeam", pieces["pot"], pieces["skin"], pieces["cutghost"])
+                    hm, img = host_mode_rate(E, pieces["s"], "aeam", pieces["pot"], pieces["skin"], pieces["cutghost"])
                     o["host_mode_ms_per_step"] = round(hm, 3)
+                    o["host_mode_images_on_device"] = img
                     o["host_mode_Matom_steps_per_s"] = round(pieces["s"].n / hm / 1e3, 2)
                 except Exception as e:  # noqa: BLE001
                     log(f"[bench] aeam host-mode measurement failed: {e}")

@@ -121,6 +121,19 @@ void mdp_aeam_file_free(mdp_aeam_file *f);
 int mdp_set_atoms_host(mdp_ctx *ctx, int nlocal, int nghost, const double *x, const int *type, const int *tag,
                        int ntypes, const int *map);
 int mdp_set_positions_host(mdp_ctx *ctx, const double *x); /* per step, same nlocal/nghost */
+/* One periodic rank: every ghost is an image of an owned atom, and Comm::forward_comm gives it its owner's position
+ * plus whole box vectors.  A host that hands over its box -- h = Domain::h = {xprd, yprd, zprd, yz, xz, xy}, before
+ * mdp_set_atoms_host and again whenever the box changes (fix npt / deform: before each mdp_set_positions_host) -- lets
+ * the library do that on the device: at mdp_set_atoms_host owner (by tag) and image counts of every ghost are derived
+ * and checked against the uploaded positions (1e-8 A); if all ghosts pass, mdp_host_ghosts_derived() returns 1 and
+ *   - mdp_set_positions_host reads x[0..nlocal) only (the images follow with the box of that step),
+ *   - mdp_aeam_density_host accepts fp == NULL (and rho == NULL): fp stays on the device, images included,
+ *   - mdp_aeam_force_host accepts fp_all == NULL, folds what the images collected onto their owners itself (the
+ *     host's reverse_comm then carries zeros for this style) and adds into f[0..nlocal) / vatom[0..nlocal) only.
+ * With a ghost of another rank's atom, without tags, or with MDP_HOST_GHOSTS=upload the answer is 0 and everything is
+ * as before.  h == NULL withdraws the box. */
+int mdp_set_box_host(mdp_ctx *ctx, const double *h /* [6] or NULL */);
+int mdp_host_ghosts_derived(mdp_ctx *ctx);
 
 /* replaces the reads of list->inum/gnum/ilist/numneigh/firstneigh (pair_rebomos.cpp:304-307,
  * pair_aeam.cpp:150-153).  Call when the host has rebuilt its list (neighbor->ago == 0).
@@ -174,7 +187,8 @@ int mdp_rebomos_compute_host(mdp_ctx *ctx, int eflag, int vflag, double *f, doub
  *   force:    pass 3; fp_all[nall] must hold the owners' values on ghosts (after forward_comm).
  *             f[nall][3] is accumulated into: owned atoms fully, ghosts only with the angular
  *             three-body terms (folded by the host's reverse_comm).  vatom[nall][6] (vflag & 4, may be
- *             NULL) follows ev_tally / ev_tally3 (pair_aeam.cpp:393,472): halves / thirds, ghosts as for f. */
+ *             NULL) follows ev_tally / ev_tally3 (pair_aeam.cpp:393,472): halves / thirds, ghosts as for f.
+ * With mdp_host_ghosts_derived() == 1 fp / rho / fp_all may be NULL (see mdp_set_box_host): no fp round trip. */
 int mdp_aeam_density_host(mdp_ctx *ctx, int eflag, double *fp, double *rho, double *eng_vdwl, double *eatom);
 int mdp_aeam_force_host(mdp_ctx *ctx, int eflag, int vflag, const double *fp_all, double *f, double *eng_vdwl,
                         double *virial, double *eatom, double *vatom);

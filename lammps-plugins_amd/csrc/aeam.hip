@@ -1977,7 +1977,10 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
     c->rebo_packed = true;
     return MDP_OK;
   }
-  if (!fp) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_density_host: fp missing for %d owned atoms", c->nlocal);
+  // fp may stay on the device when the library derives the images itself (mdp_host_ghosts_derived): the style's
+  // forward_comm of fp (pair_aeam.cpp:307) then happens there too
+  if (!fp && !c->host_ghosts_derived)
+    return mdp_fail(c, MDP_EINVAL, "mdp_aeam_density_host: fp missing for %d owned atoms", c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   if (!c->rebo_packed) { // reuse the flag: "style structures follow the current list"
     if (own_lists) {
@@ -2006,16 +2009,19 @@ int mdp_aeam_density_host(mdp_ctx *c, int eflag, double *fp, double *rho, double
   if (c->host_sort) { // back to the host's atom order
     MDP_HIP(c, c->host_stage.reserve((size_t) 10 * c->nall + 16));
     double *s0 = c->host_stage.p, *s1 = s0 + n, *s2 = s1 + n;
-    MDP_TRY(mdp_to_host_order(c, n, 1, c->fp.p, s0));
-    MDP_TRY(mdp_to_host_order(c, n, 1, c->rho.p, s1));
+    if (fp) MDP_TRY(mdp_to_host_order(c, n, 1, c->fp.p, s0));
+    if (rho) MDP_TRY(mdp_to_host_order(c, n, 1, c->rho.p, s1));
     if (eflag & MDP_EFLAG_ATOM) MDP_TRY(mdp_to_host_order(c, n, 1, c->eatom.p, s2));
     dfp = s0;
     drho = s1;
     dea = s2;
   }
-  MDP_HIP(c, hipMemcpyAsync(fp, dfp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (fp) MDP_HIP(c, hipMemcpyAsync(fp, dfp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (rho) MDP_HIP(c, hipMemcpyAsync(rho, drho, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, dea, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  // nothing for the host to wait for on a force-only step that keeps fp here: overflow bits are sticky and stop the
+  // force half's read (mdp_flags_check)
+  if (!fp && !rho && !(eflag & (MDP_EFLAG_GLOBAL | MDP_EFLAG_ATOM))) return MDP_OK;
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, nullptr));
   if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) n);
   return MDP_OK;
@@ -2028,14 +2034,17 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   if (!c->have_aeam || !c->atoms_set || !c->neigh_set || !c->rebo_packed)
     return mdp_fail(c, MDP_ESTATE, "aeam: call mdp_aeam_density_host first");
   if (c->nlocal == 0) return MDP_OK; // every force term starts from an owned atom (pair_aeam.cpp:337)
-  if (!fp_all || !f) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: fp / f missing for %d atoms", c->nall);
+  const bool local_halo = c->host_ghosts_derived; // images filled and folded here, owned atoms' results only go back
+  if ((!fp_all && !local_halo) || !f) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: fp / f missing for %d atoms", c->nall);
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;
   hipStream_t st = c->stream;
   const int n = c->nlocal, nall = c->nall;
   // ghosts' fp come from the host's forward comm; owned values are already on the device
-  if (c->host_sort) { // the host's array is in its own atom order: whole array up, then into device order
+  if (!fp_all) {
+    MDP_TRY(mdp_host_ghost_scalar(c, c->fp.p)); // Comm::forward_comm of fp on one periodic rank
+  } else if (c->host_sort) { // the host's array is in its own atom order: whole array up, then into device order
     MDP_HIP(c, c->host_stage.reserve((size_t) 10 * nall + 16));
     MDP_HIP(c, hipMemcpyAsync(c->host_stage.p, fp_all, sizeof(double) * nall, hipMemcpyHostToDevice, st));
     MDP_TRY(mdp_to_device_order(c, nall, 1, c->host_stage.p, c->fp.p));
@@ -2044,30 +2053,37 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   MDP_TRY(mdp_acc_begin(c, true));
   MDP_HIP(c, hipMemsetAsync(c->eatom.p, 0, sizeof(double) * n, st));
   MDP_TRY(mdp_aeam_run_force(c, eflag, vflag));
-  // results come back through the pinned buffer and are ADDED on the host (LAMMPS semantics; ghosts included)
+  // results come back through the pinned buffer and are ADDED on the host (LAMMPS semantics; ghosts included, unless
+  // the images are the library's own: then what they collected is folded onto their owners here, which is what the
+  // host's reverse_comm would do with it, and the host's ghost entries receive nothing)
+  const int nout = local_halo ? n : nall;
+  if (local_halo) {
+    MDP_TRY(mdp_host_ghost_fold(c, 3, c->f.p));
+    if (vflag & MDP_VFLAG_ATOM) MDP_TRY(mdp_host_ghost_fold(c, 6, c->vatom.p));
+  }
   MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nall + 16));
   double *hf = c->h_down, *he = hf + (size_t) 3 * nall, *hv = he + nall;
   const double *df = c->f.p, *de = c->eatom.p, *dv = c->vatom.p;
   if (c->host_sort) {
+    MDP_HIP(c, c->host_stage.reserve((size_t) 10 * nall + 16));
     double *s0 = c->host_stage.p, *s1 = s0 + (size_t) 3 * nall, *s2 = s1 + nall;
-    MDP_TRY(mdp_to_host_order(c, nall, 3, c->f.p, s0));
+    MDP_TRY(mdp_to_host_order(c, nout, 3, c->f.p, s0));
     df = s0;
     if (eflag & MDP_EFLAG_ATOM) {
       MDP_TRY(mdp_to_host_order(c, n, 1, c->eatom.p, s1));
       de = s1;
     }
     if (vflag & MDP_VFLAG_ATOM) {
-      MDP_TRY(mdp_to_host_order(c, nall, 6, c->vatom.p, s2));
+      MDP_TRY(mdp_to_host_order(c, nout, 6, c->vatom.p, s2));
       dv = s2;
     }
   }
-  MDP_HIP(c, hipMemcpyAsync(hf, df, sizeof(double) * 3 * nall, hipMemcpyDeviceToHost, st));
   if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, de, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   if (vflag & MDP_VFLAG_ATOM)
-    MDP_HIP(c, hipMemcpyAsync(hv, dv, sizeof(double) * 6 * nall, hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipMemcpyAsync(hv, dv, sizeof(double) * 6 * nout, hipMemcpyDeviceToHost, st));
+  MDP_TRY(mdp_host_download_add(c, f, hf, df, (size_t) 3 * nout));
   MDP_TRY(aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
-  if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nall);
-  mdp_host_add(f, hf, (size_t) 3 * nall);
+  if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nout);
   if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) n);
   return MDP_OK;
 }

@@ -193,6 +193,111 @@ __global__ void permute_kernel(int n, int w, const int *__restrict__ perm, const
   dst[k] = src[(size_t) perm[i] * w + q];
 }
 
+// ---- host mode on one periodic rank: ghosts as images of owned atoms (Comm::forward_comm done on the device) ----------
+// tagmap[tag] = host index of the owned atom with that tag; flag bit 0: a tag out of range or seen twice
+__global__ void host_tagmap_kernel(const int nlocal, const int *__restrict__ tag, const int maxtag, int *__restrict__ tagmap,
+                                   int *__restrict__ flag)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlocal) return;
+  const int t = tag[i];
+  if (t < 1 || t > maxtag || atomicExch(&tagmap[t], i) != -1) atomicOr(flag, 1);
+}
+
+__global__ void host_inv_kernel(const int nall, const int *__restrict__ perm, int *__restrict__ inv)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < nall) inv[perm[p]] = p;
+}
+
+// ghost at device position nlocal+g: owner (device position) and how many box vectors it sits away from it.  The counts
+// must reproduce the uploaded image to 1e-8 A with the box the host handed over (flag bit 1 otherwise: a ghost of
+// another rank's atom, a box that is not the one the positions were made with).  perm / inv null: device order = host order
+__global__ void host_ghost_owner_kernel(const int nlocal, const int nall, const int *__restrict__ perm,
+                                        const int *__restrict__ inv, const int *__restrict__ tag,
+                                        const int *__restrict__ type, const int maxtag, const int *__restrict__ tagmap,
+                                        const double *__restrict__ x3, const double h0, const double h1, const double h2,
+                                        const double h3, const double h4, const double h5, int *__restrict__ owner,
+                                        double *__restrict__ count, double *__restrict__ shift, int *__restrict__ flag)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nall - nlocal) return;
+  const int hh = perm ? perm[nlocal + g] : nlocal + g;
+  const int t = tag[hh];
+  const int o = (t >= 1 && t <= maxtag) ? tagmap[t] : -1;
+  owner[g] = -1;
+  count[3 * (size_t) g] = count[3 * (size_t) g + 1] = count[3 * (size_t) g + 2] = 0.0;
+  shift[3 * (size_t) g] = shift[3 * (size_t) g + 1] = shift[3 * (size_t) g + 2] = 0.0;
+  if (hh < nlocal || o < 0 || type[o] != type[hh]) {
+    atomicOr(flag, 2);
+    return;
+  }
+  const double sx = x3[3 * (size_t) hh] - x3[3 * (size_t) o], sy = x3[3 * (size_t) hh + 1] - x3[3 * (size_t) o + 1],
+               sz = x3[3 * (size_t) hh + 2] - x3[3 * (size_t) o + 2];
+  const double nz = rint(sz / h2), ny = rint((sy - nz * h3) / h1), nx = rint((sx - ny * h5 - nz * h4) / h0);
+  const double ex = sx - (nx * h0 + ny * h5 + nz * h4), ey = sy - (ny * h1 + nz * h3), ez = sz - nz * h2;
+  if (!(fabs(ex) < 1e-8 && fabs(ey) < 1e-8 && fabs(ez) < 1e-8) || (nx == 0.0 && ny == 0.0 && nz == 0.0) ||
+      fabs(nx) > 64.0 || fabs(ny) > 64.0 || fabs(nz) > 64.0) {
+    atomicOr(flag, 2);
+    return;
+  }
+  owner[g] = inv ? inv[o] : o;
+  count[3 * (size_t) g] = nx;
+  count[3 * (size_t) g + 1] = ny;
+  count[3 * (size_t) g + 2] = nz;
+  shift[3 * (size_t) g] = sx; // as uploaded: the list build matches images by position (rebomos.hip rev_kernel)
+  shift[3 * (size_t) g + 1] = sy;
+  shift[3 * (size_t) g + 2] = sz;
+}
+
+__global__ void host_tag_dev_kernel(const int nall, const int *__restrict__ perm, const int *__restrict__ tag,
+                                    int *__restrict__ tag_dev)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < nall) tag_dev[p] = tag[perm ? perm[p] : p];
+}
+
+// x of an image = x of its owner + count . box, with the box of THIS step (the operand order of Comm::forward_comm's
+// pack with pbc flags: x + pbc[0]*xprd + pbc[5]*xy + pbc[4]*xz, ...)
+__global__ void host_ghost_refresh_kernel(const int nlocal, const int nghost, const int *__restrict__ owner,
+                                          const double *__restrict__ count, const double h0, const double h1,
+                                          const double h2, const double h3, const double h4, const double h5,
+                                          double4 *__restrict__ xq)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nghost) return;
+  const double4 xo = xq[owner[g]];
+  const double nx = count[3 * (size_t) g], ny = count[3 * (size_t) g + 1], nz = count[3 * (size_t) g + 2];
+  double4 x = xq[nlocal + g];
+  x.x = xo.x + nx * h0 + ny * h5 + nz * h4;
+  x.y = xo.y + ny * h1 + nz * h3;
+  x.z = xo.z + nz * h2;
+  xq[nlocal + g] = x;
+}
+
+__global__ void host_ghost_scalar_kernel(const int nlocal, const int nghost, const int *__restrict__ owner,
+                                         double *__restrict__ a)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g < nghost) a[nlocal + g] = a[owner[g]];
+}
+
+// Comm::reverse_comm on one periodic rank: what the images collected goes to their owners (several images per owner:
+// atomics; the order of the additions is not fixed, the sum is to the last bit or two)
+__global__ void host_ghost_fold_kernel(const int nlocal, const int nghost, const int w, const int *__restrict__ owner,
+                                       double *__restrict__ a)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nghost) return;
+  const int o = owner[g];
+  double *ag = a + (size_t) w * (nlocal + g);
+  for (int k = 0; k < w; k++)
+    if (ag[k] != 0.0) {
+      atomicAdd(&a[(size_t) w * o + k], ag[k]);
+      ag[k] = 0.0;
+    }
+}
+
 // start of every compute: energy/virial accumulators (+ their slots), the four flag words, the overflow counter.
 // flags[0] (overflow bits of the compute just finished) is folded into the STICKY word flags[4] first: force-only
 // steps of a resident run never read the flags, and a truncated neighbour set must still stop the run at the next
@@ -499,11 +604,36 @@ void mdp_host_add(double *dst, const double *src, size_t n)
   });
 }
 
+// h_dst[0..n) += d_src[0..n) through the pinned buffer h_stage.  Large arrays come down in a few chunks: while the
+// DMA engine drains chunk k+1 the host threads add chunk k into the host's array (a 96 MB download followed by a 96 MB
+// read-modify-write was 3 of the 8.5 ms of a 4 M-atom step).  Returns with all of it added.
+int mdp_host_download_add(mdp_ctx *c, double *h_dst, double *h_stage, const double *d_src, size_t n)
+{
+  hipStream_t st = c->stream;
+  const int nch = n > (1u << 21) ? 8 : 1;
+  const size_t per = ((n + nch - 1) / nch + 7) & ~(size_t) 7;
+  if (!c->ev_down[0])
+    for (int k = 0; k < 8; k++) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_down[k], hipEventDisableTiming));
+  for (int k = 0; k < nch; k++) {
+    const size_t b = (size_t) k * per, e = b + per < n ? b + per : n;
+    if (b >= e) break;
+    MDP_HIP(c, hipMemcpyAsync(h_stage + b, d_src + b, sizeof(double) * (e - b), hipMemcpyDeviceToHost, st));
+    MDP_HIP(c, hipEventRecord(c->ev_down[k], st));
+  }
+  for (int k = 0; k < nch; k++) {
+    const size_t b = (size_t) k * per, e = b + per < n ? b + per : n;
+    if (b >= e) break;
+    MDP_HIP(c, hipEventSynchronize(c->ev_down[k]));
+    mdp_host_add(h_dst + b, h_stage + b, e - b);
+  }
+  return MDP_OK;
+}
+
 // xraw (device [n][3]) (+ device type[]) -> xq.  d_type null: keep the element already in xq.w
-int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type)
+int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type, int count)
 {
   static_assert(sizeof(double4) == 32, "double4 layout");
-  const int n = c->nall;
+  const int n = count >= 0 ? count : c->nall;
   if (n <= 0) return MDP_OK;
   int *d_map = nullptr;
   if (d_type) {
@@ -724,6 +854,10 @@ int mdp_destroy(mdp_ctx *c)
   c->rev.release();
   c->rev16.release();
   c->host_perm.release();
+  c->host_tagmap.release();
+  c->host_inv.release();
+  c->host_tag_dev.release();
+  c->host_img.release();
   c->host_stage.release();
   host_unregister_all(c);
   for (int k = 0; k < 8; k++)
@@ -800,7 +934,7 @@ double mdp_device_bytes(const mdp_ctx *c)
       c->aeam_frho.bytes(), c->aeam_rhor.bytes(), c->aeam_z2r.bytes(), c->aeam_rhor_v4.bytes(),
       c->aeam_rhor_d4.bytes(), c->aeam_z2r_v4.bytes(), c->aeam_z2r_d4.bytes(), c->aeam_pair_d8.bytes(),
       c->aeam_rhor_ys.bytes(), c->aeam_z2r_ys.bytes(), c->aeam_maps.bytes(), c->xq.bytes(), c->xraw.bytes(),
-      c->host_perm.bytes(), c->host_stage.bytes(), c->tag.bytes(), c->type.bytes(), c->f.bytes(),
+      c->host_perm.bytes(), c->host_tagmap.bytes(), c->host_inv.bytes(), c->host_tag_dev.bytes(), c->host_img.bytes(), c->host_stage.bytes(), c->tag.bytes(), c->type.bytes(), c->f.bytes(),
       c->eatom.bytes(), c->vatom.bytes(), c->acc.bytes(), c->flags.bytes(), c->nb_off.bytes(), c->nb.bytes(),
       c->cand_cnt.bytes(), c->cand_off.bytes(), c->cand.bytes(), c->lj_off.bytes(), c->lj_cnt.bytes(),
       c->lj.bytes(), c->cl_flag.bytes(), c->cl_pos.bytes(), c->cl_order.bytes(), c->lj_split.bytes(),
@@ -889,6 +1023,73 @@ int mdp_rebomos_set_params(mdp_ctx *c, const mdp_rebomos_params *p)
   return MDP_OK;
 }
 
+// host mode: are all ghosts periodic images of owned atoms, reproducible from the host's box?  (after host_sort_atoms)
+static int host_derive_ghosts(mdp_ctx *c, const int *h_tag)
+{
+  c->host_ghosts_derived = false;
+  const char *e = getenv("MDP_HOST_GHOSTS"); // "upload": keep taking the ghosts' positions from the host
+  if (c->md || !c->host_box_set || !h_tag || c->nghost <= 0 || c->nlocal <= 0 || (e && !strcmp(e, "upload"))) return MDP_OK;
+  const int nlocal = c->nlocal, nall = c->nall, nghost = c->nghost;
+  int maxtag = 0;
+  for (int i = 0; i < nlocal; i++) maxtag = h_tag[i] > maxtag ? h_tag[i] : maxtag;
+  if (maxtag < 1 || (long long) maxtag > 16ll * nall + (1ll << 20)) return MDP_OK; // no tags / a sparse tag space
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->host_tagmap.reserve((size_t) maxtag + 4));
+  MDP_HIP(c, c->ghost_owner.reserve((size_t) nghost + 1));
+  MDP_HIP(c, c->ghost_shift.reserve((size_t) 3 * nghost + 3));
+  MDP_HIP(c, c->host_img.reserve((size_t) 3 * nghost + 3));
+  MDP_HIP(c, c->host_tag_dev.reserve((size_t) nall + 1));
+  int *flag = c->host_tagmap.p + maxtag + 1;
+  MDP_HIP(c, hipMemsetAsync(c->host_tagmap.p, 0xff, sizeof(int) * ((size_t) maxtag + 1), st));
+  MDP_HIP(c, hipMemsetAsync(flag, 0, sizeof(int), st));
+  host_tagmap_kernel<<<(nlocal + 255) / 256, 256, 0, st>>>(nlocal, c->tag.p, maxtag, c->host_tagmap.p, flag);
+  const int *perm = nullptr, *inv = nullptr;
+  if (c->host_sort) {
+    MDP_HIP(c, c->host_inv.reserve((size_t) nall + 1));
+    host_inv_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->host_perm.p, c->host_inv.p);
+    perm = c->host_perm.p;
+    inv = c->host_inv.p;
+  }
+  const double *h = c->host_h;
+  host_ghost_owner_kernel<<<(nghost + 255) / 256, 256, 0, st>>>(nlocal, nall, perm, inv, c->tag.p, c->type.p, maxtag,
+                                                                c->host_tagmap.p, c->xraw.p, h[0], h[1], h[2], h[3], h[4],
+                                                                h[5], c->ghost_owner.p, c->host_img.p, c->ghost_shift.p,
+                                                                flag);
+  host_tag_dev_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, perm, c->tag.p, c->host_tag_dev.p);
+  MDP_HIP(c, hipGetLastError());
+  int hflag = 1;
+  MDP_TRY(mdp_read_one(c, flag, sizeof(int), &hflag));
+  c->host_ghosts_derived = hflag == 0;
+  return MDP_OK;
+}
+
+// positions of the images from their owners', with the box of this step
+static int host_refresh_ghosts(mdp_ctx *c)
+{
+  const double *h = c->host_h;
+  host_ghost_refresh_kernel<<<(c->nghost + 255) / 256, 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
+                                                                            c->host_img.p, h[0], h[1], h[2], h[3], h[4],
+                                                                            h[5], c->xq.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+extern "C++" int mdp_host_ghost_scalar(mdp_ctx *c, double *d_a)
+{
+  if (!c->host_ghosts_derived || c->nghost <= 0) return MDP_OK;
+  host_ghost_scalar_kernel<<<(c->nghost + 255) / 256, 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p, d_a);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+extern "C++" int mdp_host_ghost_fold(mdp_ctx *c, int w, double *d_a)
+{
+  if (!c->host_ghosts_derived || c->nghost <= 0) return MDP_OK;
+  host_ghost_fold_kernel<<<(c->nghost + 255) / 256, 256, 0, c->stream>>>(c->nlocal, c->nghost, w, c->ghost_owner.p, d_a);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
 // ---- host-mode atoms ----------------------------------------------------------------------------
 int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, const int *type, const int *tag,
                        int ntypes, const int *map)
@@ -920,6 +1121,7 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
   MDP_HIP(c, hipMemcpyAsync(c->type.p + nall, c->map, sizeof(int) * 16, hipMemcpyHostToDevice, st));
   if (tag && nall) MDP_HIP(c, hipMemcpyAsync(c->tag.p, tag, sizeof(int) * nall, hipMemcpyHostToDevice, st));
   c->atoms_set = true;
+  c->host_check_armed = false;
   if (!c->md) { // host mode: bounding box for the device binning, padded so that motion inside the skin stays inside
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int i = 0; i < nall; i++)
@@ -935,6 +1137,7 @@ int mdp_set_atoms_host(mdp_ctx *c, int nlocal, int nghost, const double *x, cons
   }
   MDP_TRY(host_sort_atoms(c));
   MDP_TRY(mdp_pack_xq(c, c->xraw.p, c->type.p));
+  MDP_TRY(host_derive_ghosts(c, tag));
   MDP_HIP(c, hipStreamSynchronize(st)); // host buffers may change after return
   c->neigh_set = false;
   c->rebo_packed = false;
@@ -948,11 +1151,34 @@ int mdp_set_positions_host(mdp_ctx *c, const double *x)
   if (c->nall == 0) return MDP_OK; // empty sub-domain: nothing to move (x may be NULL)
   if (!x) return mdp_fail(c, MDP_EINVAL, "mdp_set_positions_host: x missing for %d atoms", c->nall);
   MDP_HIP(c, hipSetDevice(c->device));
-  MDP_TRY(host_upload(c, c->xraw.p, x, sizeof(double) * 3 * c->nall));
-  MDP_TRY(mdp_pack_xq(c, c->xraw.p, nullptr));
+  if (c->host_ghosts_derived) { // owned atoms only; the images follow their owners on the device
+    MDP_TRY(host_upload(c, c->xraw.p, x, sizeof(double) * 3 * c->nlocal));
+    MDP_TRY(mdp_pack_xq(c, c->xraw.p, nullptr, c->nlocal));
+    MDP_TRY(host_refresh_ghosts(c));
+  } else {
+    MDP_TRY(host_upload(c, c->xraw.p, x, sizeof(double) * 3 * c->nall));
+    MDP_TRY(mdp_pack_xq(c, c->xraw.p, nullptr));
+  }
+  MDP_TRY(mdp_rebomos_host_precheck(c));
   MDP_HIP(c, hipStreamSynchronize(c->stream));
   return MDP_OK;
 }
+
+int mdp_set_box_host(mdp_ctx *c, const double *h)
+{
+  if (!c) return MDP_EINVAL;
+  if (!h) { // back to "ghost positions come from the host"
+    c->host_box_set = false;
+    c->host_ghosts_derived = false;
+    return MDP_OK;
+  }
+  if (!(h[0] > 0.0 && h[1] > 0.0 && h[2] > 0.0)) return mdp_fail(c, MDP_EINVAL, "mdp_set_box_host: box lengths must be positive");
+  for (int k = 0; k < 6; k++) c->host_h[k] = h[k];
+  c->host_box_set = true;
+  return MDP_OK;
+}
+
+int mdp_host_ghosts_derived(mdp_ctx *c) { return c && c->host_ghosts_derived ? 1 : 0; }
 
 static int upload_csr(mdp_ctx *c, double skin)
 {
@@ -1105,32 +1331,13 @@ int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double
   }
   MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nlocal + 16));
   double *hf = c->h_down, *he = hf + (size_t) 3 * nlocal, *hv = he + nlocal;
-  // forces come down in a few chunks: while the DMA engine drains chunk k+1 the host threads add chunk k into the
-  // host's array (a 96 MB download followed by a 96 MB read-modify-write was 3 of the 8.5 ms of a 4 M-atom step)
   const size_t n3 = (size_t) 3 * nlocal;
-  const int nch = n3 > (1u << 21) ? 8 : 1;
-  const size_t per = ((n3 + nch - 1) / nch + 7) & ~(size_t) 7;
-  if (nch > 1 && !c->ev_down[0])
-    for (int k = 0; k < 8; k++) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_down[k], hipEventDisableTiming));
-  for (int k = 0; k < nch; k++) {
-    const size_t b = (size_t) k * per, e = b + per < n3 ? b + per : n3;
-    if (b >= e) break;
-    MDP_HIP(c, hipMemcpyAsync(hf + b, df + b, sizeof(double) * (e - b), hipMemcpyDeviceToHost, st));
-    if (nch > 1) MDP_HIP(c, hipEventRecord(c->ev_down[k], st));
-  }
   if (eflag & MDP_EFLAG_ATOM) MDP_HIP(c, hipMemcpyAsync(he, de, sizeof(double) * nlocal, hipMemcpyDeviceToHost, st));
   if (vflag & MDP_VFLAG_ATOM)
     MDP_HIP(c, hipMemcpyAsync(hv, dv, sizeof(double) * 6 * nlocal, hipMemcpyDeviceToHost, st));
-  if (nch > 1)
-    for (int k = 0; k < nch; k++) {
-      const size_t b = (size_t) k * per, e = b + per < n3 ? b + per : n3;
-      if (b >= e) break;
-      MDP_HIP(c, hipEventSynchronize(c->ev_down[k]));
-      mdp_host_add(f + b, hf + b, e - b);
-    }
+  MDP_TRY(mdp_host_download_add(c, f, hf, df, n3));
   MDP_TRY(fetch_acc(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr));
   if (vflag & MDP_VFLAG_ATOM) mdp_host_add(vatom, hv, (size_t) 6 * nlocal);
-  if (nch == 1) mdp_host_add(f, hf, n3);
   if (eflag & MDP_EFLAG_ATOM) mdp_host_add(eatom, he, (size_t) nlocal);
   return MDP_OK;
 }

@@ -245,6 +245,14 @@ struct mdp_ctx {
   bool host_sort = false;       // host mode, rebomos: device storage order = Hilbert order (host_perm: device -> host index)
   DevBuf<int> host_perm;
   DevBuf<double> host_stage;    // per-atom results back in host order before the download
+  // host mode on one periodic rank: every ghost is an image of an owned atom.  Once the host has handed over its box
+  // (mdp_set_box_host), owner (device order, in ghost_owner) and image counts (as doubles, in ghost_shift) are derived
+  // from tags and positions at mdp_set_atoms_host, and the per-step upload carries the owned atoms only.
+  bool host_box_set = false, host_ghosts_derived = false;
+  bool host_check_armed = false; // rebomos host mode: the displacement check ran behind the last position upload
+  double host_h[6] = {1, 1, 1, 0, 0, 0}; // xprd, yprd, zprd, yz, xz, xy (Domain::h)
+  DevBuf<int> host_tagmap, host_inv, host_tag_dev; // tag -> owned host index; host -> device index; tags in device order
+  DevBuf<double> host_img;                         // [nghost][3] image counts (ghost_shift: the Cartesian shift at the list build)
   std::vector<std::pair<const void *, size_t>> host_regs; // host arrays page-locked in place (large x arrays)
   char *h_up[2] = {nullptr, nullptr};          // pinned upload staging (double-buffered chunks)
   hipEvent_t ev_up[2] = {nullptr, nullptr};
@@ -428,7 +436,10 @@ int mdp_write_small(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes); /
   } while (0)
 
 // modules
-int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null); // xraw/type -> xq
+int mdp_pack_xq(mdp_ctx *c, const double *d_x3, const int *d_type_or_null, int count = -1); // xraw/type -> xq (first `count` atoms; -1: all)
+int mdp_rebomos_host_precheck(mdp_ctx *c);                 // host mode: displacement check behind the position upload
+int mdp_host_ghost_scalar(mdp_ctx *c, double *d_a);        // host mode, derived images: a[image] = a[owner]
+int mdp_host_ghost_fold(mdp_ctx *c, int w, double *d_a);   // a[owner] += a[image], a[image] = 0 (w doubles per atom)
 int mdp_scan_exclusive_int(mdp_ctx *c, const int *d_in, int *d_out, int n);  // d_out[n] = total (n+1 entries)
 int mdp_chunk_by_element(mdp_ctx *c, int n, int n_owned, const int *d_idx_in, int *d_idx_out, const double4 *d_xq,
                          const int *d_type, const int *d_map); // element-sorted runs of 32 owned atoms (stable)
@@ -456,6 +467,7 @@ void mdp_span_end(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
 int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq); // integrate kernel (+ displacement check)
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
+int mdp_host_download_add(mdp_ctx *c, double *h_dst, double *h_stage, const double *d_src, size_t n); // chunked D2H + add
 int mdp_to_host_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst);   // per-atom arrays, device -> host order
 int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d_dst); // host -> device order
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)

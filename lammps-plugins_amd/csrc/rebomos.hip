@@ -2721,6 +2721,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
 {
   if (!c->have_rebomos) return mdp_fail(c, MDP_ESTATE, "rebomos parameters not set");
   if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  c->host_check_armed = false;
   double s_in = c->skin > 0.0 ? c->skin : 2.0;
   {
     // Inner skin (A): starts at 1.0 and ADAPTS -- when the displacement trigger fires again within 200 computes
@@ -2793,8 +2794,13 @@ int mdp_rebomos_repack(mdp_ctx *c)
   // own, the gather of their owned neighbours reads the owner centre's slots instead (rev_kernel).  MDP_IMAGE_CENTRES=1
   // computes them as before (A/B switch).
   static const bool image_centres = getenv("MDP_IMAGE_CENTRES") && atoi(getenv("MDP_IMAGE_CENTRES")) != 0;
-  const int self_end = (c->md && !image_centres && c->ghost_owner.p && c->tag.p && c->remote_start > nlocal)
+  // Host mode knows the same once the library keeps the images itself (mdp_set_box_host): every ghost is one.
+  const bool host_images = !c->md && c->host_ghosts_derived && c->ghost_owner.p && c->host_tag_dev.p;
+  const int self_end = image_centres ? nlocal
+                       : host_images ? nall
+                       : (c->md && c->ghost_owner.p && c->tag.p && c->remote_start > nlocal)
                            ? (c->remote_start < nall ? c->remote_start : nall) : nlocal;
+  const int *tag_dev = host_images ? c->host_tag_dev.p : c->tag.p; // tags in the device's atom order
   const int per_block = 256 / RP_L;
   const int nghost = nall - nlocal;
   if (nlocal)
@@ -2952,7 +2958,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, hipGetLastError());
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
-                                                                     c->rev16.p, c->flags.p, self_end, c->xq.p, c->tag.p,
+                                                                     c->rev16.p, c->flags.p, self_end, c->xq.p, tag_dev,
                                                                      c->ghost_owner.p, c->ghost_shift.p);
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
@@ -3106,11 +3112,28 @@ static int rebomos_check_launch(mdp_ctx *c, const double trig)
   return MDP_OK;
 }
 
+// host mode: the displacement check of the compute that follows, launched where the stream is waited for anyway
+// (mdp_set_positions_host) instead of with a wait of its own
+int mdp_rebomos_host_precheck(mdp_ctx *c)
+{
+  c->host_check_armed = false;
+  if (c->md || !c->have_rebomos || c->have_aeam || !c->rebo_packed || !c->nall) return MDP_OK;
+  MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
+  c->host_check_armed = true;
+  return MDP_OK;
+}
+
 static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
 {
   stale = false;
   if (!c->nall) return MDP_OK;
   int *h = (int *) (c->h_pinned + 24);
+  if (!c->md && c->host_check_armed) { // host mode: launched behind the upload, which has waited for it already
+    c->host_check_armed = false;
+    stale = h[0] != 0;
+    if (c->prune_valid && h[2]) c->prune_stale = true;
+    return MDP_OK;
+  }
   if (!c->md || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
     c->sflag_pending = false; // (words of a check armed before the positions were rewritten)
     c->check_now = false;

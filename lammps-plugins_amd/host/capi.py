@@ -50,6 +50,7 @@ EXPORTS = [
     "mdp_abi_version", "mdp_device_count", "mdp_create", "mdp_destroy", "mdp_last_error", "mdp_set_stream",
     "mdp_sync", "mdp_rebomos_set_params", "mdp_rebomos_read_file", "mdp_rebomos_params_from_scalars",
     "mdp_aeam_set_tables", "mdp_aeam_file_read", "mdp_aeam_file_info", "mdp_aeam_file_build", "mdp_aeam_file_free", "mdp_set_atoms_host", "mdp_set_positions_host",
+    "mdp_set_box_host", "mdp_host_ghosts_derived",
     "mdp_set_neighbors_host", "mdp_set_skin", "mdp_set_neighbors_csr_host", "mdp_rebomos_compute_host", "mdp_aeam_density_host",
     "mdp_aeam_force_host", "mdp_md_setup", "mdp_md_build_neighbors", "mdp_md_initial_integrate",
     "mdp_md_final_integrate", "mdp_md_final_initial_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
@@ -238,6 +239,18 @@ class Context:
         x_all = np.ascontiguousarray(x_all, dtype=np.float64)
         self._ck(self.L.mdp_set_positions_host(self.h, _dp(x_all)))
 
+    def set_box_host(self, box):
+        """Domain::h of the host's box (xprd, yprd, zprd, yz, xz, xy); None withdraws it"""
+        if box is None:
+            self._ck(self.L.mdp_set_box_host(self.h, None))
+            return
+        xy, xz, yz = box.tilt
+        h = np.array([box.prd[0], box.prd[1], box.prd[2], yz, xz, xy], dtype=np.float64)
+        self._ck(self.L.mdp_set_box_host(self.h, _dp(h)))
+
+    def host_ghosts_derived(self):
+        return bool(self.L.mdp_host_ghosts_derived(self.h))
+
     def set_neighbors_csr_host(self, numneigh, offset, neigh, skin):
         numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
         offset = np.ascontiguousarray(offset, dtype=np.int64)
@@ -294,16 +307,17 @@ class Context:
                                                  _dp(vir), _dp(eatom), _dp(vatom)))
         return dict(f=f, eng=eng.value, virial=vir, eatom=eatom, vatom=vatom)
 
-    def aeam_density_host(self, nlocal, eflag=3):
-        fp = np.zeros(nlocal)
-        rho = np.zeros(nlocal)
+    def aeam_density_host(self, nlocal, eflag=3, keep_fp=False):
+        """keep_fp: fp (and rho) stay on the device (needs host_ghosts_derived())"""
+        fp = None if keep_fp else np.zeros(nlocal)
+        rho = None if keep_fp else np.zeros(nlocal)
         eng = C.c_double(0.0)
         eatom = np.zeros(nlocal)
         self._ck(self.L.mdp_aeam_density_host(self.h, C.c_int(eflag), _dp(fp), _dp(rho), C.byref(eng), _dp(eatom)))
         return dict(fp=fp, rho=rho, eng=eng.value, eatom=eatom)
 
     def aeam_force_host(self, nall, nlocal, fp_all, eflag=3, vflag=1):
-        fp_all = np.ascontiguousarray(fp_all, dtype=np.float64)
+        fp_all = None if fp_all is None else np.ascontiguousarray(fp_all, dtype=np.float64)
         f = np.zeros((nall, 3))
         eng = C.c_double(0.0)
         vir = np.zeros(6)

@@ -39,6 +39,7 @@ class Memory;
 class Error;
 class Atom;
 class Comm;
+class Domain;
 class Force;
 class Neighbor;
 class NeighList;
@@ -103,6 +104,15 @@ class Atom {
   void set_mass(const char *file, int line, int itype, double value);
 };
 
+class Domain { // the members of LAMMPS' Domain the adapters read (box of this step)
+ public:
+  int triclinic = 0;
+  int xperiodic = 1, yperiodic = 1, zperiodic = 1;
+  double xprd = 1.0, yprd = 1.0, zprd = 1.0, xy = 0.0, xz = 0.0, yz = 0.0;
+  double boxlo[3] = {0, 0, 0}, boxhi[3] = {1, 1, 1};
+  double h[6] = {1, 1, 1, 0, 0, 0}; // xprd, yprd, zprd, yz, xz, xy
+};
+
 class Comm {
  public:
   int me = 0, nprocs = 1, nthreads = 1;
@@ -144,6 +154,7 @@ class LAMMPS {
   Error *error = nullptr;
   Atom *atom = nullptr;
   Comm *comm = nullptr;
+  Domain *domain = nullptr;
   Force *force = nullptr;
   Neighbor *neighbor = nullptr;
   MPI_Comm world = 0;
@@ -152,7 +163,7 @@ class LAMMPS {
 class Pointers {
  public:
   explicit Pointers(LAMMPS *ptr) :
-      lmp(ptr), memory(ptr->memory), error(ptr->error), atom(ptr->atom), comm(ptr->comm), force(ptr->force),
+      lmp(ptr), memory(ptr->memory), error(ptr->error), atom(ptr->atom), comm(ptr->comm), domain(ptr->domain), force(ptr->force),
       neighbor(ptr->neighbor), world(ptr->world)
   {
   }
@@ -164,6 +175,7 @@ class Pointers {
   Error *&error;
   Atom *&atom;
   Comm *&comm;
+  Domain *&domain;
   Force *&force;
   Neighbor *&neighbor;
   MPI_Comm &world;

@@ -176,6 +176,7 @@ struct Host {
   Neighbor neighbor;
   NeighList list;
   PeriodicComm comm;
+  Domain domain;
   Pair *pair = nullptr;
 
   // registry of plugin styles
@@ -222,6 +223,7 @@ struct Host {
     lmp.error = &error;
     lmp.atom = &atom;
     lmp.comm = &comm;
+    lmp.domain = &domain;
     lmp.force = &force;
     lmp.neighbor = &neighbor;
     comm.h = this;
@@ -567,8 +569,22 @@ struct Host {
   // ---------------------------------------------------------------- Verlet
   void force_clear() { std::fill(fs.begin(), fs.end(), 0.0); }
 
+  void sync_domain() // Domain::set_global_box
+  {
+    domain.xprd = prd[0]; domain.yprd = prd[1]; domain.zprd = prd[2];
+    domain.xy = tilt[0]; domain.xz = tilt[1]; domain.yz = tilt[2];
+    domain.triclinic = tilt[0] != 0.0 || tilt[1] != 0.0 || tilt[2] != 0.0;
+    for (int d = 0; d < 3; d++) {
+      domain.boxlo[d] = boxlo[d];
+      domain.boxhi[d] = boxlo[d] + prd[d];
+      domain.h[d] = prd[d];
+    }
+    domain.h[3] = tilt[2]; domain.h[4] = tilt[1]; domain.h[5] = tilt[0];
+  }
+
   void compute_forces(int eflag, int vflag)
   {
+    sync_domain();
     force_clear();
     pair->compute(eflag, vflag);
     fold_ghost_forces();

@@ -15,6 +15,7 @@
 
 #include "atom.h"
 #include "comm.h"
+#include "domain.h"
 #include "error.h"
 #include "force.h"
 #include "memory.h"
@@ -209,6 +210,10 @@ void PairAEAM::compute(int eflag, int vflag)
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   int rc;
+  // the box of this step: on one periodic rank the library keeps the images itself (positions, fp, their share of the
+  // three-body forces), as Comm::forward_comm / reverse_comm would
+  rc = mdp_set_box_host(dev, comm->nprocs == 1 ? domain->h : nullptr);
+  if (rc != MDP_OK) fail_one(rc, "box");
   if (neighbor->ago == 0 || nall != nall_uploaded) {
     rc = mdp_set_atoms_host(dev, nlocal, atom->nghost, nall ? atom->x[0] : nullptr, atom->type, atom->tag,
                             atom->ntypes, nullptr);
@@ -233,14 +238,16 @@ void PairAEAM::compute(int eflag, int vflag)
   const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
   const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0) | (vflag_atom ? MDP_VFLAG_ATOM : 0);
 
-  // passes 1+2 on the device; fp (owned) comes back for the halo
-  rc = mdp_aeam_density_host(dev, ef, fp, rho, &eng_vdwl, eatom);
+  // passes 1+2 on the device; fp (owned) comes back for the halo -- unless every ghost is an image the library keeps
+  // itself: then rho and fp (private to this class, as in the reference) never leave the device
+  const bool local_halo = mdp_host_ghosts_derived(dev) == 1;
+  rc = mdp_aeam_density_host(dev, ef, local_halo ? nullptr : fp, local_halo ? nullptr : rho, &eng_vdwl, eatom);
   if (rc != MDP_OK) fail_one(rc, "density pass");
 
   // communicate the derivative of the embedding function (pair_aeam.cpp:307)
-  comm->forward_comm(this);
+  if (!local_halo) comm->forward_comm(this);
 
-  rc = mdp_aeam_force_host(dev, ef, vf, fp, nall ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
+  rc = mdp_aeam_force_host(dev, ef, vf, local_halo ? nullptr : fp, nall ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
                            (vflag_atom && vatom) ? vatom[0] : nullptr);
   if (rc != MDP_OK) fail_one(rc, "force pass");
 }

@@ -18,6 +18,7 @@
 
 #include "atom.h"
 #include "comm.h"
+#include "domain.h"
 #include "error.h"
 #include "force.h"
 #include "memory.h"
@@ -174,6 +175,10 @@ void PairREBOMoS::compute(int eflag, int vflag)
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   int rc;
+  // the box of this step: on one periodic rank the library gives the images their positions itself, as
+  // Comm::forward_comm does (owner + whole box vectors), and takes the owned atoms' positions only
+  rc = mdp_set_box_host(dev, comm->nprocs == 1 ? domain->h : nullptr);
+  if (rc != MDP_OK) fail_one(rc, "box");
   if (neighbor->ago == 0 || nall != nall_uploaded) {
     // the host rebuilt its list this step: atoms may have migrated / been re-sorted
     rc = mdp_set_atoms_host(dev, nlocal, atom->nghost, nall ? atom->x[0] : nullptr, atom->type, atom->tag,
