@@ -213,6 +213,8 @@ struct MdpDomain {
   DevBuf<int> cnt_dev;
 };
 
+constexpr int MDP_UP_RING = 2;      // host-mode upload: pinned staging chunks in flight
+constexpr int MDP_DOWN_CHUNKS = 8;  // host-mode download: pieces of the force array
 struct mdp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -254,9 +256,9 @@ struct mdp_ctx {
   DevBuf<int> host_tagmap, host_inv, host_tag_dev; // tag -> owned host index; host -> device index; tags in device order
   DevBuf<double> host_img;                         // [nghost][3] image counts (ghost_shift: the Cartesian shift at the list build)
   std::vector<std::pair<const void *, size_t>> host_regs; // host arrays page-locked in place (large x arrays)
-  char *h_up[2] = {nullptr, nullptr};          // pinned upload staging (double-buffered chunks)
-  hipEvent_t ev_up[2] = {nullptr, nullptr};
-  hipEvent_t ev_down[8] = {};                  // chunked force download (host mode)
+  char *h_up[MDP_UP_RING] = {};                // pinned upload staging (a ring of chunks)
+  hipEvent_t ev_up[MDP_UP_RING] = {};
+  hipEvent_t ev_down[MDP_DOWN_CHUNKS] = {};    // chunked force download (host mode)
   double *h_down = nullptr;     // pinned download buffer
   size_t h_down_cap = 0;
   DevBuf<int> tag, type;
