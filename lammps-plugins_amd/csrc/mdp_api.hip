@@ -570,10 +570,14 @@ static int host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes)
       MDP_HIP(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
     }
   }
+  // about eight pieces per array, 2 to 16 MB each: what is copied before the DMA engine has work is an eighth of the
+  // array, and a 24 MB array (1 M atoms) is not two pieces that barely overlap
+  size_t piece = ((bytes / 8 + (1u << 20) - 1) >> 20) << 20;
+  piece = piece < (2u << 20) ? (2u << 20) : (piece > kChunk ? kChunk : piece);
   int k = 0;
-  for (size_t off = 0; off < bytes; off += kChunk, k = (k + 1) % MDP_UP_RING) {
-    const size_t n = bytes - off < kChunk ? bytes - off : kChunk;
-    if (off >= MDP_UP_RING * kChunk) MDP_HIP(c, hipEventSynchronize(c->ev_up[k])); // the DMA out of this buffer has finished
+  for (size_t off = 0; off < bytes; off += piece, k = (k + 1) % MDP_UP_RING) {
+    const size_t n = bytes - off < piece ? bytes - off : piece;
+    if (off >= MDP_UP_RING * piece) MDP_HIP(c, hipEventSynchronize(c->ev_up[k])); // the DMA out of this buffer has finished
     host_copy_threads(c->h_up[k], (const char *) h_src + off, n);
     MDP_HIP(c, hipMemcpyAsync((char *) d_dst + off, c->h_up[k], n, hipMemcpyHostToDevice, st));
     MDP_HIP(c, hipEventRecord(c->ev_up[k], st));
