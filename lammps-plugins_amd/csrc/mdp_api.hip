@@ -570,10 +570,13 @@ static int host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes)
       MDP_HIP(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
     }
   }
-  // about eight pieces per array, 2 to 16 MB each: what is copied before the DMA engine has work is an eighth of the
-  // array, and a 24 MB array (1 M atoms) is not two pieces that barely overlap
-  size_t piece = ((bytes / 8 + (1u << 20) - 1) >> 20) << 20;
-  piece = piece < (2u << 20) ? (2u << 20) : (piece > kChunk ? kChunk : piece);
+  // arrays below 64 MB go in about eight pieces of at least 2 MB, so that a 24 MB array (1 M atoms) is not two pieces
+  // that barely overlap (0.82 -> 0.70 ms); large arrays in 16 MB pieces (measured above)
+  size_t piece = kChunk;
+  if (bytes < (64u << 20)) {
+    piece = ((bytes / 8 + (1u << 20) - 1) >> 20) << 20;
+    piece = piece < (2u << 20) ? (2u << 20) : (piece > kChunk ? kChunk : piece);
+  }
   int k = 0;
   for (size_t off = 0; off < bytes; off += piece, k = (k + 1) % MDP_UP_RING) {
     const size_t n = bytes - off < piece ? bytes - off : piece;
