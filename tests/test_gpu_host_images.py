@@ -169,3 +169,56 @@ def test_aeam_fp_and_image_forces_stay_on_the_device(oracle, ncell, frac, device
     r = ctx.aeam_force_host(nall, n, np.concatenate([d["fp"], d["fp"][eng.owner]]), eflag=0, vflag=0)
     assert np.abs(r["f"][:n] - eng.compute(x2)["f_owned"]).max() < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_kept_and_uploaded_images_agree_at_scale(style):
+    """a few hundred thousand atoms (many tiles, Hilbert-sorted device order, images across all three box vectors): the
+    same displaced positions through a context that keeps the images and one that takes them from the host"""
+    rng = np.random.default_rng(11)
+    if style == "rebomos":
+        s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (10, 10, 10)), 0.02, seed=12)     # 288 k atoms
+        p = capi.read_rebomos_file(POT_REBOMOS)
+        cut, skin, map_ = 3.0 * p.rcmax[0][0] + 2.0, 2.0, [0, 0, 1]
+    else:
+        s = S.jitter(S.fcc_cell(4.045, 40, frac_type2=0.0075, seed=13), 0.05, seed=14)    # 256 k atoms
+        af = capi.AeamFile(POT_AEAM)
+        tabs = af.build()
+        cut, skin, map_ = float(af.cut_table(tabs).max()) + 1.0, 1.0, None
+    xa, ta, ga, owner, shift, n, ng = S.with_ghosts(s, cut)
+    nall = n + ng
+    out = []
+    for box in (s.box, None):
+        ctx = capi.Context(0)
+        if style == "rebomos":
+            ctx.rebomos_set_params(p)
+        else:
+            ctx.aeam_set_tables(tabs)
+            ctx.aeam_device_lists(True)
+        ctx.set_box_host(box)
+        ctx.set_atoms_host(n, xa, ta, ga, 2, map_=map_)
+        assert ctx.host_ghosts_derived() == (box is not None)
+        ctx.set_skin(skin)
+        disp = np.zeros_like(xa)
+        rng2 = np.random.default_rng(15)
+        f = None
+        for step in range(3):
+            if step:
+                disp[:n] += 0.03 * rng2.standard_normal((n, 3))
+                disp[n:] = disp[owner]
+                xnew = xa + disp
+                ctx.set_positions_host(_poison_ghosts(xnew, n) if box is not None else xnew)
+            if style == "rebomos":
+                f = ctx.rebomos_compute_host(n, eflag=0, vflag=0)["f"]
+            else:
+                keep = box is not None
+                d = ctx.aeam_density_host(n, eflag=0, keep_fp=keep)
+                fp_all = None if keep else np.concatenate([d["fp"], d["fp"][owner]])
+                r = ctx.aeam_force_host(nall, n, fp_all, eflag=0, vflag=0)
+                f = r["f"][:n].copy()
+                if not keep:
+                    np.add.at(f, owner, r["f"][n:])
+        out.append(f)
+        ctx.close()
+    assert np.abs(out[0]).max() > 0.1
+    assert np.abs(out[0] - out[1]).max() < 1e-10
