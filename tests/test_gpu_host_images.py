@@ -222,3 +222,13 @@ def test_kept_and_uploaded_images_agree_at_scale(style):
         ctx.close()
     assert np.abs(out[0]).max() > 0.1
     assert np.abs(out[0] - out[1]).max() < 1e-10
+
+
+def test_box_arguments(rctx):
+    """a box with a non-positive length is refused; NULL withdraws the box and with it the derived images"""
+    h = np.array([10.0, 0.0, 10.0, 0.0, 0.0, 0.0])
+    assert rctx.L.mdp_set_box_host(rctx.h, capi._dp(h)) != 0
+    assert "positive" in rctx.L.mdp_last_error(rctx.h).decode()
+    assert rctx.L.mdp_set_box_host(rctx.h, None) == 0
+    assert not rctx.host_ghosts_derived()
+    assert rctx.L.mdp_host_ghosts_derived(None) == 0
