@@ -2483,7 +2483,7 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
                                                   int *__restrict__ rev16, int *__restrict__ flags,
                                                   const int self_end, const double4 *__restrict__ xq,
                                                   const int *__restrict__ tag, const int *__restrict__ ghost_owner,
-                                                  const double *__restrict__ ghost_shift)
+                                                  const RebomosDev P)
 {
   const int s = threadIdx.x % RP_L;
   const long long a64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
@@ -2496,9 +2496,10 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
     int r = -1;
     if (j >= nlocal && j < self_end) { // a periodic image: its owner's slot of MY image
       const int o = ghost_owner[j - nlocal];
-      const double *sh = ghost_shift + 3 * (size_t) (j - nlocal);
-      const double4 xa = xq[a];
-      const double px = xa.x - sh[0], py = xa.y - sh[1], pz = xa.z - sh[2];
+      // the image's shift as it is NOW (x_j - x_o): the box may have changed since the images were derived (fix npt /
+      // deform refresh them at owner + count * h of the step), a shift stored then would miss a' by count * dh
+      const double4 xa = xq[a], xj = xq[j], xo = xq[o];
+      const double px = xa.x - (xj.x - xo.x), py = xa.y - (xj.y - xo.y), pz = xa.z - (xj.z - xo.z);
       const int ta = tag[a];
       const int oo = cand_off[o], no = cand_off[o + 1] - oo;
       for (int u = 0; u < no; u++) {
@@ -2510,6 +2511,14 @@ __global__ __launch_bounds__(256) void rev_kernel(const int nlocal, const int *_
           r = oo + u;
           break;
         }
+      }
+      if (r < 0) { // only a pair at the outer edge of the list skin may lack its mirror (see above): anything that can
+                   // come inside rcmax before the next list build (half the inner skin of motion on either side) must not
+        const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
+        const int pt = 2 * (int) xa.w + (int) xj.w;
+        const double rskin = sqrt(P.cand_cutsq[pt]) - sqrt(P.rcmaxsq[pt]);
+        const double rlim = sqrt(P.rcmaxsq[pt]) + 0.5 * rskin;
+        if (dx * dx + dy * dy + dz * dz < rlim * rlim) atomicOr(&flags[2], 1);
       }
     } else {
       const int oj = cand_off[j], nj = cand_off[j + 1] - oj;
@@ -2959,7 +2968,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   if (nlocal)
     rev_kernel<<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(nlocal, c->cand_off.p, c->cand.p, c->rev.p,
                                                                      c->rev16.p, c->flags.p, self_end, c->xq.p, tag_dev,
-                                                                     c->ghost_owner.p, c->ghost_shift.p);
+                                                                     c->ghost_owner.p, c->rebomos);
   if (nall) hold_all_kernel<<<(nall + 255) / 256, 256, 0, st>>>(nall, c->xq.p, c->xhold_all.p);
   MDP_HIP(c, hipGetLastError());
   int hflags[4] = {0, 0, 0, 0};
@@ -2967,6 +2976,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
     const MdpRead rd[2] = {{c->class_count.p, sizeof(int) * MDP_NCLASS, c->h_class_count}, {c->flags.p, sizeof(int) * 4, hflags}};
     MDP_TRY(mdp_read_small(c, rd, 2));
   }
+  if (hflags[2])
+    return mdp_fail(c, MDP_ESTATE, "rebomos: a periodic image within rcmax + half the inner skin of an owned atom has no mirror "
+                                   "slot in its owner's row (images inconsistent with the owned atoms' positions)");
   if (hflags[1]) {
     if (getenv("MDP_DIAG")) repack_diag(c);
     // A candidate row holds the atoms within rcmax + inner skin and the active mask has 64 bits.  Rows that

@@ -204,6 +204,10 @@ class DeviceDomain:
         self.nghost = self.nself + self.nrecv
         self.builds += 1
         self.fresh_ghosts = True
+        # Whether a step exchanges anything is decided for ALL ranks alike, once per reneighboring: every exchange is a
+        # collective over the whole group, so a rank without neighbours of its own (a brick facing vacuum across
+        # non-periodic faces) takes part with empty messages as long as any rank has a halo.
+        self.halo_active = tr.any(bool(self.nsend or self.nrecv)) if tr is not None else False
         if self.style == capi.STYLE_AEAM and tr is not None:
             # ghost forces are non-zero only when some rank has an angular centre next to a remote ghost: the reverse
             # exchange is skipped by all ranks alike otherwise (decided once per reneighboring)
@@ -215,7 +219,7 @@ class DeviceDomain:
 
     # ------------------------------------------------------------------ halo
     def _active(self):
-        return self.tr is not None and (self.nsend or self.nrecv)
+        return self.tr is not None and self.halo_active
 
     def forward_positions(self, async_op=False):
         if self.native:
@@ -238,12 +242,17 @@ class DeviceDomain:
         self.tr.exchange(self.send1, self.send_counts, self.recv_counts, 1, recv=self.recv1)
         self.ctx.dd_forward_scalar_unpack(self.recv1.data_ptr())
 
-    def reverse_forces(self):
+    def reverse_forces(self, remote=True):
+        """ghost forces back to their owners.  remote=False: only the rank's own periodic images are folded -- the
+        caller knows (collectively, `ghost_forces`) that no rank put a force on a remote ghost."""
         if self.native:
-            self.ctx.dd_comm_reverse()            # folds the self-images too
+            if remote:
+                self.ctx.dd_comm_reverse()        # folds the self-images too
+            else:
+                self.ctx.md_fold_self_ghost_f()
             return
         self.ctx.md_fold_self_ghost_f()
-        if not self._active():
+        if not remote or not self._active():
             return
         self.ctx.dd_reverse_pack(self.recv3.data_ptr())
         self.tr.exchange(self.recv3, self.recv_counts, self.send_counts, 3, recv=self.send3)
@@ -283,12 +292,15 @@ class DeviceDomain:
                     work.wait()
                 ctx.dd_forward_unpack(self.recv3.data_ptr())
         ctx.md_aeam_density(eflag)                               # B: the rest of passes 1 + 2 (+ three-body forces)
+        rev = self.ghost_forces
         if not ctx.md_aeam_state()["phase"] & 4:                 # phase A did not run (pruning due, CSR lists, ...)
+            # That is THIS rank's business (its own rows are due for pruning): the peers may be on the phased order in
+            # the same step, so the exchanges issued here are exactly theirs, in their order -- fp forward, then the
+            # ghost forces back iff `ghost_forces` says any rank has some (decided collectively per reneighboring).
             self.forward_fp()
             ctx.md_aeam_force(eflag, vflag)
-            self.reverse_forces()
+            self.reverse_forces(remote=rev)
             return
-        rev = self.ghost_forces
         self.aeam_overlapped += 1
         if self.native:
             ctx.dd_comm_aeam_exchange_begin(rev)                 # fp out, ghost forces back: one group of sends
@@ -393,7 +405,8 @@ class ThreadTransport:
         def __init__(self, world):
             import threading
             self.world = world
-            self.barrier = threading.Barrier(world)
+            # (a timeout: ranks whose exchange schedules diverge fail the test with BrokenBarrierError instead of hanging)
+            self.barrier = threading.Barrier(world, timeout=float(_os.environ.get("MDP_THREAD_BARRIER_TIMEOUT", "180")))
             self.slots = [None] * world
 
     def __init__(self, shared: "ThreadTransport.Shared", rank: int, ctx: capi.Context, device):

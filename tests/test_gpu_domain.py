@@ -253,6 +253,31 @@ def test_aeam_exchanges_behind_the_interior_tiles(oracle, world, temp, drift):
     assert np.allclose(many["th"]["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_aeam_pure_metal_bricks_keep_one_exchange_schedule(world):
+    """No angular atom anywhere: nothing is ever put on a remote ghost and the reverse exchange is skipped by all ranks
+    (`ghost_forces` false).  A rank whose rows are due for pruning takes the blocking order for that step while its
+    peers stay on the phased one -- a rank-local decision -- and must still issue exactly the peers' exchanges (fp
+    forward, nothing back), or the collectives of the ranks pair up wrongly.  Hot, drifting run with prunings."""
+    s = S.jitter(S.fcc_cell(4.045, 16, frac_type2=0.0, seed=21), 0.05, seed=22)
+    s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+    v0 = S.gaussian_velocities(s, 863.0, seed=23) + np.array([40.0, 25.0, -30.0])
+    steps, every = 36, 12
+    one = _run(1, s, v0, steps, every, style=capi.STYLE_AEAM)
+    many = _run(world, s, v0, steps, every, style=capi.STYLE_AEAM, defer=True)
+    for r in many["ranks"]:
+        assert not r["aeam"]["ghost_forces"]
+        assert r["prunes"]["prunings"] > 1                   # prunings between the reneighborings: blocking steps ...
+        assert 0 < r["overlapped"] < steps                   # ... among phased ones
+    assert many["left"] > 20
+    dx = many["x"] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(many["f"] - one["f"]).max() < 1e-7
+    assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+    assert np.allclose(many["th"]["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
+
+
 def test_aeam_phases_on_one_rank_with_every_image_remote(oracle):
     """the same phases on ONE brick whose periodic images are all treated as remote ghosts (`self_remote`, thread
     transport with one rank): shell = everything within the ghost cutoff of the box faces"""

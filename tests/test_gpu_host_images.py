@@ -82,6 +82,39 @@ def test_rebomos_images_follow_a_changing_box(rctx, oracle, P):
         assert g["eng"] == pytest.approx(o["eng"], rel=1e-10)
 
 
+def test_rebomos_style_lists_rebuilt_under_a_changed_box(rctx, oracle, P):
+    """The box changes by far more than the mirror-slot matching tolerance (count * dh = 0.15 A against 1e-3 A) and THEN
+    atoms move beyond half the inner skin, so the style rebuilds its own lists -- reverse slots of image pairs included
+    -- before the host hands over atoms again.  The mirror slot of (a, image of o) has to be found with the image's shift
+    of THIS step, or the image clusters' forces on the owned atoms next to the periodic faces are silently dropped."""
+    import dataclasses
+    s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (2, 2, 1)), 0.02, seed=11)
+    eng = mdref.RebomosCPU(oracle, P, s, skin=2.0)
+    rctx.set_box_host(s.box)
+    rctx.set_atoms_host(eng.nlocal, eng.all_positions(s.x), eng.type_all, eng.tag_all, 2, map_=[0, 0, 1])
+    assert rctx.host_ghosts_derived()
+    rctx.set_skin(2.0)
+    rctx.rebomos_compute_host(eng.nlocal)
+    builds0 = rctx.rebomos_list_info()["builds"]
+    for f, sign in ((1.004, 1.0), (0.996, -1.0)):
+        s2 = S.scale(s, f)
+        x3 = s2.x.copy()
+        x3[[3, 101, 200, 555]] += sign * np.array([0.4, 0.3, 0.2])  # 0.54 A > half the 1.0 A inner skin: the style rebuilds
+        s3 = dataclasses.replace(s2, x=x3)
+        eng3 = mdref.RebomosCPU(oracle, P, s3, skin=2.0)
+        rctx.set_box_host(s2.box)
+        xa = eng.all_positions(s.x) * f
+        xa[:eng.nlocal] = x3
+        rctx.set_positions_host(_poison_ghosts(xa, eng.nlocal))
+        g = rctx.rebomos_compute_host(eng.nlocal)
+        assert rctx.rebomos_list_info()["builds"] > builds0
+        builds0 = rctx.rebomos_list_info()["builds"]
+        o = eng3.compute(s3.x)
+        assert np.abs(g["f"] - o["f_owned"]).max() < 1e-9
+        assert g["eng"] == pytest.approx(o["eng"], rel=1e-10)
+        assert np.abs(g["eatom"] - o["eatom_owned"]).max() < 1e-9
+
+
 def test_a_ghost_that_is_nobodys_image_switches_the_path_off(rctx, oracle, P):
     """(a) a ghost of another rank's atom (its tag is not owned here), (b) a box that is not the one the images were
     made with, (c) no box at all, (d) MDP_HOST_GHOSTS=upload: positions of all atoms are read as before"""
