@@ -95,6 +95,25 @@ def engine(style, s, orc, P=None, T=None):
     return mdref.RebomosCPU(orc, P, s) if style == "rebomos" else mdref.AeamCPU(orc, T, s)
 
 
+class _RebomosCuts:
+    """what mdref.RebomosCPU reads of the parameter struct to build ghosts and lists"""
+
+    def __init__(self, rcmax):
+        self.rcmax = rcmax
+        self.cut3rebo = 3.0 * rcmax[0][0]              # pair_rebomos.cpp:257
+
+
+class _AeamCuts:
+    def __init__(self, cut):                           # cut[a][b], elements 0-based (setfl->cut)
+        self.nelements, self.cut = len(cut), cut
+
+
+def lists_only(style, s, cuts):
+    """ghosts + neighbor lists of a fixture WITHOUT the oracle (the GPU tests): `cuts` = rcmax[2][2] of the product's
+    own parameter file parser (rebomos) or its cut[ne][ne] table (aeam).  compute() of the result must not be called."""
+    return mdref.RebomosCPU(None, _RebomosCuts(cuts), s) if style == "rebomos" else mdref.AeamCPU(None, _AeamCuts(cuts), s)
+
+
 def _fold(a, owner, nlocal):
     out = a[:nlocal].copy()
     np.add.at(out, owner, a[nlocal:])
