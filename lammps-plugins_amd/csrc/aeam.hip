@@ -384,10 +384,7 @@ __global__ __launch_bounds__(256) void aeam_tile_density_kernel(
 // aeam_force_kernel.  LDS record of a union member: x y z q with q = Fptmp*F' of metal neighbours, 0 otherwise.
 // EV: also the pair energy (global and per atom) and the global virial of this rank's own visits, tallied exactly
 // as aeam_force_kernel<.., true> does (ev_tally of the visit i = a: pair_aeam.cpp:386-393).
-// MINOR: only what the persistent force kernel (aeam_pforce_kernel, below) leaves out -- the visits of the minority pair
-// types: cluster atoms of type 0 against segment 1 (neighbours of the other type), cluster atoms of another type against
-// both segments.  The union's type-0 members are staged only in tiles that hold a cluster atom of another type.
-template <int CL, bool EV, bool MULTI, bool MINOR = false>
+template <int CL, bool EV, bool MULTI>
 __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     const AeamDev A, const int nlocal, const int nclus, const int t_begin, const double4 *__restrict__ xq,
     const double *__restrict__ fp, const int cap, const int capL, const int *__restrict__ tu, const int *__restrict__ tile_nu,
@@ -425,29 +422,19 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     T = par_fill(A, s_rec + 4 * (size_t) capL, tid);
     s_ty = reinterpret_cast<int *>(reinterpret_cast<char *>(s_rec + 4 * (size_t) capL) + kParBytes);
   }
-  int u_first = 0; // MINOR: members [0, u_first) are not staged (nobody reads them)
-  if (MINOR) {
-    bool other = false;
-#pragma unroll
-    for (int c = 0; c < CL; c++) other = other || (have && kc * CL + c < nlocal && (int) xa[c].w != 0);
-    if (!__syncthreads_or(other)) {
-      if (nU == N0) return; // (block-uniform) nothing of a minority pair type in this tile
-      u_first = N0;
-    }
-  }
   {
     double4 sv[SK];
     double sq[SK];
 #pragma unroll
     for (int k = 0; k < SK; k++) {
-      const int j = tid + 256 * k < nU && tid + 256 * k >= u_first ? sidx[k] : 0;
+      const int j = tid + 256 * k < nU ? sidx[k] : 0;
       sv[k] = xq[j];
       sq[k] = fp[j];
     }
 #pragma unroll
     for (int k = 0; k < SK; k++) {
       const int u = tid + 256 * k;
-      if (u < nU && u >= u_first) {
+      if (u < nU) {
         const int tu_ = MULTI ? (int) sv[k].w : (u < N0 ? 0 : 1);
         s4[u] = make_double4(sv[k].x, sv[k].y, sv[k].z, tu_ < A.nnonangular ? sq[k] : 0.0);
         if (MULTI) s_ty[u] = tu_;
@@ -455,7 +442,6 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
     }
   }
   for (int u = tid + 256 * SK; u < nU; u += 256) {
-    if (u < u_first) continue;
     const int j = mem[u];
     const double4 v = xq[j];
     const int tu_ = MULTI ? (int) v.w : (u < N0 ? 0 : 1);
@@ -479,21 +465,9 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
   }
   __syncthreads();
   const int nm1 = A.nrmax + 1;
-  bool real_all[CL]; // (MINOR: `real` is narrowed per segment)
-#pragma unroll
-  for (int c = 0; c < CL; c++) real_all[c] = real[c];
   auto segment = [&](auto tjc) {
     constexpr int TJ = decltype(tjc)::value;
     const int kb = TJ ? split : 0, ke = TJ ? cnt : split;
-    if (MINOR) { // segment 0: only cluster atoms of another type (the persistent kernel has the (0,0) pairs)
-      bool any = false;
-#pragma unroll
-      for (int c = 0; c < CL; c++) {
-        real[c] = real_all[c] && (TJ == 1 || ta[c] != 0);
-        any = any || real[c];
-      }
-      if (!__any(any)) return;
-    }
     TilePar qA[CL], qJ[CL];
 #pragma unroll
     for (int c = 0; c < CL; c++) {
@@ -602,7 +576,7 @@ __global__ __launch_bounds__(256) void aeam_tile_force_kernel(
   if (s < CL) {
 #pragma unroll
     for (int c = 0; c < CL; c++)
-      if (c == s && real_all[c]) { // plain += : only writer of owned f here (stream order); the angular kernel follows
+      if (c == s && real[c]) { // plain += : only writer of owned f here (stream order); the angular kernel follows
         double *fo = f + 3 * (size_t) (kc * CL + c);
         fo[0] += fx[c];
         fo[1] += fy[c];
@@ -945,515 +919,6 @@ __global__ __launch_bounds__(NSUB * 256) void aeam_ptile_kernel(const AeamDev A,
   }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Persistent pair-force kernel (pass 3, pair part, force-only steps): the derivative tables of the majority pair
-// type live in LDS.
-//
-// A visit of the pair part needs rho'(r) and phi'(r) of the pair type at ONE table row (pair_aeam.cpp:357-376).  The
-// gather kernel above fetches them as a 48-byte record per in-range visit from a table every lane addresses at another
-// row: three L1 lookups per visit, and the L1's lookup rate is what bounds it.  The
-// derivative of a row's Hermite cubic is a quadratic in S[m], S[m+1] and d[m] = Y[m+1] - Y[m] (pair_aeam.cpp:929-941:
-// c4 = 3d - 2S[m] - S[m+1], c3 = S[m] + S[m+1] - 2d; derivative (3 c3 p + 2 c4) p + S[m], over delta), so
-// {S_rho, S_phi, d_rho, d_phi} = 32 bytes per row hold both functions.  The rows of the whole r range do not fit the
-// 160 KB of a CU twice over, so the window holds the rows from r_w up to the cutoff (about 4.0-4.4 A of 6.5 A for
-// sample.in: the third neighbour shell outwards, 60 of the 78 neighbours of an fcc atom), and the row pruning
-// (tile_prune_nf_kernel in rebomos.hip) splits segment 0 of every row into [near | far]: the far entries stay beyond
-// r_w until the next pruning and are evaluated from LDS only; the near ones -- the first two shells -- take the
-// 48-byte records from global memory in a short loop of their own in front.  Everything else (cluster atoms of the other
-// type, neighbours of the other type: 1.5 % in sample.in; a far entry that slipped below the window after a late
-// pruning) runs through cold passes with per-lane parameters, behind the hot loops and only in waves that need them.
-// Shape as aeam_ptile_kernel: one resident workgroup per CU, NSUB sub-blocks of 256 threads walking a contiguous run
-// of tiles, the next tile's union / rows / heads requested into registers before the current tile is computed.
-// ------------------------------------------------------------------------------------------------------
-struct PForce {
-  int nlocal, nclus, cap, capL, rowcapB, per; // per = tiles per workgroup
-  int t_begin, t_end;                         // the launch walks tiles [t_begin, t_end)
-  int wlo, nw;                                // LDS window: rows [wlo, wlo + nw) of the (0,0) pair
-  double hot_rsqmax;                          // largest r^2 inside the (0,0) pair's cutoff
-  const double4 *xq;
-  const double *fp; // q = Fptmp * F' of owned atoms and ghosts
-  const int *tu, *tile_nu;
-  const long long *lj_off;
-  const int *lj_len, *lj_split, *lj_near; // pruned rows: total length, end of segment 0, end of its near part
-  const unsigned short *lj16;
-  const double4 *sd4; // [nrmax+1] {S_rho, S_phi, d_rho, d_phi} of the (0,0) pair
-  double *f;
-  int dbg;
-};
-
-template <int NSUB>
-__global__ __launch_bounds__(NSUB * 256) void aeam_pforce_kernel(const AeamDev A, const PForce P)
-{
-  constexpr int L = 16, CL = 2, SK = 3, RK = 2;
-  extern __shared__ double4 s_dyn4[];
-  double4 *__restrict__ s_tab = s_dyn4; // [nw]
-  const int tid = threadIdx.x, sub = tid >> 8, t8 = tid & 255, lane = tid & 63, s = lane % L, gq = t8 / L;
-  char *sb = reinterpret_cast<char *>(s_tab + P.nw) + (size_t) sub * ((size_t) P.capL * 32 + P.rowcapB);
-  double *__restrict__ s_pos = reinterpret_cast<double *>(sb);                    // [capL][3]
-  double *__restrict__ s_q = s_pos + 3 * (size_t) P.capL;                         // [capL]
-  unsigned short *__restrict__ s_row = reinterpret_cast<unsigned short *>(sb + (size_t) P.capL * 32);
-  double2 *__restrict__ s_row2 = reinterpret_cast<double2 *>(s_row);
-  const int nm1 = A.nrmax + 1;
-  {
-    const double4 *__restrict__ src = P.sd4 + P.wlo;
-    for (int i = tid; i < P.nw; i += NSUB * 256) s_tab[i] = src[i];
-  }
-  const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int t_first = P.t_begin + wg * P.per;
-  const int t_last = t_first + P.per < P.t_end ? t_first + P.per : P.t_end; // exclusive
-  const int rounds = (P.per + NSUB - 1) / NSUB;
-
-  // ---- stage 1 of the prefetch: tile header + union member indices (two tiles ahead) -- requests only ----
-  int m_t, m_idx[SK];
-  bool m_valid;
-  int2 m_nu;
-  long long m_rb;
-  int m_re;
-  const int *__restrict__ off_lo = reinterpret_cast<const int *>(P.lj_off);
-  auto load_meta = [&](const int tt) {
-    m_valid = tt < t_last;
-    m_t = m_valid ? tt : P.t_end - 1;
-    m_nu = reinterpret_cast<const int2 *>(P.tile_nu)[m_t];
-    m_rb = P.lj_off[(size_t) m_t * kTile];
-    m_re = off_lo[2 * ((size_t) m_t * kTile + kTile)];
-    const int *__restrict__ mem = P.tu + (size_t) m_t * P.cap;
-#pragma unroll
-    for (int k = 0; k < SK; k++) m_idx[k] = mem[t8 + 256 * k];
-  };
-  // ---- stage 2: the union's coordinates and q, the tile's rows, the cluster heads (one tile ahead) ----
-  int n_t, n_nU, n_N0, n_rtot, n_split, n_near;
-  long long n_rb;
-  int n_b;
-  double4 n_sv[SK], n_xa[CL];
-  double n_sq[SK], n_qa[CL];
-  double n_rv[RK][2];
-  auto gather = [&]() {
-    n_t = m_t;
-    n_nU = m_valid ? m_nu.x : 0;
-    n_N0 = m_nu.y;
-    n_rtot = m_valid ? m_re - (int) m_rb : 0;
-    n_rb = m_rb;
-#pragma unroll
-    for (int k = 0; k < SK; k++) {
-      const int j = t8 + 256 * k < n_nU ? m_idx[k] : 0;
-      n_sv[k] = P.xq[j];
-      n_sq[k] = P.fp[j];
-    }
-    const double2 *__restrict__ rsrc = reinterpret_cast<const double2 *>(P.lj16 + m_rb);
-#pragma unroll
-    for (int k = 0; k < RK; k++) {
-      const double2 v = rsrc[(t8 + 256 * k) * 8 < n_rtot ? t8 + 256 * k : 0];
-      n_rv[k][0] = v.x;
-      n_rv[k][1] = v.y;
-    }
-    const int kc = m_t * kTile + gq;
-    n_b = off_lo[2 * kc];
-    n_split = P.lj_split[kc];
-    n_near = P.lj_near[kc];
-#pragma unroll
-    for (int c = 0; c < CL; c++) {
-      const int ia = kc * CL + c < P.nlocal ? kc * CL + c : P.nlocal - 1;
-      n_xa[c] = P.xq[ia];
-      n_qa[c] = P.fp[ia];
-    }
-  };
-  // registers -> LDS (between two barriers)
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < SK; k++) {
-      const int u = t8 + 256 * k;
-      if (u < n_nU) {
-        s_pos[3 * u] = n_sv[k].x;
-        s_pos[3 * u + 1] = n_sv[k].y;
-        s_pos[3 * u + 2] = n_sv[k].z;
-        s_q[u] = (u < n_N0 ? 0 : 1) < A.nnonangular ? n_sq[k] : 0.0; // (two types: members [0, N0) are of type 0)
-      }
-    }
-    if (n_nU > 256 * SK) { // a union beyond the register stage: fetched here (not seen in practice)
-      const int *__restrict__ mem = P.tu + (size_t) n_t * P.cap;
-      for (int u = t8 + 256 * SK; u < n_nU; u += 256) {
-        const int j = mem[u];
-        const double4 v = P.xq[j];
-        s_pos[3 * u] = v.x;
-        s_pos[3 * u + 1] = v.y;
-        s_pos[3 * u + 2] = v.z;
-        s_q[u] = (u < n_N0 ? 0 : 1) < A.nnonangular ? P.fp[j] : 0.0;
-      }
-    }
-    if (t8 == 0) { // the dummy member every padding entry points at: outside every cutoff
-      s_pos[3 * n_nU] = 1.0e30;
-      s_pos[3 * n_nU + 1] = 0.0;
-      s_pos[3 * n_nU + 2] = 0.0;
-      s_q[n_nU] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < RK; k++) {
-      const int e = t8 + 256 * k;
-      if (e * 8 < n_rtot) s_row2[e] = make_double2(n_rv[k][0], n_rv[k][1]);
-    }
-    if (n_rtot > 256 * RK * 8) {
-      const double2 *__restrict__ rsrc = reinterpret_cast<const double2 *>(P.lj16 + n_rb);
-      for (int e = t8 + 256 * RK; e * 8 < n_rtot; e += 256) s_row2[e] = rsrc[e];
-    }
-  };
-
-  load_meta(t_first + sub);
-  gather();
-  load_meta(t_first + NSUB + sub);
-  __syncthreads(); // (the table)
-  commit();
-  __syncthreads();
-
-  const double rdr0 = A.rdr[0], c2max = P.hot_rsqmax;
-  const int nr0 = A.nr[0];
-  int o_at = -1; // the atom whose forces this lane still holds (from the previous round)
-  double o_f[3] = {0.0, 0.0, 0.0};
-  for (int rd = 0; rd < rounds; rd++) {
-    // ---- the tile to compute now: heads out of the stage registers ----
-    const int t = n_t, nU = n_nU;
-    const int split = __builtin_amdgcn_readfirstlane(nU ? n_split : 0);
-    const int near = __builtin_amdgcn_readfirstlane(nU ? n_near : 0);
-    const int roff = n_b - (int) n_rb;
-    const int kc = t * kTile + gq;
-    double4 xa[CL];
-    double qa[CL];
-    int ta[CL];
-    bool real[CL], hot[CL];
-#pragma unroll
-    for (int c = 0; c < CL; c++) {
-      xa[c] = n_xa[c];
-      ta[c] = (int) xa[c].w;
-      real[c] = nU > 0 && kc < P.nclus && kc * CL + c < P.nlocal;
-      hot[c] = real[c] && ta[c] == 0;
-      qa[c] = ta[c] < A.nnonangular ? n_qa[c] : 0.0; // (1 - deli): angular centres embed through the three-body kernel
-    }
-    // ---- request the next tile, and the header of the one after ----
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing is in flight here (see aeam_ptile_kernel)
-    gather();
-    load_meta(t_first + (rd + 2) * NSUB + sub);
-    // ---- the PREVIOUS tile's forces leave now: their round trip to L2 lies behind this tile's loops, not in front of
-    // the wait above (added, not stored: the three-body kernel may have run already; atomics WITHOUT return -- a
-    // read-modify-write would be a load whose use waits for every load in flight, the prefetch just requested) ----
-    if (o_at >= 0) {
-      double *fo = P.f + 3 * (size_t) o_at;
-      unsafeAtomicAdd(fo, o_f[0]);
-      unsafeAtomicAdd(fo + 1, o_f[1]);
-      unsafeAtomicAdd(fo + 2, o_f[2]);
-    }
-
-    double fx[CL], fy[CL], fz[CL];
-#pragma unroll
-    for (int c = 0; c < CL; c++) fx[c] = fy[c] = fz[c] = 0.0;
-    const unsigned short *__restrict__ row = s_row + roff;
-    bool anyhot = false;
-#pragma unroll
-    for (int c = 0; c < CL; c++) anyhot = anyhot || hot[c];
-    bool below = false; // a far entry whose row lies below the window (late pruning): the fallback pass takes it
-    // geometry of one (entry, cluster atom) visit of the (0,0) pair
-    auto geom = [&](const int li, const int c, double &dx, double &dy, double &dz, double &recip, double &pf, int &m) {
-      const double *__restrict__ pj = s_pos + 3 * li;
-      dx = pj[0] - xa[c].x;
-      dy = pj[1] - xa[c].y;
-      dz = pj[2] - xa[c].z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      const bool in = hot[c] && rsq > 0.0 && rsq <= c2max; // (the union holds the cluster's own atoms too)
-      recip = rsqrt_n1(in ? rsq : 1.0);
-      m = spline_index((in ? rsq : 1.0) * recip, rdr0, nr0, pf);
-      return in;
-    };
-    if (__any(anyhot)) {
-      // NEAR part, first half: the 48-byte records of its first two trips (the first two neighbour shells: rows below
-      // the window) are REQUESTED here, unconditionally (a lane without a visit asks for the row of r = 1) and touched
-      // only behind the far loop, which reads LDS alone -- their round trip costs nothing
-      constexpr int NT = 2;
-      int nli[NT];
-      double2 nrec[NT][CL][3];
-      if (!(P.dbg & 2)) {
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-          nli[q] = q * L + s < near ? (int) row[q * L + s] : nU;
-#pragma unroll
-          for (int c = 0; c < CL; c++) {
-            double dx, dy, dz, recip, pf;
-            int m;
-            const bool in = geom(nli[q], c, dx, dy, dz, recip, pf, m);
-            const double2 *rec = A.pair_d6 + 3 * (size_t) m; // pair type 0
-            nrec[q][c][0] = nrec[q][c][1] = nrec[q][c][2] = make_double2(0.0, 0.0);
-            if (in || (P.dbg & 8)) { // (a third of the padded entries of the near part are no visit: no L1 lookups for them)
-              nrec[q][c][0] = rec[0];
-              nrec[q][c][1] = rec[1];
-              nrec[q][c][2] = rec[2];
-            }
-          }
-        }
-      }
-      // FAR part of segment 0: both visits of a (0,0) pair from the LDS window, every parameter a scalar,
-      //   fpair_a + fpair_j = -((q_a + q_j) rho'(r) + phi'(r)) / r          (pair_aeam.cpp:371-376, both directions)
-      if (!(P.dbg & 1)) {
-        int li_next = near + s < split ? (int) row[near + s] : nU;
-        for (int k = near + s; k < split; k += L) {
-          const int li = li_next;
-          const double *__restrict__ pj = s_pos + 3 * li;
-          const double xj = pj[0], yj = pj[1], zj = pj[2];
-          li_next = k + L < split ? (int) row[k + L] : nU;
-#pragma unroll
-          for (int c = 0; c < CL; c++) {
-            const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
-            const double rsq = dx * dx + dy * dy + dz * dz;
-            if (!(hot[c] && rsq > 0.0 && rsq <= c2max)) continue;
-            const double recip = rsqrt_n1(rsq);
-            const double r = rsq * recip;
-            double pf;
-            const int m = spline_index(r, rdr0, nr0, pf);
-            if (m < P.wlo) {
-              below = true;
-              continue;
-            }
-            lds_double *src = (lds_double *) (s_tab + (m - P.wlo));
-            const double Sr = src[0], Sp = src[1], dr = src[2], dp = src[3], Sr1 = src[4], Sp1 = src[5];
-            const double c4r = 3.0 * dr - 2.0 * Sr - Sr1, c3r = Sr + Sr1 - 2.0 * dr;
-            const double c4p = 3.0 * dp - 2.0 * Sp - Sp1, c3p = Sp + Sp1 - 2.0 * dp;
-            const double rhop = (3.0 * c3r * pf + 2.0 * c4r) * pf + Sr; // (times rdr: below)
-            const double phip = (3.0 * c3p * pf + 2.0 * c4p) * pf + Sp;
-            const double qj = ((lds_double *) s_q)[li];
-            const double ft = -((qa[c] + qj) * rhop + phip) * (rdr0 * recip);
-            fx[c] -= dx * ft;
-            fy[c] -= dy * ft;
-            fz[c] -= dz * ft;
-          }
-        }
-      }
-      // NEAR part, second half: the records have arrived; the geometry is taken again from LDS (cheaper than keeping it)
-      if (!(P.dbg & 2)) {
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-          const double qj = s_q[nli[q]];
-#pragma unroll
-          for (int c = 0; c < CL; c++) {
-            double dx, dy, dz, recip, pf;
-            int m;
-            const bool in = geom(nli[q], c, dx, dy, dz, recip, pf, m);
-            const double rhop = (nrec[q][c][0].x * pf + nrec[q][c][0].y) * pf + nrec[q][c][1].x;
-            const double phip = (nrec[q][c][1].y * pf + nrec[q][c][2].x) * pf + nrec[q][c][2].y;
-            const double ft = in ? -((qa[c] + qj) * rhop + phip) * recip : 0.0;
-            fx[c] -= dx * ft;
-            fy[c] -= dy * ft;
-            fz[c] -= dz * ft;
-          }
-        }
-        // (a near part longer than two trips: the rest with its loads inside the loop)
-        for (int k = NT * L + s; k < near; k += L) {
-          const int li = (int) row[k];
-          const double qj = s_q[li];
-#pragma unroll
-          for (int c = 0; c < CL; c++) {
-            double dx, dy, dz, recip, pf;
-            int m;
-            const bool in = geom(li, c, dx, dy, dz, recip, pf, m);
-            const double2 *rec = A.pair_d6 + 3 * (size_t) m;
-            const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2];
-            const double rhop = (a0.x * pf + a0.y) * pf + a1.x;
-            const double phip = (a1.y * pf + a2.x) * pf + a2.y;
-            const double ft = in ? -((qa[c] + qj) * rhop + phip) * recip : 0.0;
-            fx[c] -= dx * ft;
-            fy[c] -= dy * ft;
-            fz[c] -= dz * ft;
-          }
-        }
-      }
-    }
-    // COLD passes: per-lane parameters, records from global memory -- the visit arithmetic of aeam_tile_force_kernel.
-    //   MODE 0: cluster atoms that are not hot (segment 0), every cluster atom (segment 1)
-    //   MODE 1: hot atoms, far entries whose row lies below the window
-    auto cold = [&](auto tjc, auto modec, const int kb, const int ke) {
-      constexpr int TJ = decltype(tjc)::value, MODE = decltype(modec)::value;
-      TilePar qA[CL], qJ[CL];
-      bool want[CL];
-#pragma unroll
-      for (int c = 0; c < CL; c++) {
-        qA[c] = tile_par<TJ, false>(A, ta[c]); // visit (i = a, j)
-        qJ[c] = tile_par<TJ, true>(A, ta[c]);  // visit (i = j, a)
-        want[c] = MODE == 1 ? hot[c] : (TJ == 1 ? real[c] : real[c] && !hot[c]);
-      }
-      int li_next = kb + s < ke ? (int) row[kb + s] : nU;
-      for (int k = kb + s; k < ke; k += L) {
-        const int li = li_next;
-        const double *__restrict__ pj = s_pos + 3 * li;
-        const double xj = pj[0], yj = pj[1], zj = pj[2];
-        const double qj = s_q[li];
-        li_next = k + L < ke ? (int) row[k + L] : nU;
-#pragma unroll
-        for (int c = 0; c < CL; c++) {
-          const double dx = xj - xa[c].x, dy = yj - xa[c].y, dz = zj - xa[c].z;
-          const double rsq = dx * dx + dy * dy + dz * dz;
-          const bool pair = want[c] && rsq > 0.0 && rsq < 1.0e20;
-          if (!pair) continue;
-          const double recip = MODE == 1 ? rsqrt_n1(rsq) : rsqrt_nr(rsq);
-          const double r = rsq * recip;
-          bool in_a = r <= qA[c].cut, in_j = r <= qJ[c].cut;
-          if (MODE == 1) in_a = in_j = rsq <= c2max; // (exactly the hot loops' test)
-          if (!(in_a || in_j)) continue;
-          double pfa;
-          const int ma = spline_index(r, qA[c].rdr, qA[c].nr, pfa);
-          if (MODE == 1 && ma >= P.wlo) continue; // the far loop had it
-          double fpair_a = 0.0, fpair_j = 0.0, dfa = 0.0;
-          if (in_a) {
-            const double2 *rec = A.pair_d6 + 3 * ((size_t) qA[c].pair * nm1 + ma);
-            const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2];
-            dfa = (a0.x * pfa + a0.y) * pfa + a1.x;
-            const double phip = (a1.y * pfa + a2.x) * pfa + a2.y;
-            fpair_a = -qa[c] * dfa * recip + 0.5 * (-phip * recip);
-          }
-          if (in_j) {
-            if (TJ == ta[c] && in_a) { // same element: both visits read the same table rows
-              fpair_j = fpair_a + (qa[c] - qj) * dfa * recip;
-            } else {
-              double pf;
-              const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
-              const double2 *rec = A.pair_d6 + 3 * ((size_t) qJ[c].pair * nm1 + m);
-              const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2];
-              const double dfja = (j0.x * pf + j0.y) * pf + j1.x;
-              const double phip = (j1.y * pf + j2.x) * pf + j2.y;
-              fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
-            }
-          }
-          const double ft = fpair_a + fpair_j;
-          fx[c] -= dx * ft;
-          fy[c] -= dy * ft;
-          fz[c] -= dz * ft;
-        }
-      }
-    };
-    // (the visits of the minority pair types -- segment 1, cluster atoms of the other type -- are not this kernel's:
-    //  aeam_tile_force_kernel<.., MINOR> follows.  In here they would be a global round trip at the end of most rounds)
-    if (__any(below)) cold(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, near, split);
-    // ---- results of the tile ----
-#pragma unroll
-    for (int c = 0; c < CL; c++) {
-      fx[c] = lane_sum<L>(fx[c]);
-      fy[c] = lane_sum<L>(fy[c]);
-      fz[c] = lane_sum<L>(fz[c]);
-    }
-    // lane s of a group keeps atom s of its cluster until the next round's requests are out
-    o_at = -1;
-#pragma unroll
-    for (int c = 0; c < CL; c++)
-      if (c == s && hot[c]) {
-        o_at = kc * CL + c;
-        o_f[0] = fx[c];
-        o_f[1] = fy[c];
-        o_f[2] = fz[c];
-      }
-    // ---- the next tile's data goes to LDS ----
-    __syncthreads();
-    commit();
-    __syncthreads();
-  }
-  if (o_at >= 0) {
-    double *fo = P.f + 3 * (size_t) o_at;
-    unsafeAtomicAdd(fo, o_f[0]);
-    unsafeAtomicAdd(fo + 1, o_f[1]);
-    unsafeAtomicAdd(fo + 2, o_f[2]);
-  }
-}
-
-// Segment 1 of the rows behind the persistent force kernel: cluster atoms of type 0 against their neighbours of the other
-// type (1.5 % of the row entries in sample.in), both visits of each pair.  One WAVE per tile, four lanes per cluster, no
-// LDS and no barrier: a tile has a handful of such entries, and what costs is the chain row entry -> member -> position
-// -> table record, so many small independent waves beat one workgroup per tile.  (Cluster atoms of the other type are
-// served from their CSR rows by aeam_force_kernel with the list of angular centres.)
-__global__ __launch_bounds__(256) void aeam_seg1_force_kernel(
-    const AeamDev A, const int nlocal, const int nclus, const int t_begin, const int t_end,
-    const double4 *__restrict__ xq, const double *__restrict__ fp, const int cap, const int *__restrict__ tu,
-    const int *__restrict__ tile_nu, const long long *__restrict__ lj_off, const int *__restrict__ lj_len,
-    const int *__restrict__ lj_split, const unsigned short *__restrict__ lj16, double *__restrict__ f)
-{
-  constexpr int CL = 2, Q = 4;
-  const int lane = threadIdx.x & 63, g = lane / Q, q = lane % Q;
-  const int t = t_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= t_end) return; // (wave-uniform)
-  const int2 nu = reinterpret_cast<const int2 *>(tile_nu)[t];
-  if (nu.x == nu.y) return; // no member of another type in this tile's union
-  const int kc = t * kTile + g;
-  const long long b = lj_off[kc];
-  const int len = lj_len[kc], split = lj_split[kc];
-  const int *__restrict__ mem = tu + (size_t) t * cap;
-  const unsigned short *__restrict__ row = lj16 + b;
-  const int nm1 = A.nrmax + 1;
-  double4 xa[CL];
-  double qa[CL];
-  bool want[CL];
-  TilePar qA[CL], qJ[CL];
-  double fx[CL], fy[CL], fz[CL];
-#pragma unroll
-  for (int c = 0; c < CL; c++) {
-    const int ia = kc < nclus && kc * CL + c < nlocal ? kc * CL + c : nlocal - 1;
-    xa[c] = xq[ia];
-    const int ta = (int) xa[c].w;
-    want[c] = kc < nclus && kc * CL + c < nlocal && ta == 0;
-    qa[c] = ta < A.nnonangular ? fp[ia] : 0.0;
-    qA[c] = tile_par<1, false>(A, 0); // visit (i = a of type 0, j of type 1)
-    qJ[c] = tile_par<1, true>(A, 0);  // visit (i = j of type 1, a)
-    fx[c] = fy[c] = fz[c] = 0.0;
-  }
-  for (int k = split + q; k < len; k += Q) {
-    const int li = (int) row[k];
-    if (li >= nu.x) continue; // padding
-    const int j = mem[li];
-    const double4 xj = xq[j];
-    const double qj = 1 < A.nnonangular ? fp[j] : 0.0;
-#pragma unroll
-    for (int c = 0; c < CL; c++) {
-      const double dx = xj.x - xa[c].x, dy = xj.y - xa[c].y, dz = xj.z - xa[c].z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (!(want[c] && rsq > 0.0)) continue;
-      const double recip = rsqrt_nr(rsq);
-      const double r = rsq * recip;
-      const bool in_a = r <= qA[c].cut, in_j = r <= qJ[c].cut;
-      if (!(in_a || in_j)) continue;
-      double fpair_a = 0.0, fpair_j = 0.0;
-      if (in_a) {
-        double pf;
-        const int m = spline_index(r, qA[c].rdr, qA[c].nr, pf);
-        const double2 *rec = A.pair_d6 + 3 * ((size_t) qA[c].pair * nm1 + m);
-        const double2 a0 = rec[0], a1 = rec[1], a2 = rec[2];
-        const double dfa = (a0.x * pf + a0.y) * pf + a1.x;
-        const double phip = (a1.y * pf + a2.x) * pf + a2.y;
-        fpair_a = -qa[c] * dfa * recip + 0.5 * (-phip * recip);
-      }
-      if (in_j) {
-        double pf;
-        const int m = spline_index(r, qJ[c].rdr, qJ[c].nr, pf);
-        const double2 *rec = A.pair_d6 + 3 * ((size_t) qJ[c].pair * nm1 + m);
-        const double2 j0 = rec[0], j1 = rec[1], j2 = rec[2];
-        const double dfja = (j0.x * pf + j0.y) * pf + j1.x;
-        const double phip = (j1.y * pf + j2.x) * pf + j2.y;
-        fpair_j = -qj * dfja * recip + 0.5 * (-phip * recip);
-      }
-      const double ft = fpair_a + fpair_j;
-      fx[c] -= dx * ft;
-      fy[c] -= dy * ft;
-      fz[c] -= dz * ft;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < CL; c++) {
-    fx[c] = lane_sum<Q>(fx[c]);
-    fy[c] = lane_sum<Q>(fy[c]);
-    fz[c] = lane_sum<Q>(fz[c]);
-  }
-  if (q < CL) {
-#pragma unroll
-    for (int c = 0; c < CL; c++)
-      if (c == q && want[c] && (fx[c] != 0.0 || fy[c] != 0.0 || fz[c] != 0.0)) {
-        double *fo = f + 3 * (size_t) (kc * CL + c);
-        unsafeAtomicAdd(fo, fx[c]);
-        unsafeAtomicAdd(fo + 1, fy[c]);
-        unsafeAtomicAdd(fo + 2, fz[c]);
-      }
-  }
-}
-
 // ---- angular centres: one wave per centre, in-range neighbours staged in LDS (list order kept) ------
 // slot record: dx dy dz r rsq f df fx fy fz   (d = x_j - x_i; the flag -- inside cut - CutDec, the range of
 // pass 1 and of the k loop of pass 3)
@@ -1608,17 +1073,14 @@ __global__ __launch_bounds__(256) void aeam_force_kernel(const AeamDev A, const 
                                                          const int *__restrict__ nb, const double *__restrict__ fp,
                                                          double *__restrict__ f, double *__restrict__ eatom,
                                                          double *__restrict__ vatom, double *__restrict__ acc,
-                                                         const int eflag, const int vflag,
-                                                         const int *__restrict__ list = nullptr)
+                                                         const int eflag, const int vflag)
 {
-  // list: the kernel serves the atoms list[0 .. nlocal) instead of 0 .. nlocal (the angular centres of a tiled run, whose
-  // CSR rows exist: the pair part of the minority atom type behind the persistent force kernel)
   constexpr int U = 2;
   const int lane = threadIdx.x & 63;
   const int s = lane % L;
   const long long a64 = (long long) blockIdx.x * (256 / L) + threadIdx.x / L;
   const bool have = a64 < nlocal;
-  const int a = have ? (list ? list[a64] : (int) a64) : (list ? list[0] : 0);
+  const int a = have ? (int) a64 : 0;
   const double4 xa = xq[a];
   const int ta = (int) xa.w;
   const bool a_metal = ta < A.nnonangular;
@@ -1903,18 +1365,6 @@ __global__ void ys_kernel(const size_t nrows, const double *__restrict__ src, do
   ys[i] = make_double2(src[7 * i + 6], src[7 * i + 5]);
 }
 
-// {S_rho, S_phi, d_rho, d_phi} of one pair type per row (see AeamDev::pair_sd4): slopes = column 5 of the reference's
-// 7-column rows, d = difference of column 6 to the next row (0 for the last row, whose cubic is never evaluated)
-__global__ void pair_sd_kernel(const int nm1, const double *__restrict__ rhor_tab, const double *__restrict__ z2r_tab,
-                               double4 *__restrict__ out)
-{
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= nm1) return;
-  const double *a = rhor_tab + (size_t) m * 7, *b = z2r_tab + (size_t) m * 7;
-  const bool last = m + 1 >= nm1;
-  out[m] = make_double4(a[5], b[5], last ? 0.0 : a[7 + 6] - a[6], last ? 0.0 : b[7 + 6] - b[6]);
-}
-
 // derivative coefficients of rho (c0..c2) and of phi (c0..c2) of ONE pair type side by side in a 48-byte
 // record: the pair-force visit needs both at the same row.  The tile kernels are bound by the vector L1's
 // lookup rate (~0.9 lookups per clock per CU measured, every lane a different row): a lookup moves at most 16
@@ -2144,140 +1594,6 @@ static int aeam_ptile_launch(mdp_ctx *c, const int t_begin, const int t_end, boo
   return MDP_OK;
 }
 
-// Persistent force kernel: does it apply, and with which geometry?  Decided from what a list build fixes (largest union,
-// most row entries of a tile), so the answer holds between two list builds: the row pruning splits segment 0 at the radius
-// the window begins at (c->prune_near_r, requested before every mdp_prune_upkeep), the launch checks that the rows it
-// walks were split for the same window.  Sub-blocks: three when the window still reaches down far enough, else two.
-static bool aeam_pforce_geometry(mdp_ctx *c, int *nsub_out, int *nw_out, int *wlo_out)
-{
-  const char *e = getenv("MDP_AEAM_PFORCE"); // unset / 1: whenever it applies; 0: never (the gather kernel)
-  if (e && atoi(e) == 0) return false;
-  if (!c->md || !c->aeam_tiled || c->tile_rowmax <= 0 || c->aeam.ntypes != 2 || c->aeam_cl != 2) return false;
-  if (c->aeam.nnonangular != 1) return false; // (the atoms of type 1 are served through the list of angular centres)
-  if ((double) c->h_ang_count > 0.1 * (double) c->nlocal) return false; // (as the persistent density kernel)
-  if (!c->lds_max) {
-    int v = 0, n = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return false;
-    c->lds_max = v;
-    c->num_cu = n > 0 ? n : 256;
-  }
-  const AeamDev &A = c->aeam;
-  const int capL = (c->tile_maxu + 1 + 7) & ~7;
-  const int rowcapB = (2 * c->tile_rowmax + 15) & ~15;
-  const size_t sub_bytes = (size_t) capL * 32 + rowcapB;
-  const int nr = A.nr[0];
-  const char *ens = getenv("MDP_AEAM_PF_NSUB");
-  const int force_nsub = ens ? atoi(ens) : 0;
-  for (int ns = 3; ns >= 2; ns--) {
-    if (force_nsub && ns != force_nsub) continue;
-    const long long room = (long long) c->lds_max - (long long) ns * (long long) sub_bytes - 64;
-    if (room <= 0) continue;
-    int w = (int) (room / 32);
-    if (w > nr) w = nr;
-    const int wlo = nr + 1 - w;
-    // the near part reaches to r_w + buffer: with 0.3 A of buffer at most ~0.73 (three sub-blocks) / ~0.80 (two) of the
-    // cutoff, i.e. at least 60 % / 50 % of the pair volume served from LDS -- below that the gather kernel is the better one
-    const double frac = ((wlo - 1) / A.rdr[0] + 0.3) / A.cut[0];
-    if (frac <= (ns == 3 ? 0.73 : 0.80) || force_nsub) {
-      *nsub_out = ns;
-      *nw_out = w;
-      *wlo_out = wlo;
-      return w >= 2;
-    }
-  }
-  return false;
-}
-
-// radius at which the far part of a pruned row begins (0: no split wanted)
-static double aeam_pforce_near_r(mdp_ctx *c)
-{
-  int ns = 0, nw = 0, wlo = 0;
-  if (!aeam_pforce_geometry(c, &ns, &nw, &wlo)) return 0.0;
-  c->pf_nsub = ns;
-  c->pf_nw = nw;
-  c->pf_wlo = wlo;
-  return (wlo - 1) / c->aeam.rdr[0] + 1.0e-9; // row m covers r in [(m-1) delta, m delta)
-}
-
-static int aeam_pforce_launch(mdp_ctx *c, const int t_begin, const int t_end, bool *done)
-{
-  *done = false;
-  if (!c->prune_valid || !c->prune_nf) return MDP_OK;
-  int nsub = 0, nw = 0, wlo = 0;
-  if (!aeam_pforce_geometry(c, &nsub, &nw, &wlo)) return MDP_OK;
-  if (c->prune_nf_r != (wlo - 1) / c->aeam.rdr[0] + 1.0e-9) return MDP_OK; // rows split for another window
-  *done = true;
-  const int nt = t_end - t_begin;
-  if (nt <= 0) return MDP_OK;
-  const AeamDev &A = c->aeam;
-  PForce P = {};
-  P.nlocal = c->nlocal;
-  P.nclus = c->nclus;
-  P.cap = c->tile_cap;
-  P.capL = (c->tile_maxu + 1 + 7) & ~7;
-  P.rowcapB = (2 * c->tile_rowmax + 15) & ~15;
-  P.t_begin = t_begin;
-  P.t_end = t_end;
-  int grid = (nt + nsub - 1) / nsub;
-  if (grid > c->num_cu) grid = c->num_cu;
-  P.per = (nt + grid - 1) / grid;
-  grid = (nt + P.per - 1) / P.per;
-  P.nw = nw;
-  P.wlo = wlo;
-  P.xq = c->xq.p;
-  P.fp = c->fp.p;
-  P.tu = c->tu.p;
-  P.tile_nu = c->tile_nu.p;
-  P.lj_off = c->lj_off.p;
-  P.lj_len = c->lj_len_in.p;
-  P.lj_split = c->lj_split_in.p;
-  P.lj_near = c->lj_near_in.p;
-  P.lj16 = c->lj16_in.p;
-  P.sd4 = A.pair_sd4;
-  P.f = c->f.p;
-  {
-    const double cut = A.cut[0];
-    double t = cut * cut;
-    while (sqrt(t) > cut) t = nextafter(t, 0.0);
-    while (sqrt(nextafter(t, INFINITY)) <= cut) t = nextafter(t, INFINITY);
-    P.hot_rsqmax = t;
-  }
-  if (const char *ed = getenv("MDP_PF_DBG")) {
-    P.dbg = atoi(ed);
-    if (P.dbg & 4) P.hot_rsqmax = -1.0;
-  }
-  const size_t lds = (size_t) nw * 32 + (size_t) nsub * ((size_t) P.capL * 32 + P.rowcapB);
-  if (nsub == 3) {
-    MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_pforce_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    aeam_pforce_kernel<3><<<grid, 3 * 256, lds, c->stream>>>(c->aeam, P);
-  } else {
-    MDP_HIP(c, hipFuncSetAttribute((const void *) aeam_pforce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    aeam_pforce_kernel<2><<<grid, 2 * 256, lds, c->stream>>>(c->aeam, P);
-  }
-  // the minority pair types: type-0 cluster atoms against segment 1 of their rows (a wave per tile) ...
-  aeam_seg1_force_kernel<<<(nt + 3) / 4, 256, 0, c->stream>>>(c->aeam, c->nlocal, c->nclus, t_begin, t_end, c->xq.p, c->fp.p,
-                                                              c->tile_cap, c->tu.p, c->tile_nu.p, c->lj_off.p,
-                                                              c->lj_len_in.p, c->lj_split_in.p, c->lj16_in.p, c->f.p);
-  // ... and the cluster atoms of the other type (the angular centres: geometry() admits two types and at most 10 % of
-  // them) from their CSR rows, once per compute -- with the launch that holds the last tile
-  if (t_end == c->ntile && c->h_ang_count > 0) {
-    if (c->aeam.nnonangular != 1) return mdp_fail(c, MDP_ESTATE, "aeam: persistent force kernel with nnonangular != 1");
-    aeam_force_kernel<AE_L, 2, false><<<nblk(c->h_ang_count, 256 / AE_L), 256, 0, c->stream>>>(
-        c->aeam, c->h_ang_count, c->xq.p, c->nb_off.p, c->nb.p, c->fp.p, c->f.p, c->eatom.p, c->vatom.p, c->acc.p, 0, 0,
-        c->ang_list.p);
-  }
-  MDP_HIP(c, hipGetLastError());
-  if (getenv("MDP_DEBUG") && !c->ptile_reported[1]) {
-    c->ptile_reported[1] = true;
-    fprintf(stderr, "[mdp] aeam persistent force kernel: %d workgroups x %d sub-blocks, %d tiles each, window rows [%d, %d] of %d "
-                    "(%.1f KB, r >= %.3f A), staging %zu B per sub-block\n",
-            grid, nsub, P.per, P.wlo, A.nr[0], A.nr[0], nw * 32 / 1024.0, (wlo - 1) / A.rdr[0],
-            (size_t) P.capL * 32 + P.rowcapB);
-  }
-  return MDP_OK;
-}
-
 // ---- one compute() in phases ---------------------------------------------------------------------------------------
 // A step of a multi-GPU run hides its exchanges behind the tiles that reach no remote ghost (tiles [0, aeam_split):
 // the shell atoms of a brick are stored behind the interior ones, csrc/domain.hip):
@@ -2344,11 +1660,6 @@ static int aeam_force_tiles(mdp_ctx *c, const int t_begin, const int t_end, cons
   const bool multi = c->aeam.ntypes != 2;
   const size_t lds = (size_t) capL * 4 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
   const bool ev = eflag || vflag;
-  if (!ev) { // force-only steps: the persistent kernel with the far rows of both derivative tables in LDS, when it applies
-    bool persistent = false;
-    MDP_TRY(aeam_pforce_launch(c, t_begin, t_end, &persistent));
-    if (persistent) return MDP_OK;
-  }
 #define MDP_ATF(CLV, EVV, MV)                                                                                        \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
@@ -2404,7 +1715,6 @@ int mdp_aeam_run_begin(mdp_ctx *c, int eflag, int vflag)
   double cut[4];
   aeam_prune_cuts(c, cut);
   bool due = false;
-  c->prune_near_r = aeam_pforce_near_r(c);
   MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin, /*may_prune=*/false, &due));
   if (due) return MDP_OK;
   MDP_TRY(aeam_open(c));
@@ -2430,7 +1740,6 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
       // of the entries of a list built with 1 A of skin on a 6.5 A cutoff are skin
       double cut[4];
       aeam_prune_cuts(c, cut);
-      c->prune_near_r = aeam_pforce_near_r(c); // segment 0 of the pruned rows split where the force kernel's window begins
       MDP_TRY(mdp_prune_upkeep(c, cut, c->cfg.skin, /*may_prune=*/true, nullptr));
     } else
       c->prune_valid = false;
@@ -2638,14 +1947,6 @@ int mdp_aeam_set_tables(mdp_ctx *c, const mdp_aeam_tables *t)
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipStreamSynchronize(c->stream));
     A.pair_d6 = reinterpret_cast<const double2 *>(c->aeam_pair_d8.p);
-    // the (0,0) pair's slopes and value differences: the LDS table of the persistent force kernel
-    MDP_HIP(c, c->aeam_pair_sd4.reserve((size_t) nm1 + 2));
-    pair_sd_kernel<<<(nm1 + 255) / 256, 256, 0, c->stream>>>(nm1, c->aeam_rhor.p + (size_t) t->type2rhor[(size_t) 1 * (nt + 1) + 1] * nm1 * 7,
-                                                              c->aeam_z2r.p + (size_t) t->type2z2r[(size_t) 1 * (nt + 1) + 1] * nm1 * 7,
-                                                              c->aeam_pair_sd4.p);
-    MDP_HIP(c, hipGetLastError());
-    MDP_HIP(c, hipStreamSynchronize(c->stream));
-    A.pair_sd4 = c->aeam_pair_sd4.p;
   }
   c->have_aeam = true;
   return MDP_OK;

@@ -139,10 +139,6 @@ struct AeamDev {
   const double4 *rhor_v4, *rhor_d4, *z2r_v4, *z2r_d4; // the same rows as aligned {c3..c6} / {c0..c2,0} records
   const double2 *rhor_ys, *z2r_ys; // [table][nrmax+1] (value, slope) = columns 6 and 5 of a row: the persistent tile kernels' tables
   const double2 *pair_d6; // [ntypes*ntypes][nrmax+1][3]: {rho' c0 c1 | rho' c2, phi' c0 | phi' c1 c2} of the pair type, 48 B per row
-  // pair type (0,0) only, [nrmax+1]: {S_rho, S_phi, d_rho, d_phi} with S = the row's slope (column 5) and d = Y[m+1]-Y[m]
-  // (column 6): the derivative of a row's Hermite cubic needs S[m], S[m+1], d[m] of each function (pair_aeam.cpp:929-941),
-  // 32 bytes per row -- the table the persistent force kernel keeps in LDS
-  const double4 *pair_sd4;
 };
 
 // 30-bit key of a cell (10 bits per axis) along a 3-D Hilbert curve (Skilling, "Programming the Hilbert curve":
@@ -233,7 +229,6 @@ struct mdp_ctx {
   DevBuf<double> aeam_frho, aeam_rhor, aeam_z2r;
   DevBuf<double4> aeam_rhor_v4, aeam_rhor_d4, aeam_z2r_v4, aeam_z2r_d4;
   DevBuf<double> aeam_pair_d8;
-  DevBuf<double4> aeam_pair_sd4;
   DevBuf<double2> aeam_rhor_ys, aeam_z2r_ys;
   int lds_max = 0, num_cu = 0; // device limits (queried once)
   bool ptile_reported[3] = {false, false, false};
@@ -316,15 +311,6 @@ struct mdp_ctx {
   // until an atom has moved prune_buf/2 since (second trigger of moved_kernel), then they are pruned again
   DevBuf<unsigned short> lj16_in; // pruned rows, at the offsets of the rows as built
   DevBuf<int> lj_len_in, lj_split_in; // their lengths and splits
-  // Optional split of segment 0 of a pruned row into [near | far] (aeam, persistent force kernel): an entry is "near"
-  // when it lies within prune_near_r + prune_buf of a cluster atom of class 0 (or within reach of one of another
-  // class); the far entries then stay beyond prune_near_r until the next pruning, i.e. inside the LDS table window.
-  // lj_near_in[row] = padded length of the near part (0 < near <= split); prune_nf says the current rows carry it.
-  DevBuf<int> lj_near_in;
-  double prune_near_r = 0.0; // request (set by the style before mdp_prune_upkeep / mdp_tile_prune); 0: no split
-  bool prune_nf = false;     // the pruned rows were made with the split ...
-  double prune_nf_r = 0.0;   // ... at this radius
-  int pf_nsub = 0, pf_nw = 0, pf_wlo = 0; // geometry of the persistent force kernel the split was made for
   DevBuf<mdp_hold_t> xhold_prune; // [nall][3] positions at the last pruning
   bool prune_valid = false, prune_stale = false;
   double prune_buf = 0.3;

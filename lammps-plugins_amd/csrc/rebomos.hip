@@ -2323,169 +2323,6 @@ __global__ __launch_bounds__(256) void tile_prune_kernel(const PruneLimits lim, 
   }
 }
 
-// The same pruning with segment 0 of every row split into [near | far] (aeam's persistent force kernel keeps the table
-// rows of the far distances in LDS and reads the near ones -- the first neighbour shells -- from global memory):
-//   near: within sqrt(near_rsq) of a cluster atom of class 0, or within reach (lim) of a cluster atom of another class;
-//   far : every other kept entry -- beyond sqrt(near_rsq) - buffer of all class-0 cluster atoms until the next pruning.
-// Both parts are padded like segments (whole 16-lane steps, the longest of the four rows of a wave); kernels that
-// know nothing of the split walk [0, split) and meet dummy entries in between.  Output goes to a second LDS copy of the
-// rows (a two-way partition cannot be compacted in place); the class of an entry is kept in bits 14-15 of its staged
-// index in between.  When the three padded parts do not fit the row as built, the row's near part is everything.
-template <int CL>
-__global__ __launch_bounds__(256) void tile_prune_nf_kernel(const PruneLimits lim, const double near_rsq, const int nlocal,
-                                                            const int nclus, const double4 *__restrict__ xq, const int cap,
-                                                            const int capL, const int rowcap, const int *__restrict__ tu,
-                                                            const int *__restrict__ tile_nu,
-                                                            const long long *__restrict__ lj_off,
-                                                            const int *__restrict__ lj_split,
-                                                            const unsigned short *__restrict__ lj16,
-                                                            unsigned short *__restrict__ lj16_in, int *__restrict__ len_in,
-                                                            int *__restrict__ split_in, int *__restrict__ near_in)
-{
-  constexpr int L = 16, SK = 3;
-  extern __shared__ double s_pos[]; // [capL][3], then the rows as staged, then the rows as written
-  unsigned short *__restrict__ s_rows = reinterpret_cast<unsigned short *>(s_pos + 3 * (size_t) capL);
-  unsigned short *__restrict__ s_out = s_rows + rowcap;
-  const int tid = threadIdx.x, lane = tid & 63, s = lane % L, glane0 = lane - s;
-  const int t = blockIdx.x;
-  const int kc = t * MDP_TILE + tid / L;
-  const int nU = tile_nu[2 * t];
-  const int *__restrict__ mem = tu + (size_t) t * cap;
-  const long long rb = lj_off[(size_t) t * MDP_TILE];
-  const int rtot = (int) (lj_off[(size_t) t * MDP_TILE + MDP_TILE] - rb); // entries of the whole tile (multiple of 16)
-  {
-    int sidx[SK];
-#pragma unroll
-    for (int k = 0; k < SK; k++) sidx[k] = mem[tid + 256 * k];
-    double4 sv[SK];
-#pragma unroll
-    for (int k = 0; k < SK; k++) sv[k] = xq[tid + 256 * k < nU ? sidx[k] : 0];
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(lj16 + rb);
-    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(s_rows);
-    uint4 *__restrict__ dst2 = reinterpret_cast<uint4 *>(s_out);
-    for (int e = tid; e * 8 < rtot; e += 256) {
-      const uint4 v = src[e];
-      dst[e] = v;
-      dst2[e] = v; // (what lies behind a row's new length stays a valid index)
-    }
-#pragma unroll
-    for (int k = 0; k < SK; k++) {
-      const int u = tid + 256 * k;
-      if (u < nU) {
-        s_pos[3 * u] = sv[k].x;
-        s_pos[3 * u + 1] = sv[k].y;
-        s_pos[3 * u + 2] = sv[k].z;
-      }
-    }
-    for (int u = tid + 256 * SK; u < nU; u += 256) {
-      const double4 v = xq[mem[u]];
-      s_pos[3 * u] = v.x;
-      s_pos[3 * u + 1] = v.y;
-      s_pos[3 * u + 2] = v.z;
-    }
-  }
-  const long long b = lj_off[kc];
-  const int cnt = __builtin_amdgcn_readfirstlane((int) (lj_off[kc + 1] - b));
-  const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
-  unsigned short *__restrict__ row = s_rows + (int) (b - rb);
-  unsigned short *__restrict__ out = s_out + (int) (b - rb);
-  double4 xa[CL];
-  bool real[CL];
-  int ta[CL];
-#pragma unroll
-  for (int c = 0; c < CL; c++) {
-    const int ia = kc * CL + c;
-    real[c] = kc < nclus && ia < nlocal;
-    xa[c] = xq[real[c] ? ia : nlocal - 1];
-    ta[c] = (int) xa[c].w;
-    if (ta[c] < 0) {
-      real[c] = false;
-      ta[c] = 0;
-    }
-    ta[c] = ta[c] > 1 ? 1 : ta[c];
-  }
-  __syncthreads();
-  const unsigned long long below = (1ull << s) - 1ull;
-  // sweep A: classify (bit 15 = kept, bit 14 = near), count
-  int nnear = 0, nfar = 0, n1 = 0;
-#pragma unroll
-  for (int seg = 0; seg < 2; seg++) {
-    const int kb = seg ? split : 0, ke = seg ? cnt : split;
-    double lim_c[CL];
-#pragma unroll
-    for (int c = 0; c < CL; c++) lim_c[c] = lim.rsq[ta[c] * 2 + seg];
-    for (int k = kb; k < ke; k += L) {
-      const int li = (int) row[k + s];
-      bool keep = false, near = false;
-      if (li < nU) {
-        const double xj = s_pos[3 * li], yj = s_pos[3 * li + 1], zj = s_pos[3 * li + 2];
-#pragma unroll
-        for (int c = 0; c < CL; c++) {
-          const double dx = xa[c].x - xj, dy = xa[c].y - yj, dz = xa[c].z - zj;
-          const double rsq = dx * dx + dy * dy + dz * dz;
-          const bool in = real[c] && rsq <= lim_c[c];
-          keep = keep || in;
-          near = near || (in && (ta[c] != 0 || rsq < near_rsq));
-        }
-      }
-      row[k + s] = (unsigned short) (li | (keep ? 0x8000 : 0) | (near ? 0x4000 : 0));
-      const unsigned long long gn = (__ballot(keep && near) >> glane0) & 0xFFFFull;
-      const unsigned long long gf = (__ballot(keep && !near) >> glane0) & 0xFFFFull;
-      if (seg == 0) {
-        nnear += __popcll(gn);
-        nfar += __popcll(gf);
-      } else
-        n1 += __popcll(gn) + __popcll(gf);
-    }
-  }
-  auto pad = [](int n) {
-    int p = (n + 15) & ~15;
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) p = max(p, __shfl_xor(p, o, 64));
-    return p;
-  };
-  int pnear = pad(nnear), pfar = pad(nfar);
-  const int p1 = pad(n1);
-  const bool all_near = pnear + pfar + p1 > cnt; // (wave-uniform: cnt and the padded lengths are)
-  if (all_near) {
-    pnear = pad(nnear + nfar);
-    pfar = 0;
-  }
-  // sweep B: fill (LDS only)
-  int wn = 0, wf = 0, w1 = 0;
-  for (int k = 0; k < split; k += L) {
-    const int code = (int) row[k + s];
-    const bool keep = (code & 0x8000) != 0, near = all_near || (code & 0x4000) != 0;
-    const unsigned long long gn = (__ballot(keep && near) >> glane0) & 0xFFFFull;
-    const unsigned long long gf = (__ballot(keep && !near) >> glane0) & 0xFFFFull;
-    if (keep && near) out[wn + __popcll(gn & below)] = (unsigned short) (code & 0x3FFF);
-    if (keep && !near) out[pnear + wf + __popcll(gf & below)] = (unsigned short) (code & 0x3FFF);
-    wn += __popcll(gn);
-    wf += __popcll(gf);
-  }
-  for (int q = wn + s; q < pnear; q += L) out[q] = (unsigned short) nU;
-  for (int q = wf + s; q < pfar; q += L) out[pnear + q] = (unsigned short) nU;
-  for (int k = split; k < cnt; k += L) {
-    const int code = (int) row[k + s];
-    const bool keep = (code & 0x8000) != 0;
-    const unsigned long long g = (__ballot(keep) >> glane0) & 0xFFFFull;
-    if (keep) out[pnear + pfar + w1 + __popcll(g & below)] = (unsigned short) (code & 0x3FFF);
-    w1 += __popcll(g);
-  }
-  for (int q = w1 + s; q < p1; q += L) out[pnear + pfar + q] = (unsigned short) nU;
-  if (s == 0) {
-    near_in[kc] = pnear;
-    split_in[kc] = pnear + pfar;
-    len_in[kc] = pnear + pfar + p1;
-  }
-  __syncthreads();
-  {
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(s_out);
-    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(lj16_in + rb);
-    for (int e = tid; e * 8 < rtot; e += 256) dst[e] = src[e];
-  }
-}
-
 // does the tile's union reach a remote ghost?  Such tiles wait for the halo.
 __global__ __launch_bounds__(256) void tile_boundary_kernel(const int ntile, const int cap, const int remote_start,
                                                             const int *__restrict__ tile_nu,
@@ -3397,27 +3234,8 @@ int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
   const size_t lds = (size_t) capL * 3 * sizeof(double) + (size_t) 2 * c->tile_rowmax + 32;
   if (c->tile_rowmax <= 0 || lds > 160 * 1024) { // (rows of a tile do not fit LDS next to its union: no pruning)
     c->prune_valid = false;
-    c->prune_nf = false;
     return MDP_OK;
   }
-  // segment 0 split into [near | far] on request of the style (aeam: prune_near_r = where the LDS window of its
-  // persistent force kernel begins); class bits ride in bits 14-15 of the staged indices
-  const int rowcap = (c->tile_rowmax + 15) & ~7;
-  const size_t lds_nf = (size_t) capL * 3 * sizeof(double) + (size_t) 4 * rowcap + 32;
-  const bool nf = c->prune_near_r > 0.0 && c->tile_rows_cl == 2 && c->tile_cap < 0x3FFF && lds_nf <= 160 * 1024;
-  c->prune_nf = nf;
-  c->prune_nf_r = nf ? c->prune_near_r : 0.0;
-  if (nf) {
-    MDP_HIP(c, c->lj_near_in.reserve(nrow + 1));
-    const double rn = c->prune_near_r + c->prune_buf;
-    if (lds_nf > 48 * 1024)
-      MDP_HIP(c, hipFuncSetAttribute((const void *) tile_prune_nf_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int) lds_nf));
-    tile_prune_nf_kernel<2><<<c->ntile, 256, lds_nf, st>>>(lim, rn * rn, c->nlocal, c->nclus, c->xq.p, c->tile_cap, capL,
-                                                           rowcap, c->tu.p, c->tile_nu.p, c->lj_off.p, c->lj_split.p,
-                                                           c->lj16.p, c->lj16_in.p, c->lj_len_in.p, c->lj_split_in.p,
-                                                           c->lj_near_in.p);
-  } else {
 #define MDP_TP(CLV)                                                                                                    \
   do {                                                                                                                 \
     if (lds > 48 * 1024)                                                                                               \
@@ -3427,12 +3245,11 @@ int mdp_tile_prune(mdp_ctx *c, const double lim_rsq[4])
                                                        c->tile_nu.p, c->lj_off.p, c->lj_split.p, c->lj16.p,            \
                                                        c->lj16_in.p, c->lj_len_in.p, c->lj_split_in.p);               \
   } while (0)
-    if (c->tile_rows_cl == 1)
-      MDP_TP(1);
-    else
-      MDP_TP(2);
+  if (c->tile_rows_cl == 1)
+    MDP_TP(1);
+  else
+    MDP_TP(2);
 #undef MDP_TP
-  }
   if (c->nall) hold_all_kernel<<<(c->nall + 255) / 256, 256, 0, st>>>(c->nall, c->xq.p, c->xhold_prune.p);
   MDP_HIP(c, hipGetLastError());
   c->prune_valid = true;
