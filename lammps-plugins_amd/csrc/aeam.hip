@@ -1020,14 +1020,38 @@ __global__ __launch_bounds__(256) void aeam_density_ang_kernel(const AeamDev A, 
 }
 
 // ---- pass 2 (pair_aeam.cpp:264-303, 329-332) -----------------------------------------------------------
+// nimg > 0 (resident runs): threads nlocal .. nlocal + nimg serve the periodic self-images -- the style's forward_comm
+// of fp on one rank (pair_aeam.cpp:307, 946-963) -- by evaluating their OWNER's embedding once more (a table row and
+// thirty flops against a kernel launch of its own); an image of another rank's atom (owner < 0) waits for the exchange.
 __global__ __launch_bounds__(256) void aeam_embed_kernel(const AeamDev A, const int nlocal,
                                                          const double4 *__restrict__ xq,
                                                          const double *__restrict__ rho, double *__restrict__ fp,
                                                          double *__restrict__ eatom, double *__restrict__ acc,
-                                                         const int eflag, const int accumulate)
+                                                         const int eflag, const int accumulate, const int nimg = 0,
+                                                         const int *__restrict__ img_owner = nullptr)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   double e = 0.0;
+  if (i >= nlocal && i < nlocal + nimg) {
+    const int o = img_owner[i - nlocal];
+    if (o >= 0) {
+      const int ti = (int) xq[o].w;
+      const bool metal = ti < A.nnonangular;
+      const double rh = rho[o];
+      const double u = metal ? rh : sqrt(rh);
+      const int nrho_t = A.g_nrho[ti];
+      double p = u * A.g_rdrho[ti] + 1.0;
+      int m = (int) p;
+      m = m < nrho_t - 1 ? m : nrho_t - 1;
+      m = m > 1 ? m : 1;
+      p -= m;
+      p = p < 1.0 ? p : 1.0;
+      const double *c = A.frho + ((size_t) A.g_t2frho[ti] * (A.nrhomax + 1) + m) * 7;
+      double fptmp = 0.0;
+      if (rh > 0.0000000000001) fptmp = metal ? 1.0 : 0.5 / sqrt(rh);
+      fp[i] = fptmp * sp_der(c, p); // (the same operations as the owner's thread below: bit-identical)
+    }
+  }
   if (i < nlocal) {
     const int ti = (int) xq[i].w;
     const bool metal = ti < A.nnonangular;
@@ -1228,8 +1252,11 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
                                                              const int *__restrict__ nb, const double *__restrict__ fp,
                                                              double *__restrict__ f, double *__restrict__ vatom,
                                                              double *__restrict__ acc, int *__restrict__ flags,
-                                                             const int vflag)
+                                                             const int vflag, const int nlocal = 0,
+                                                             const int *__restrict__ img_owner = nullptr)
 {
+  // img_owner (resident runs): what lands on a periodic self-image is added to its owner at once -- the host's
+  // reverse_comm on one rank -- instead of being folded by a kernel of its own afterwards
   __shared__ double s_rec[4][ANG_CAP * AREC];
   __shared__ int s_j[4][ANG_CAP];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1313,7 +1340,11 @@ __global__ __launch_bounds__(256) void aeam_force_ang_kernel(const AeamDev A, co
   for (int a = lane; a < n; a += 64) { // one flush per neighbour (ghosts included: the host's reverse comm folds them)
     const double *qa = rec + a * AREC;
     if (qa[7] != 0.0 || qa[8] != 0.0 || qa[9] != 0.0) {
-      const int jj = jdx[a] & MDP_NEIGHMASK;
+      int jj = jdx[a] & MDP_NEIGHMASK;
+      if (img_owner && jj >= nlocal) {
+        const int o = img_owner[jj - nlocal];
+        jj = o >= 0 ? o : jj;
+      }
       atomicAdd(&f[3 * (size_t) jj], qa[7]);
       atomicAdd(&f[3 * (size_t) jj + 1], qa[8]);
       atomicAdd(&f[3 * (size_t) jj + 2], qa[9]);
@@ -1388,14 +1419,24 @@ __global__ void pair_der_kernel(const int npair, const int nm1, const int *__res
 
 // owned angular centres; count[0] = their number, count[2] = 1 when one of them sits in a tile at or behind
 // count[1] = the first tile whose union reaches a remote ghost (its row may then hold one: ghost forces must travel)
-__global__ void ang_list_kernel(const AeamDev A, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
+__global__ void ang_list_kernel(const int nnonangular, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
                                 int *__restrict__ count, const int atoms_per_tile)
 {
+  // one atomic per wave, not per centre: 7 500 single-lane atomics on one counter took 0.2 ms per reneighboring
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nlocal) return;
-  if ((int) xq[i].w >= A.nnonangular) {
-    list[atomicAdd(count, 1)] = i;
-    if (i / atoms_per_tile >= count[1]) count[2] = 1;
+  const bool ang = i < nlocal && (int) xq[i < nlocal ? i : 0].w >= nnonangular;
+  const unsigned long long b = __ballot(ang);
+  if (!b) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long) b) - 1) base = atomicAdd(count, __popcll(b));
+  base = __shfl(base, __ffsll((long long) b) - 1, 64);
+  if (ang) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+  // (thousands of plain stores to ONE word are as slow as atomics on it -- 0.2 ms per reneighboring: one store per wave,
+  //  and none in a run without remote ghosts, where nobody reads the word)
+  if (atoms_per_tile > 0) {
+    const bool reach = ang && i / atoms_per_tile >= count[1];
+    if (__any(reach) && lane == __ffsll((long long) b) - 1) count[2] = 1;
   }
 }
 
@@ -1447,6 +1488,7 @@ int mdp_aeam_prepare(mdp_ctx *c)
   c->aeam_split = 0;
   c->aeam_ang_remote = false;
   c->aeam_phase = 0;
+  c->f_prezeroed = false; // (the atom arrays were rebuilt or re-ordered)
   const char *e = getenv("MDP_AEAM_TILE");
   // (tile kernels: up to MDP_AEAM_MAXT types -- their parameter block lives in the kernel arguments / in LDS)
   if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0) && c->aeam.ntypes <= MDP_AEAM_MAXT) {
@@ -1471,8 +1513,8 @@ int mdp_aeam_prepare(mdp_ctx *c)
       tile_first_remote_kernel<<<nblk(c->ntile, 4), 256, 0, st>>>(c->ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
                                                                   c->tu.p, c->ang_count.p);
     if (c->nlocal)
-      ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p,
-                                                            kTile * c->aeam_cl);
+      ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam.nnonangular, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p,
+                                                            remote && c->aeam_tiled ? kTile * c->aeam_cl : 0);
     MDP_HIP(c, hipGetLastError());
     int h[3] = {0, 0, 0};
     MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof h, h));
@@ -1612,7 +1654,9 @@ static int aeam_open(mdp_ctx *c)
   if (c->aeam_phase & AE_OPEN) return MDP_OK;
   if (!c->have_aeam || !c->neigh_set) return mdp_fail(c, MDP_ESTATE, "aeam: tables / neighbor list not set");
   MDP_TRY(mdp_acc_begin(c, true));
-  MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, c->stream));
+  if (!c->f_prezeroed) // (resident runs on one GPU: the integrate kernel and the image refresh of this step did it)
+    MDP_HIP(c, hipMemsetAsync(c->f.p, 0, sizeof(double) * 3 * c->nall, c->stream));
+  c->f_prezeroed = false;
   c->aeam_phase |= AE_OPEN;
   return MDP_OK;
 }
@@ -1694,7 +1738,8 @@ static int aeam_ang_forces(mdp_ctx *c, const int vflag)
     aeam_force_ang_kernel<<<nblk(c->h_ang_count, 4), 256, 0, c->stream>>>(c->aeam, c->h_ang_count, c->ang_list.p,
                                                                           c->xq.p, c->nb_off.p, c->nb.p, c->fp.p,
                                                                           c->f.p, c->vatom.p, c->acc.p, c->flags.p,
-                                                                          vflag);
+                                                                          vflag, c->nlocal,
+                                                                          c->md ? c->ghost_owner.p : nullptr);
   MDP_HIP(c, hipGetLastError());
   c->aeam_phase |= AE_ANG_F;
   return MDP_OK;
@@ -1767,9 +1812,12 @@ int mdp_aeam_run_density(mdp_ctx *c, int eflag)
   MDP_HIP(c, hipGetLastError());
   mdp_span_end(c, 1);
   mdp_span_begin(c, 2);
+  // resident runs: the periodic self-images [nlocal, remote_start) get their fp in the same launch
+  const int nimg = c->md && c->ghost_owner.p ? (c->remote_start >= nlocal && c->remote_start <= c->nall ? c->remote_start - nlocal : c->nghost) : 0;
   if (nlocal)
-    aeam_embed_kernel<<<nblk(nlocal, 256), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->rho.p, c->fp.p, c->eatom.p,
-                                                         c->acc.p, eflag, /*accumulate=*/0);
+    aeam_embed_kernel<<<nblk(nlocal + nimg, 256), 256, 0, st>>>(c->aeam, nlocal, c->xq.p, c->rho.p, c->fp.p, c->eatom.p,
+                                                                c->acc.p, eflag, /*accumulate=*/0, nimg, c->ghost_owner.p);
+  c->aeam_img_fp = nlocal > 0 && nimg > 0;
   MDP_HIP(c, hipGetLastError());
   mdp_span_end(c, 2);
   c->aeam_phase |= AE_DENS;

@@ -194,8 +194,15 @@ __global__ __launch_bounds__(256) void nbuild_list_kernel(const Grid g, const Cu
 __global__ void ang_select_kernel(const int nlocal, const int min_type, const double4 *__restrict__ xq,
                                   int *__restrict__ list, int *__restrict__ count)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nlocal && (int) xq[i].w >= min_type) list[atomicAdd(count, 1)] = i;
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool sel = i < nlocal && (int) xq[i < nlocal ? i : 0].w >= min_type;
+  const unsigned long long b = __ballot(sel); // one atomic per wave (thousands on one counter cost 70 us)
+  if (!b) return;
+  const int leader = __ffsll((long long) b) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, __popcll(b));
+  base = __shfl(base, leader, 64);
+  if (sel) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
 }
 
 // fix nve on the device.  FINAL: the final_integrate of the step just finished and the initial_integrate of the next
@@ -206,9 +213,9 @@ __global__ void ang_select_kernel(const int nlocal, const int min_type, const do
 // SC: the style-level checks and the accumulator reset of the compute that follows, in the same pass (MdpStyleCheck).
 template <bool FINAL, bool CHECK>
 __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
-                                   const double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
+                                   double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
                                    const mdp_hold_t *__restrict__ xhold, const double trigsq, const double hardsq,
-                                   int *__restrict__ flag, const MdpStyleCheck SC)
+                                   int *__restrict__ flag, const MdpStyleCheck SC, const int zero_f)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool t = false, h = false, sa = false, sah = false, sp = false, sph = false;
@@ -226,6 +233,11 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
   if (i < nlocal) {
     const double s = dtf / rmass[i];
     const double fx = f[3 * (size_t) i], fy = f[3 * (size_t) i + 1], fz = f[3 * (size_t) i + 2];
+    if (zero_f) { // the forces have had their last reader: force_clear of the next compute (a style that accumulates)
+      f[3 * (size_t) i] = 0.0;
+      f[3 * (size_t) i + 1] = 0.0;
+      f[3 * (size_t) i + 2] = 0.0;
+    }
     double vx = v[3 * (size_t) i], vy = v[3 * (size_t) i + 1], vz = v[3 * (size_t) i + 2];
     if (FINAL) { // final_integrate (step n)
       vx += s * fx;
@@ -286,10 +298,16 @@ __global__ void nve_final_kernel(int nlocal, double dtf, const double *__restric
 }
 
 __global__ void ghost_refresh_kernel(int nlocal, int nghost, const int *__restrict__ owner,
-                                     const double *__restrict__ shift, double4 *__restrict__ xq)
+                                     const double *__restrict__ shift, double4 *__restrict__ xq,
+                                     double *__restrict__ fzero = nullptr)
 {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= nghost) return;
+  if (fzero) { // force_clear of the compute that follows, for the images (the integrate kernel does the owned atoms)
+    fzero[3 * (size_t) (nlocal + g)] = 0.0;
+    fzero[3 * (size_t) (nlocal + g) + 1] = 0.0;
+    fzero[3 * (size_t) (nlocal + g) + 2] = 0.0;
+  }
   const int o = owner[g];
   if (o < 0) return;
   const double4 xo = xq[o];
@@ -756,18 +774,20 @@ void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc)
   }
   c->sflag_chk = sc;
   c->sflag_armed = sc.flag != nullptr;
-  if (!c->sflag_armed) c->sflag_pending = false;
+  c->sflag_committed[set] = false; // (what this set held was collected a step ago, or never will be)
 }
 
 int mdp_sflag_commit(mdp_ctx *c)
 {
   if (!c->sflag_armed) return MDP_OK;
-  if (!c->ev_sflag) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_sflag, hipEventDisableTiming));
-  MDP_HIP(c, hipEventRecord(c->ev_sflag, c->stream));
-  c->sflag_pending = true;
-  c->sflag_read_set = c->sflag_set;
+  const int set = c->sflag_set;
+  if (!c->ev_sflag[set]) MDP_HIP(c, hipEventCreateWithFlags(&c->ev_sflag[set], hipEventDisableTiming));
+  MDP_HIP(c, hipEventRecord(c->ev_sflag[set], c->stream));
+  c->sflag_committed[set] = true;
   return MDP_OK;
 }
+
+void mdp_sflag_drop(mdp_ctx *c) { c->sflag_committed[0] = c->sflag_committed[1] = false; }
 
 // the words of the step before (their last writer was queued a whole compute ago).  *far / *toofar: the style lists'
 // trigger / half their skin, valid only if no list build happened since the check was armed; the pruning part is
@@ -776,10 +796,13 @@ int mdp_sflag_collect(mdp_ctx *c, bool *far, bool *toofar)
 {
   if (far) *far = false;
   if (toofar) *toofar = false;
-  if (!c->sflag_pending) return MDP_OK;
-  MDP_HIP(c, hipEventSynchronize(c->ev_sflag));
-  c->sflag_pending = false;
-  const int set = c->sflag_read_set;
+  // the set of the step BEFORE the one whose integrate kernel was queued last: its writers ran a whole compute ago
+  // (the set being written now is read by the next compute -- the triggers fire early by kStaleMargin / kPruneMargin
+  // for exactly this one compute of delay)
+  const int set = c->sflag_set ^ 1;
+  if (!c->sflag_committed[set]) return MDP_OK;
+  MDP_HIP(c, hipEventSynchronize(c->ev_sflag[set]));
+  c->sflag_committed[set] = false;
   const int *h = (const int *) (c->h_pinned + 32) + 8 * set;
   const MdpStyleCheckMeta &m = c->sflag_meta[set];
   if (m.has_style && m.build_epoch == c->style_builds) {
@@ -803,13 +826,18 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
   if (c->final_deferred_seen && with_final && !c->final_pending) with_final = false;
   if (with_final) c->final_pending = false;
   const double dtf = 0.5 * c->cfg.dt * c->cfg.ftm2v;
+  // aeam accumulates into f (three-body atomics, tile kernels): its force_clear rides in this kernel and in the refresh
+  // of the images when every ghost is a periodic self-image (one GPU).  The flag is dropped by whatever rebuilds or
+  // re-orders the atom arrays before the compute (mdp_aeam_prepare) -- the compute then clears f itself.
+  const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
+  const bool zero_f = c->cfg.style == 2 && c->nlocal > 0 && nself == c->nghost && c->neigh_set && c->f.p;
   if (c->nlocal) {
     const int g = nblk(c->nlocal);
     MdpStyleCheck sc;
     mdp_sflag_arm(c, sc);
 #define MDP_ADV(FV, CV)                                                                                               \
   nve_advance_kernel<FV, CV><<<g, 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p, c->xq.p, \
-                                                      c->xhold.p, trigsq, hardsq, flag, sc)
+                                                      c->xhold.p, trigsq, hardsq, flag, sc, zero_f ? 1 : 0)
     if (with_final) {
       if (flag) MDP_ADV(true, true);
       else MDP_ADV(true, false);
@@ -823,10 +851,11 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
     if (!(c->remote_start < c->nall)) MDP_TRY(mdp_sflag_commit(c));
   }
   // periodic self-images come first in the ghost range; remote ghosts are refreshed by the halo exchange
-  const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
   if (nself)
-    ghost_refresh_kernel<<<nblk(nself), 256, 0, c->stream>>>(c->nlocal, nself, c->ghost_owner.p, c->ghost_shift.p, c->xq.p);
+    ghost_refresh_kernel<<<nblk(nself), 256, 0, c->stream>>>(c->nlocal, nself, c->ghost_owner.p, c->ghost_shift.p, c->xq.p,
+                                                             zero_f ? c->f.p : nullptr);
   MDP_HIP(c, hipGetLastError());
+  c->f_prezeroed = zero_f;
   return MDP_OK;
 }
 
@@ -872,8 +901,9 @@ int mdp_md_aeam_density(mdp_ctx *c, int eflag)
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
   if (c->cfg.style != 2) return mdp_fail(c, MDP_EINVAL, "not an aeam sub-domain");
   MDP_TRY(mdp_aeam_run_density(c, eflag));
-  // forward comm of fp on one rank: periodic self-images copy their owner's value
-  if (c->nghost)
+  // forward comm of fp on one rank: periodic self-images copy their owner's value -- normally done by the embedding
+  // kernel itself (aeam_img_fp)
+  if (c->nghost && !c->aeam_img_fp)
     ghost_scalar_refresh_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
                                                                         c->fp.p);
   MDP_HIP(c, hipGetLastError());
@@ -892,6 +922,9 @@ int mdp_md_fold_self_ghost_f(mdp_ctx *c)
 {
   if (!c) return MDP_EINVAL;
   if (!c->md) return mdp_fail(c, MDP_ESTATE, "mdp_md_setup not called");
+  // aeam: the three-body kernel adds what belongs to a periodic self-image to its owner directly (img_owner), so
+  // nothing is left on the images; rebomos writes nothing to ghosts at all
+  if (c->cfg.style == 2) return MDP_OK;
   if (c->nghost)
     fold_self_ghost_f_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p, c->f.p);
   MDP_HIP(c, hipGetLastError());
@@ -1028,7 +1061,7 @@ int mdp_md_upload_x(mdp_ctx *c, const double *x)
   c->prune_valid = false;
   c->prune_stale = false;
   c->prune_epoch++;
-  c->sflag_pending = false;
+  mdp_sflag_drop(c);
   c->check_now = true;
   return MDP_OK;
 }
@@ -1182,7 +1215,7 @@ int mdp_md_list_state(mdp_ctx *c, double out[8])
   out[2] = c->prune_valid ? c->prune_buf : 0.0;
   out[3] = (double) c->dangerous_builds;
   if (c->h_pinned) {
-    const int *h = (const int *) (c->h_pinned + 40);
+    const int *h = (const int *) (c->h_pinned + 40) + 4 * c->ovf_par; // (the set the last compute published)
     out[4] = (double) h[0] + h[1] + h[2] + h[3];
   }
   out[5] = (c->ovf3_hot[0] > 0 || c->ovf3_hot[1] > 0 || c->ovf3_hot[2] > 0 || c->ovf3_hot[3] > 0) ? 1.0 : 0.0;

@@ -861,6 +861,7 @@ int mdp_destroy(mdp_ctx *c)
   c->lj16_in.release();
   c->lj_len_in.release();
   c->lj_split_in.release();
+  c->cand_stage.release();
   c->xhold_prune.release();
   c->tile_nu.release();
   c->tile_flag.release();
@@ -915,7 +916,8 @@ int mdp_destroy(mdp_ctx *c)
   c->sort_keys_b.release();
   c->sort_vals_b.release();
   c->nb_cnt.release();
-  if (c->ev_sflag) (void) hipEventDestroy(c->ev_sflag);
+  for (int k = 0; k < 2; k++)
+    if (c->ev_sflag[k]) (void) hipEventDestroy(c->ev_sflag[k]);
   if (c->h_pinned) (void) hipHostFree(c->h_pinned);
   if (c->h_small) (void) hipHostFree(c->h_small);
   c->h_small = nullptr;
@@ -953,7 +955,7 @@ double mdp_device_bytes(const mdp_ctx *c)
   const MdpDomain &D = c->dd;
   const size_t parts[] = {
       c->aeam_frho.bytes(), c->aeam_rhor.bytes(), c->aeam_z2r.bytes(), c->aeam_rhor_v4.bytes(),
-      c->aeam_rhor_d4.bytes(), c->aeam_z2r_v4.bytes(), c->aeam_z2r_d4.bytes(), c->aeam_pair_d8.bytes(),
+      c->aeam_rhor_d4.bytes(), c->aeam_z2r_v4.bytes(), c->aeam_z2r_d4.bytes(), c->aeam_pair_d8.bytes(), c->cand_stage.bytes(),
       c->aeam_rhor_ys.bytes(), c->aeam_z2r_ys.bytes(), c->aeam_maps.bytes(), c->xq.bytes(), c->xraw.bytes(),
       c->host_perm.bytes(), c->host_tagmap.bytes(), c->host_inv.bytes(), c->host_tag_dev.bytes(), c->host_img.bytes(), c->host_stage.bytes(), c->tag.bytes(), c->type.bytes(), c->f.bytes(),
       c->eatom.bytes(), c->vatom.bytes(), c->acc.bytes(), c->flags.bytes(), c->nb_off.bytes(), c->nb.bytes(),

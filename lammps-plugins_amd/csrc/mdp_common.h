@@ -85,7 +85,8 @@ struct RebomosDev {
 // were built / half the pruning buffer since the rows were pruned?) ride in kernels that touch the positions anyway:
 // owned atoms in the integrate kernel, remote ghosts in the halo unpack; periodic self-images move with their owners.
 // Flag words are pinned host memory, two sets used alternately (the words of step n are read during step n+1, after
-// the integrate kernel of step n+1 was queued): [0] beyond the list trigger [1] beyond half the inner skin [2] beyond
+// the integrate kernel of step n+1 was queued -- never in the step that writes them, which would be a host wait on a
+// kernel just launched): [0] beyond the list trigger [1] beyond half the inner skin [2] beyond
 // the pruning trigger [3] beyond half the buffer; [4..7] the same for remote ghosts.
 // Reference positions of the displacement checks (at the last reneighboring, style-list build, row pruning): single
 // precision -- the triggers have margins of 0.07-0.1 A, a float resolves 6e-5 A at |x| = 1000 A -- which takes 36 of
@@ -321,6 +322,10 @@ struct mdp_ctx {
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
+  int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
+  bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
+  bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too
+  DevBuf<int> cand_stage;         // [nall][64] candidate rows at a fixed stride, written by the counting sweep of a list build
   DevBuf<int> class_list;         // [MDP_NCLASS][nall]   class = 2 * (lane-group size index) + element
   DevBuf<int> class_count;        // [MDP_NCLASS]
   DevBuf<int> pk_cand;            // per class, per centre: its first UA*G candidates, contiguous in class order
@@ -341,11 +346,14 @@ struct mdp_ctx {
   long long style_builds = 0;     // number of style-list builds so far
   long long dangerous_builds = 0; // deferred check saw an atom beyond half the inner skin
   // fused style-level checks (MdpStyleCheck): set armed by the last integrate kernel, event of its last writer
-  int sflag_set = 0, sflag_read_set = 0;
-  bool sflag_armed = false, sflag_pending = false;
+  // The words of a set are READ one compute after they were written (mdp_sflag_collect takes the set of the step
+  // before, whose event completed long ago): no host wait on the GPU in the step, on one GPU as on several.
+  int sflag_set = 0;
+  bool sflag_armed = false;
+  bool sflag_committed[2] = {false, false}; // the set's last writer has been queued (event recorded), not yet collected
   MdpStyleCheck sflag_chk;
   MdpStyleCheckMeta sflag_meta[2];
-  hipEvent_t ev_sflag = nullptr;
+  hipEvent_t ev_sflag[2] = {nullptr, nullptr};
   bool final_pending = false;      // the host deferred the final half-kick of the finished step (mdp_md_defer_final)
   bool final_deferred_seen = false; // the host uses mdp_md_defer_final at all (older hosts: with_final is authoritative)
   bool acc_prezeroed = false; // the integrate kernel reset the accumulators: the next mdp_acc_begin launches nothing
@@ -475,6 +483,7 @@ int mdp_to_device_order(mdp_ctx *c, int n, int w, const double *d_src, double *d
 int mdp_acc_begin(mdp_ctx *c, bool any); // zero acc (+ slots when any energy/virial is tallied)
 void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc);  // before the integrate kernel: which references, which flag set
 int mdp_sflag_commit(mdp_ctx *c);                   // behind the last kernel that writes this step's flag words
+void mdp_sflag_drop(mdp_ctx *c);                    // positions were rewritten outside the integrator: flag words in flight say nothing
 int mdp_sflag_collect(mdp_ctx *c, bool *far, bool *toofar); // flags of the previous step (waits for their event): style part returned, pruning part applied
 int mdp_acc_end(mdp_ctx *c, bool any);   // fold the slots into acc[0..6]
 int mdp_flags_check(mdp_ctx *c, const int *hflags5); // overflow bits (last compute | sticky) -> MDP_EOVERFLOW

@@ -2351,6 +2351,11 @@ constexpr int RP_L = 16; // lanes per atom in the list-building kernels
 // REBO candidate lists (r <= rcmax + inner skin) straight from the bin grid.
 // MODE 0: count for owned atoms and mark the ghost atoms that neighbour them (they are centres too)
 // MODE 1: count for the marked ghosts            MODE 2: fill (all atoms with a non-empty row)
+// One sweep instead of two: MODES 0 and 1 also WRITE what they count, into rows of a fixed stride kCandStride (`off`
+// null, `cand` = the staging rows; a row holds what the 64-bit active mask can address, longer rows stop the build
+// anyway), and cand_compact_kernel moves them to their CSR offsets once the counts are scanned -- same candidates in
+// the same order as the second sweep (MODE 2, kept for MDP_CAND_TWO_PASS=1) writes.
+constexpr int kCandStride = 64;
 template <int MODE>
 __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const int R, const RebomosDev P,
                                                          const int nall, const int nlocal,
@@ -2393,6 +2398,7 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
   }
   int n = 0;
   int *row = (MODE == 2 && have) ? cand + off[i] : nullptr;
+  int *stage = (MODE != 2 && have && cand) ? cand + (size_t) i * kCandStride : nullptr;
   const unsigned long long below = (1ull << s) - 1ull;
   for (int z = wzlo; z <= wzhi; z++)
     for (int y = wylo; y <= wyhi; y++) {
@@ -2417,12 +2423,27 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
         const unsigned long long bk = (__ballot(keep) >> glane0) & 0xFFFFull;
         if (keep) {
           if (MODE == 2) row[n + __popcll(bk & below)] = j;
+          if (MODE != 2 && stage && n + __popcll(bk & below) < kCandStride) stage[n + __popcll(bk & below)] = j;
           if (MODE == 0 && j >= mark_from) is_centre[j] = 1;
         }
         n += __popcll(bk);
       }
     }
   if (MODE != 2 && have && s == 0) cnt[i] = n;
+}
+
+// staging rows -> CSR (RP_L lanes per atom; rows longer than the stride are truncated here and refused by rev_kernel)
+__global__ __launch_bounds__(256) void cand_compact_kernel(const int nall, const int *__restrict__ off,
+                                                           const int *__restrict__ stage, int *__restrict__ cand)
+{
+  const int s = threadIdx.x % RP_L;
+  const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
+  if (i64 >= nall) return;
+  const int i = (int) i64, b = off[i];
+  int n = off[i + 1] - b;
+  n = n < kCandStride ? n : kCandStride;
+  const int *__restrict__ src = stage + (size_t) i * kCandStride;
+  for (int k = s; k < n; k += RP_L) cand[b + k] = src[k];
 }
 
 // positions at list-build time (all atoms, ghosts included) and the displacement trigger
@@ -2812,14 +2833,20 @@ int mdp_rebomos_repack(mdp_ctx *c)
   const int *tag_dev = host_images ? c->host_tag_dev.p : c->tag.p; // tags in the device's atom order
   const int per_block = 256 / RP_L;
   const int nghost = nall - nlocal;
+  static const bool two_pass = getenv("MDP_CAND_TWO_PASS") && atoi(getenv("MDP_CAND_TWO_PASS")) != 0; // (A/B, tests)
+  int *stage = nullptr;
+  if (!two_pass) {
+    MDP_HIP(c, c->cand_stage.reserve((size_t) nall * kCandStride + kCandStride));
+    stage = c->cand_stage.p;
+  }
   if (nlocal)
     cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        nullptr, c->is_center.p, self_end);
+        stage, c->is_center.p, self_end);
   if (nghost)
     cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        nullptr, c->is_center.p, self_end);
+        stage, c->is_center.p, self_end);
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
   // Lennard-Jones lists: tile lists for the default cluster size, unless switched off or a union outgrows LDS
@@ -2909,7 +2936,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->fnbr.reserve((size_t) 4 * cand_total + 4));
   MDP_HIP(c, c->fown.reserve((size_t) 4 * nall + 4));
   MDP_HIP(c, hipMemsetAsync(c->fown.p, 0, sizeof(double) * 4 * nall, st)); // atoms that are no centre (NULL type) keep 0
-  if (nall)
+  if (nall && stage)
+    cand_compact_kernel<<<(nall + per_block - 1) / per_block, 256, 0, st>>>(nall, c->cand_off.p, stage, c->cand.p);
+  else if (nall)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p, self_end);
@@ -3147,7 +3176,7 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
     return MDP_OK;
   }
   if (!c->md || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
-    c->sflag_pending = false; // (words of a check armed before the positions were rewritten)
+    mdp_sflag_drop(c); // (words of a check armed before the positions were rewritten)
     c->check_now = false;
     MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
     MDP_HIP(c, hipStreamSynchronize(c->stream));
@@ -3186,12 +3215,14 @@ static void launch_centre3(mdp_ctx *c, int eflag, int vflag, int part)
     const int n = c->h_class_count[k];
     if (n <= 0) continue;
     // Its centres with a fourth neighbour (S-S pairs of MoS2 dip below rcmax at 300 K) are counted per (part, elem);
-    // the count of a step is published to a pinned word by the last centre kernel of the step (read here a step or two
-    // late, no synchronisation).  While it is zero -- a cold crystal -- such a centre goes straight to the general
+    // the count of a step is published to a pinned word by the last centre kernel of the step and read here TWO computes
+    // later, without a wait of its own: two sets of words alternate (ovf_par), and the set read now was written by the
+    // compute before the last, which the deferred displacement check of this compute has waited for (mdp_sflag_collect)
+    // -- so the choice of path below is the same in every run of the same trajectory.  While it is zero -- a cold crystal -- such a centre goes straight to the general
     // kernel's list; once centres do overflow they are collected on a list of their own ...
     const int q = part * 2 + elem;
     int *list = c->ovf.p + (size_t) (q + 1) * c->ovf_stride + 1; // (count at list[-1]; zeroed with the accumulators)
-    int *h_cnt = (int *) (c->h_pinned + 40) + q;
+    int *h_cnt = (int *) (c->h_pinned + 40) + 4 * c->ovf_par + q;
     if (*h_cnt > 0) c->ovf3_hot[q] = 64;      // (hysteresis: stay in list mode for 64 computes after the last overflow)
     else if (c->ovf3_hot[q] > 0) c->ovf3_hot[q]--;
     const bool list_mode = c->ovf3_hot[q] > 0;
@@ -3201,10 +3232,13 @@ static void launch_centre3(mdp_ctx *c, int eflag, int vflag, int part)
                                                                 c->fown.p, c->acc.p, list, list_mode ? nullptr : c->ovf.p,
                                                                 eflag, vflag, elem);
     if (!list_mode) continue;
-    // ... and go through the 8-lane-group kernel at once; grid from the count seen a step ago (+ 25 % + one block),
+    // ... and go through the 8-lane-group kernel at once; grid from the count seen two computes ago,
     // the kernel itself hands what it does not cover to the general kernel
     constexpr int per_block = CentreCfg<8>::WPB * CentreCfg<8>::GPW;
-    long long est = (long long) *h_cnt + *h_cnt / 4 + per_block;
+    // (the count is two computes old: 4 x + two blocks -- at the onset of overflows it grows by 1.8 x per step --; what a grid does not cover still reaches the general kernel,
+    //  but WHICH entries those are depends on the order the list was filled in -- with a generous grid the paths, and
+    //  with them the last bits of the forces, are the same in every run)
+    long long est = 4 * (long long) *h_cnt + 2 * per_block;
     if (est > n) est = n;
     const int grid = (int) ((est + per_block - 1) / per_block);
     rebo_centre_kernel<8, true><<<grid, 64 * CentreCfg<8>::WPB, 0, c->stream>>>(
@@ -3381,6 +3415,7 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
 // parts: bit 0 = interior centres, bit 1 = boundary centres (+ the overflow pass, which must follow both)
 static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
 {
+  if (parts & 1) c->ovf_par ^= 1; // (a new compute: the set of pinned overflow counts it reads first and writes last)
   hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
   for (int part = 0; part < 2; part++) {
     if (!((parts >> part) & 1)) continue;
@@ -3401,7 +3436,8 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
                                                             c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
                                                             c->fown.p, nullptr, nullptr, c->acc.p, c->flags.p,
-                                                            eflag, vflag, (int *) (c->h_pinned + 40), c->ovf_stride);
+                                                            eflag, vflag, (int *) (c->h_pinned + 40) + 4 * c->ovf_par,
+                                                            c->ovf_stride);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
