@@ -308,12 +308,17 @@ def run_job(E, job, par):
     stage_host, native = par["stage_host"], par["native"]
     wl, rep = job["workload"], job["replicate"]
     t_setup = time.perf_counter()
+    dis = job.get("disorder")          # off-lattice variants of the secondary block (SURVEY Appendix C constructions)
     if wl == "rebomos":
         s = S.replicate(S.rebomos_bulk_cell(), tuple(rep))
         wname = "REBO-MoS bulk: in.rebomos-bulk cell replicated %dx%dx%d" % tuple(rep)
+        if dis:
+            s = S.jitter(S.scale(s, dis["scale"]), dis["jitter"], seed=dis["seed"])
+            wname += ", box and coordinates x %.2f, uniform jitter +-%.2f A (R-strain-112)" % (dis["scale"], dis["jitter"])
     else:
-        s = S.fcc_cell(4.045, tuple(rep), frac_type2=0.0075, seed=7683797)
-        wname = "AEAM AlSi: fcc a=4.045 %dx%dx%d cells, 0.75%% Si" % tuple(rep)
+        frac = dis["frac2"] if dis else 0.0075
+        s = S.fcc_cell(4.045, tuple(rep), frac_type2=frac, seed=7683797)
+        wname = "AEAM AlSi: fcc a=4.045 %dx%dx%d cells, %.2f%% Si" % (*rep, 100.0 * frac)
     v0 = S.gaussian_velocities(s, job["temp"], seed=1082337) if job["temp"] > 0 else None
     ctx = capi.Context(par["local_rank"])
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -423,9 +428,10 @@ def run_job(E, job, par):
     ms_per_step = elapsed / job["steps"] * 1e3
     if wl == "rebomos":
         lj = "rebo_lj_gather_kernel" if os.environ.get("MDP_LJ_TILE", "1") == "0" else "rebo_lj_tile_kernel"
-        phases = {"rebo_centre3_kernel + rebo_centre_kernel<8|12|16|32> (all launches)": kms[0], "tile_prune_kernel (when due)": kms[1],
-                  lj + " (one launch)": kms[2]}
-        single = {lj: kms[2]}                       # phases that are ONE launch: candidates for `dominant_kernel`
+        phases = {"rebo_centre3_kernel + rebo_centre_kernel<8|12|16|32> (all launches)": kms[0],
+                  "rebo_centre_general_kernel (centres that outgrew their lane group)": kms[1],
+                  "tile_prune_kernel (when due)": kms[2], lj + " (one launch)": kms[3]}
+        single = {lj: kms[3]}                       # phases that are ONE launch: candidates for `dominant_kernel`
     else:
         dens = "aeam_tile_density_kernel" if os.environ.get("MDP_AEAM_PERSIST", "") == "0" else "aeam_ptile_kernel"
         # (each phase is timed between its own pair of events: no exchange and no host gap lies inside one)
@@ -507,6 +513,23 @@ def run_job(E, job, par):
                               "frac": round(flops_path / FP64_PEAK_TFLOPS, 5),
                               "whole_step_frac": round(flops_step / FP64_PEAK_TFLOPS, 5)}},
     }
+    # how the work was spread over the kernel classes (the lattice-tuned fast paths against their fallbacks)
+    try:
+        cs = ctx.md_class_stats()
+    except AttributeError:       # (an older build of the library, loaded through MDP_LIB_PATH for an A/B run)
+        cs = [0] * 32
+    if wl == "rebomos":
+        names = ("1 lane/centre", "8 lanes", "12 lanes", "16 lanes", "32 lanes")
+        out["config"]["work_split"] = {
+            "centres_per_class_at_last_list_build": {f"{names[g]} {'Mo' if e == 0 else 'S'}": cs[2 * g + e] + cs[10 + 2 * g + e]
+                                                     for g in range(5) for e in range(2) if cs[2 * g + e] + cs[10 + 2 * g + e]},
+            "centres_with_a_4th_neighbour_last_step": sum(cs[25:29]),
+            "centres_handed_to_the_general_kernel_last_step": cs[24],
+            "lj_tiles_small_union_class": cs[20], "lj_tiles_large_union_class": cs[21],
+            "largest_union": cs[30], "small_class_union_limit": cs[29]}
+    else:
+        out["config"]["work_split"] = {"angular_centres_rank0": cs[0], "tiles": cs[1], "largest_union": cs[30],
+                                       "density_kernel": dens}
     if dist is not None and wl == "aeam":
         st = ctx.md_aeam_state()
         out["config"].update(aeam_tiles_rank0=st["tiles"], aeam_interior_tiles_rank0=st["interior_tiles"],
@@ -539,6 +562,9 @@ def main():
     ap.add_argument("--check-every", type=int, default=10,
                     help="several GPUs: steps between the (collective) displacement checks; one GPU checks every step")
     ap.add_argument("--thermo", type=int, default=None, help="steps between energy/virial tallies (default: the input deck's)")
+    ap.add_argument("--strain", type=float, nargs=2, default=None, metavar=("SCALE", "JITTER"),
+                    help="rebomos: box and coordinates x SCALE, uniform jitter +-JITTER A (R-strain-112: 1.12 0.15)")
+    ap.add_argument("--frac2", type=float, default=None, help="aeam: fraction of atoms of type 2 (sample.in: 0.0075)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-mode", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -561,7 +587,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to measure another rank count")
-    custom = args.replicate is not None or args.workload != "rebomos" or args.temp != 0.0
+    custom = (args.replicate is not None or args.workload != "rebomos" or args.temp != 0.0 or args.strain is not None
+              or args.frac2 is not None)
     if args.replicate is None:
         args.replicate = DEFAULT_REPLICATE[args.workload]
     if args.inner_skin is not None:
@@ -613,6 +640,10 @@ def main():
 
     job = dict(workload=args.workload, replicate=list(args.replicate), temp=args.temp, steps=args.steps, warmup=args.warmup,
                thermo_every=THERMO_EVERY[args.workload] if args.thermo is None else args.thermo, check_every=args.check_every)
+    if args.strain is not None and args.workload == "rebomos":
+        job["disorder"] = dict(scale=args.strain[0], jitter=args.strain[1], seed=1234)
+    if args.frac2 is not None and args.workload == "aeam":
+        job["disorder"] = dict(frac2=args.frac2)
     out, pieces = run_job(E, job, par)
     out["config"]["rccl_ranks"] = rccl_ranks
     if rank == 0 and world == 1 and dist is None and not args.no_host_mode:
@@ -657,6 +688,28 @@ def main():
             sec["aeam_config3"] = o
         except Exception as e:  # noqa: BLE001
             log(f"[bench] secondary AEAM run failed: {e}")
+        # ---- speed OFF the perfect lattice (the kernels' lane-group classes, one-lane S centres and element-sorted
+        # tiles are tuned to 2H-MoS2 / fcc): the strained, jittered cell of SURVEY Appendix C at full size, and the alloy
+        # with ten times the angular atoms.  Same JSON shape; `config.work_split` says which kernels carried the load.
+        try:
+            sj = dict(job, temp=300.0, steps=max(200, args.steps), warmup=20,
+                      disorder=dict(scale=1.12, jitter=0.15, seed=1234))
+            o, _ = run_job(E, sj, par)
+            sec["rebomos_strained_112_jitter_300K"] = {k: o[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")}
+            sec["rebomos_strained_112_jitter_300K"]["note"] = (
+                "R-strain-112 of SURVEY Appendix C replicated 24x24x24 (3 981 312 atoms), 300 K: switching interior, LJ cubic "
+                "branch, coordination spread -- overflow lists, general kernel and second tile launch class carry load")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] secondary strained REBO-MoS run failed: {e}")
+        try:
+            aj = dict(workload="aeam", replicate=DEFAULT_REPLICATE["aeam"], temp=863.0, steps=300, warmup=20,
+                      thermo_every=THERMO_EVERY["aeam"], check_every=args.check_every, disorder=dict(frac2=0.08))
+            o, _ = run_job(E, aj, par)
+            sec["aeam_8pct_si"] = {k: o[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")}
+            sec["aeam_8pct_si"]["note"] = ("A-6-8pct of SURVEY Appendix C at the size of config #3: 1 000 188 atoms, 8 % Si "
+                                           "(80 000 angular centres with their O(n^2) triplet loops), 863 K")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] secondary AEAM 8 % Si run failed: {e}")
         out["secondary"] = sec
     # the CPU baseline runs on rank 0 AFTER every timed region (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu_baseline:

@@ -302,6 +302,16 @@ int mdp_md_list_state(mdp_ctx *ctx, double out[8]);
  * [4]=row entries incl. padding, [5]=#clusters, [6]=#tiles in the large-union launch classes,
  * [7]=style-list builds so far.  (No reference counterpart: the CPU style reads the host's list.) */
 int mdp_rebomos_list_info(mdp_ctx *ctx, long long out[8]);
+/* how the work of the last compute was spread over the kernel classes (diagnostics of a bench line; no reference
+ * counterpart -- the CPU style has one loop, pair_rebomos.cpp:358-447, pair_aeam.cpp:337-475):
+ * rebomos: out[0..19] = centres per launch class at the last style-list build, class = 2 * (lane-group index: 0 one lane
+ * per centre, 1..4 groups of 8 / 12 / 16 / 32 lanes) + element, + 10 for centres that reach a remote ghost;
+ * [20..23] = tiles per Lennard-Jones launch class (small unions, large unions, two unused); [24] = centres the general
+ * kernel's list received in the last compute whose count has reached the host (lane-group overflow); [25..28] = centres
+ * with a fourth neighbour per (interior / boundary, element) list of the lane-per-centre kernel; [29] = largest tile union
+ * of the small launch class, [30] = largest union.
+ * aeam: out[0] = angular centres, [1] = tiles, [2] = tiles that reach no remote ghost, [30] = largest union. */
+int mdp_md_class_stats(mdp_ctx *ctx, long long out[32]);
 
 /* ---- resident mode, domain decomposition on the device ----------------------------------------------------------
  * What the reference gets from the LAMMPS host at every reneighboring -- Domain::remap, Comm::exchange,
@@ -385,7 +395,8 @@ int mdp_md_integrate_check(mdp_ctx *ctx, int with_final, int *moved, int *danger
 int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
 
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):
- * rebomos: [0]=REBO centre kernels, [1]=row pruning (0 unless one was due), [2]=LJ+gather kernel;
+ * rebomos: [0]=REBO centre kernels of the lane-group classes, [1]=the general kernel (centres that outgrew their lane
+ * group since the list build), [2]=row pruning (0 unless one was due), [3]=LJ+gather kernel;
  * aeam: [0]=density of the metal centres (tile kernel), [1]=density of the angular centres, [2]=embedding,
  * [3]=force tile kernel (incl. force_clear), [4]=angular three-body forces.
  * Enabled by mdp_set_timing(ctx,1). */

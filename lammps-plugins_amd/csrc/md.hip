@@ -226,7 +226,7 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
       if (f0) SC.flags[4] |= f0;
       SC.flags[0] = 0;
       if (SC.ovf)
-        for (int k = 0; k < 5; k++) SC.ovf[(size_t) k * SC.ovf_stride] = 0;
+        for (int k = 0; k < 6; k++) SC.ovf[(size_t) k * SC.ovf_stride] = 0;
     } else if (i < 4)
       SC.flags[i] = 0;
   }
@@ -1184,6 +1184,29 @@ int mdp_rebomos_list_info(mdp_ctx *c, long long out[8])
   out[5] = c->nclus;
   out[6] = (c->lj_class_base[2] - c->lj_class_base[1]) + (c->lj_class_base[4] - c->lj_class_base[3]);
   out[7] = c->style_builds;
+  return MDP_OK;
+}
+
+int mdp_md_class_stats(mdp_ctx *c, long long out[32])
+{
+  if (!c || !out) return MDP_EINVAL;
+  for (int k = 0; k < 32; k++) out[k] = 0;
+  out[30] = c->tile_maxu;
+  if (c->cfg.style == 2 || (c->have_aeam && !c->have_rebomos)) {
+    out[0] = c->h_ang_count;
+    out[1] = c->ntile;
+    out[2] = c->aeam_split;
+    return MDP_OK;
+  }
+  for (int k = 0; k < MDP_NCLASS; k++) out[k] = c->h_class_count[k];
+  for (int k = 0; k < 4; k++) out[20 + k] = c->lj_class_base[k + 1] - c->lj_class_base[k];
+  if (c->lj_tiled && !c->lj_ordered) out[20] = c->ntile; // (no large unions: one class, natural order)
+  if (c->h_pinned) {
+    const int *h = (const int *) (c->h_pinned + 40) + 4 * c->ovf_par; // (the set the last compute published)
+    for (int k = 0; k < 4; k++) out[25 + k] = h[k];
+    out[24] = ((const int *) (c->h_pinned + 44))[0];
+  }
+  out[29] = c->tile_small;
   return MDP_OK;
 }
 

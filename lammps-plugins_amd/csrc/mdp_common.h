@@ -100,7 +100,7 @@ struct MdpStyleCheck {
   double *acc = nullptr;
   int nacc = 0;
   int *flags = nullptr, *ovf = nullptr;
-  int ovf_stride = 0; // the five overflow counters sit at ovf[k * ovf_stride]
+  int ovf_stride = 0; // the six list counters (five overflow lists, cubic-spline tiles) sit at ovf[k * ovf_stride]
 };
 struct MdpStyleCheckMeta {
   bool has_style = false, has_prune = false;
@@ -325,6 +325,9 @@ struct mdp_ctx {
   int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
   bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
   bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too
+  DevBuf<int> lj_fix_stamp;       // [ntile] stamp of the compute that last listed the tile for rebo_lj_cubic_kernel
+  int lj_stamp = 0;
+  DevBuf<double> lj_fixtab;       // [4][12] lo hi sw lj1 lj2 lj3 lj4 rcLJmin c2 c3 - - per pair type (cubic inner spline, rare path)
   DevBuf<int> cand_stage;         // [nall][64] candidate rows at a fixed stride, written by the counting sweep of a list build
   DevBuf<int> class_list;         // [MDP_NCLASS][nall]   class = 2 * (lane-group size index) + element
   DevBuf<int> class_count;        // [MDP_NCLASS]

@@ -786,11 +786,14 @@ __global__ __launch_bounds__(256) void rebo_centre_general_kernel(
     const double4 *__restrict__ xq, const int *__restrict__ cand_off, const int *__restrict__ cand,
     unsigned long long *__restrict__ amask, double *__restrict__ fnbr, double *__restrict__ fown,
     double *__restrict__ vslot, double *__restrict__ vatom, double *__restrict__ acc, int *__restrict__ flags,
-    const int eflag, const int vflag, int *__restrict__ h_cnt4 = nullptr, const int ovf_stride = 0)
+    const int eflag, const int vflag, int *__restrict__ h_cnt4 = nullptr, const int ovf_stride = 0,
+    int *__restrict__ h_gen = nullptr)
 {
   constexpr int G = 32, CAP = 64, STRIDE = CAP * kRec + 2;
-  // (the last centre kernel of a step: publishes how many centres outgrew the lane-per-centre kernel, per list)
+  // (the last centre kernel of a step: publishes how many centres outgrew the lane-per-centre kernel, per list, and how
+  //  many this kernel itself was handed -- pinned words, statistics and grid sizes of later computes)
   if (h_cnt4 && list_count < 0 && blockIdx.x == 0 && threadIdx.x < 4) h_cnt4[threadIdx.x] = list[(size_t) (threadIdx.x + 1) * ovf_stride];
+  if (h_gen && list_count < 0 && blockIdx.x == 0 && threadIdx.x == 4) *h_gen = list[0];
   __shared__ double s_rec[8 * STRIDE];
   __shared__ int s_je[8 * CAP];
   // list_count < 0: overflow list of the fast kernels, {count, ids...}; else an explicit list of centres
@@ -1165,7 +1168,7 @@ __device__ __forceinline__ void lj_store(const bool have, const int kc, const in
 }
 
 // 12-6 branch only, straight-line: pairs inside the cubic inner spline (rcLJmin <= r < 0.95 sigma; none in
-// an equilibrium crystal) are evaluated as 12-6 here and flagged; lj_cubic_fix() then replaces them.
+// an equilibrium crystal) are evaluated as 12-6 here and flagged; rebo_lj_cubic_kernel then replaces them.
 template <bool EV>
 __device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, const double4 &xj, double &fx,
                                              double &fy, double &fz, double &e, const int vflag, double &v0,
@@ -1201,33 +1204,6 @@ __device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, 
       v5 += dy * dz * h;
     }
   }
-}
-
-// the correction for one pair flagged by lj_pair_fast: cubic spline minus the 12-6 value already added
-// (parameters by value: taking the address of the kernel-argument struct would move all of it to scratch)
-__device__ __noinline__ void lj_cubic_fix(const double c1, const double c2, const double c3, const double c4,
-                                          const double rmin, const double k2, const double k3, const double dx,
-                                          const double dy, const double dz, const double rsq,
-                                          double *out /* fx fy fz e v0..v5 */)
-{
-  const double r2inv = 1.0 / rsq, r6inv = r2inv * r2inv * r2inv;
-  const double f12 = r6inv * (c1 * r6inv - c2) * r2inv;
-  const double v12 = r6inv * (c3 * r6inv - c4);
-  const double rij = sqrt(rsq);
-  const double drp = rij - rmin;
-  const double V = drp * drp * (drp * k3 + k2);
-  const double fc = -drp * (3.0 * drp * k3 + 2.0 * k2) / rij;
-  const double df = fc - f12, h = 0.5 * df;
-  out[0] += dx * df;
-  out[1] += dy * df;
-  out[2] += dz * df;
-  out[3] += 0.5 * (V - v12);
-  out[4] += dx * dx * h;
-  out[5] += dy * dy * h;
-  out[6] += dz * dz * h;
-  out[7] += dx * dy * h;
-  out[8] += dx * dz * h;
-  out[9] += dy * dz * h;
 }
 
 // tail of both Lennard-Jones kernels: REBO slot-force gather, group reductions, stores, global tallies
@@ -1403,6 +1379,157 @@ __global__ __launch_bounds__(256, MDP_LJ_WAVES) void rebo_lj_gather_kernel(
 // ------------------------------------------------------------------------------------------------
 #define MDP_TILE 16 // clusters per tile = 256 threads / 16 lanes per cluster
 
+// Corrections for the pairs of a tile's rows that sit on the cubic inner spline (rcLJmin <= r < 0.95 sigma,
+// pair_rebomos.cpp:532-543): none in an equilibrium crystal, a few per atom in a strained, hot or disordered structure.
+// rebo_lj_tile_kernel evaluates every pair as 12-6 and puts the tiles with a flagged pair on a list; this kernel follows
+// it and walks that list (grid-stride: the count is read on the device).  Per tile: the union is staged as there, the
+// rows are scanned once more -- LDS reads, one distance and three compares per pair -- and the flagged (entry, atom)
+// pairs of a 16-lane group are compacted into a small LDS queue, which the group then works off with all its lanes:
+// the correction (cubic minus the 12-6 value already added) costs a square root and a division, and a trip of 128
+// pairs typically holds one or two flagged ones.  (The first version re-walked the rows inside the tile kernel with
+// per-lane parameters and evaluated the correction where it stood: 5.7 ms of a 7.1 ms kernel in a 3 300 K melt; as a
+// function called from the tile kernel the pass cost the crystal 6 % through spills around the call.)
+// fixtab[pt][12] = lo hi sw lj1 lj2 lj3 lj4 rcLJmin c2 c3 - -.
+template <int CL, bool EV>
+__global__ __launch_bounds__(256) void rebo_lj_cubic_kernel(
+    const double *__restrict__ fixtab, const int *__restrict__ fix_list, const int nlocal, const int nclus,
+    const double4 *__restrict__ xq, const int cap, const int *__restrict__ tu, const int *__restrict__ tile_nu,
+    const long long *__restrict__ lj_off, const int *__restrict__ lj_len, const int *__restrict__ lj_split,
+    const unsigned short *__restrict__ lj16, double *__restrict__ f, double *__restrict__ eatom, double *__restrict__ acc,
+    const int eflag, const int vflag, int *__restrict__ h_count /* pinned: the host sizes later grids from it */)
+{
+  constexpr int L = 16, kCQ = 48;
+  extern __shared__ double s_pos[]; // [capL][3]
+  __shared__ unsigned short s_cq[MDP_TILE][kCQ];
+  const int tid = threadIdx.x, lane = tid & 63, s = lane % L, glane0 = lane - s;
+  unsigned short *cq = s_cq[tid / L];
+  const unsigned long long below = (1ull << s) - 1ull;
+  const int nfix = fix_list[0];
+  if (blockIdx.x == 0 && tid == 0) *h_count = nfix;
+  for (int e = blockIdx.x; e < nfix; e += gridDim.x) {
+    const int t = fix_list[1 + e];
+    const int kc = t * MDP_TILE + tid / L;
+    const bool have = kc < nclus;
+    const int nU = tile_nu[2 * t];
+    const int *__restrict__ mem = tu + (size_t) t * cap;
+    for (int u = tid; u < nU; u += 256) {
+      const double4 v = xq[mem[u]];
+      s_pos[3 * u] = v.x;
+      s_pos[3 * u + 1] = v.y;
+      s_pos[3 * u + 2] = v.z;
+    }
+    if (tid == 0) {
+      s_pos[3 * nU] = 1.0e30;
+      s_pos[3 * nU + 1] = 0.0;
+      s_pos[3 * nU + 2] = 0.0;
+    }
+    const long long b = lj_off[kc];
+    const int cnt = __builtin_amdgcn_readfirstlane(lj_len ? lj_len[kc] : (int) (lj_off[kc + 1] - b));
+    const int split = __builtin_amdgcn_readfirstlane(lj_split[kc]);
+    const unsigned short *__restrict__ row = lj16 + b;
+    double4 xa[CL];
+    int ta[CL];
+    bool real[CL];
+    double fx[CL], fy[CL], fz[CL], ee[CL];
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      real[c] = have && kc * CL + c < nlocal;
+      xa[c] = xq[real[c] ? kc * CL + c : 0];
+      ta[c] = (int) xa[c].w;
+      if (ta[c] < 0) {
+        real[c] = false;
+        ta[c] = 0;
+      }
+      fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
+    }
+    __syncthreads();
+    int nq = 0; // items in this group's queue (the same in its 16 lanes)
+    auto flush = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int i = s; i < nq; i += L) {
+        const int it = (int) cq[i];
+        const int li = it & 0xFFF, seg = (it >> 12) & 1, c1 = (it >> 13) & 1;
+        const double ax = c1 ? xa[CL - 1].x : xa[0].x, ay = c1 ? xa[CL - 1].y : xa[0].y, az = c1 ? xa[CL - 1].z : xa[0].z;
+        const double *__restrict__ q = fixtab + 12 * ((c1 ? ta[CL - 1] : ta[0]) * 2 + seg);
+        const double dx = ax - s_pos[3 * li], dy = ay - s_pos[3 * li + 1], dz = az - s_pos[3 * li + 2];
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        // (1/rsq exactly as lj_pair_fast computed it, so that the 12-6 value subtracted here is the one added there)
+        double r2inv = __builtin_amdgcn_rcp(rsq);
+        r2inv = fma(r2inv, fma(-rsq, r2inv, 1.0), r2inv);
+        const double r6inv = r2inv * r2inv * r2inv;
+        const double f12 = r6inv * (q[3] * r6inv - q[4]) * r2inv;
+        const double rij = sqrt(rsq);
+        const double drp = rij - q[7];
+        const double fc = -drp * (3.0 * drp * q[9] + 2.0 * q[8]) / rij;
+        const double df = fc - f12;
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dfc = (CL == 1 || c == c1) ? df : 0.0;
+          fx[c] += dx * dfc;
+          fy[c] += dy * dfc;
+          fz[c] += dz * dfc;
+        }
+        if (EV) {
+          const double v12 = r6inv * (q[5] * r6inv - q[6]);
+          const double V = drp * drp * (drp * q[9] + q[8]);
+#pragma unroll
+          for (int c = 0; c < CL; c++) ee[c] += (CL == 1 || c == c1) ? 0.5 * (V - v12) : 0.0;
+          if (vflag) {
+            const double h = 0.5 * df;
+            v0 += dx * dx * h;
+            v1 += dy * dy * h;
+            v2 += dz * dz * h;
+            v3 += dx * dy * h;
+            v4 += dx * dz * h;
+            v5 += dy * dz * h;
+          }
+        }
+      }
+      nq = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int seg = 0; seg < 2; seg++) {
+      const int kb = seg ? split : 0, ke = seg ? cnt : split;
+      double lo[CL], hi[CL], sw[CL];
+#pragma unroll
+      for (int c = 0; c < CL; c++) {
+        const double *__restrict__ q = fixtab + 12 * (ta[c] * 2 + seg);
+        lo[c] = q[0];
+        hi[c] = q[1];
+        sw[c] = q[2];
+      }
+      int li_next = kb + s < ke ? (int) row[kb + s] : nU;
+      for (int k = kb + s; k < ke; k += L) { // (whole 16-lane steps, equally many for the rows of a wave)
+        const int li = li_next;
+        li_next = k + L < ke ? (int) row[k + L] : nU;
+        const double xjx = s_pos[3 * li], xjy = s_pos[3 * li + 1], xjz = s_pos[3 * li + 2];
+#pragma unroll
+        for (int c = 0; c < CL; c++) {
+          const double dx = xa[c].x - xjx, dy = xa[c].y - xjy, dz = xa[c].z - xjz;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          const bool hit = real[c] && rsq >= lo[c] && rsq <= hi[c] && rsq < sw[c]; // (the dummy entry is far outside)
+          const unsigned long long m = (__ballot(hit) >> glane0) & 0xFFFFull;
+          if (hit) cq[nq + __popcll(m & below)] = (unsigned short) (li | (seg << 12) | ((CL == 1 ? 0 : c) << 13));
+          nq += __popcll(m);
+        }
+        if (__any(nq > kCQ - 2 * L)) flush(); // (room for one more trip of both atoms in every group)
+      }
+    }
+    flush();
+    double e_fix = 0.0;
+#pragma unroll
+    for (int c = 0; c < CL; c++) e_fix += ee[c];
+    lj_store<CL, L>(have, kc, s, lane, nlocal, e_fix, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
+                    /*accumulate=*/1);
+    __syncthreads(); // (the next tile's union overwrites s_pos)
+  }
+}
+
 template <bool EV, bool GATHER, int WAVES, int CL>
 __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
@@ -1413,7 +1540,8 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const unsigned long long *__restrict__ amask, const int *__restrict__ rev, const int *__restrict__ rev16,
     const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
     double *__restrict__ eatom, double *__restrict__ acc,
-    const int eflag, const int vflag, const int accumulate)
+    const int eflag, const int vflag, const int accumulate, int *__restrict__ fix_list, int *__restrict__ fix_stamp,
+    const int stamp)
 {
   constexpr int L = 16; // lanes per row; CL atoms per row (1: every atom walks its own neighbourhood, nothing of a partner's)
   constexpr int U = 1; // row entries per lane and iteration (segments are padded to L entries, so U * L must be L)
@@ -1606,40 +1734,10 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   segment(std::integral_constant<int, 0>{});
   segment(std::integral_constant<int, 1>{});
 
-  // rare: some pair sat on the cubic inner spline -- walk the row again and replace those pairs
-  if (cub) {
-    for (int k = s; k < cnt; k += L) {
-      const int li = row[k], seg = k < split ? 0 : 1;
-      if (li == nU) continue; // padding
-      const double xjx = s_pos[3 * li], xjy = s_pos[3 * li + 1], xjz = s_pos[3 * li + 2];
-#pragma unroll
-      for (int c = 0; c < CL; c++) {
-        if (!real[c]) continue;
-        const int pt = ta[c] * 2 + seg;
-        const double dx = xa[c].x - xjx, dy = xa[c].y - xjy, dz = xa[c].z - xjz;
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        if (rsq >= P.lj_rsq_lo[pt] && rsq <= P.lj_rsq_hi[pt] && rsq < P.lj_rsq_sw[pt]) {
-          double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          lj_cubic_fix(P.lj1[pt], P.lj2[pt], P.lj3[pt], P.lj4[pt], P.rcLJmin[pt], P.ljc2[pt], P.ljc3[pt], dx, dy, dz,
-                       rsq, o);
-          fx[c] += o[0];
-          fy[c] += o[1];
-          fz[c] += o[2];
-          if (EV) {
-            ee[c] += o[3];
-            if (vflag) {
-              v0 += o[4];
-              v1 += o[5];
-              v2 += o[6];
-              v3 += o[7];
-              v4 += o[8];
-              v5 += o[9];
-            }
-          }
-        }
-      }
-    }
-  }
+  // Some pair of this wave sat on the cubic inner spline: the tile goes onto the list of rebo_lj_cubic_kernel, which
+  // follows this launch and adds the corrections (the first flagged wave of a tile appends it; `stamp` changes with
+  // every compute, so the per-tile words need no reset).  Nothing of that path costs this kernel a register.
+  if (cub && lane == 0 && atomicExch(&fix_stamp[t], stamp) != stamp) fix_list[1 + atomicAdd(&fix_list[0], 1)] = t;
 
   double e_lj = 0.0;
 #pragma unroll
@@ -2688,6 +2786,14 @@ void mdp_rebomos_fill_dev(mdp_ctx *c, double skin)
     }
     for (int k = 0; k < 4; k++) d.a[t][k] = p.a[k][t];
   }
+  // the cubic inner spline's parameters per pair type in device memory (rebo_lj_cubic_kernel reads them)
+  double tab[48];
+  for (int k = 0; k < 4; k++) {
+    const double row[12] = {d.lj_rsq_lo[k], d.lj_rsq_hi[k], d.lj_rsq_sw[k], d.lj1[k], d.lj2[k], d.lj3[k], d.lj4[k],
+                            d.rcLJmin[k], d.ljc2[k], d.ljc3[k], 0.0, 0.0};
+    for (int q = 0; q < 12; q++) tab[12 * k + q] = row[q];
+  }
+  if (c->lj_fixtab.reserve(48) == hipSuccess) (void) hipMemcpy(c->lj_fixtab.p, tab, sizeof tab, hipMemcpyHostToDevice);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2794,7 +2900,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   // overflow lists: [0] the general kernel's, [1..4] the lane-per-centre kernel's per (part, element); each {count, ids...}
-  MDP_HIP(c, c->ovf.reserve((size_t) 5 * (nall + 2)));
+  MDP_HIP(c, c->ovf.reserve((size_t) 6 * (nall + 2))); // (five overflow lists of centres + the list of tiles with a pair on the cubic LJ spline)
   c->ovf_stride = nall + 2;
   c->acc_prezeroed = false; // (the counters sit at new places: the next mdp_acc_begin zeroes them itself)
   // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost.  (Round 1 split the
@@ -2856,6 +2962,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
     int cap = c->tile_cap > 0 ? c->tile_cap : 2048;
     MDP_HIP(c, c->tile_flag.reserve(4));
     MDP_HIP(c, c->tile_nu.reserve((size_t) 2 * ntile + 2));
+    MDP_HIP(c, c->lj_fix_stamp.reserve((size_t) ntile + 1));
+    MDP_HIP(c, hipMemsetAsync(c->lj_fix_stamp.p, 0, sizeof(int) * ((size_t) ntile + 1), st)); // (no compute has stamp 0)
     for (;;) {
       MDP_HIP(c, c->tu.reserve((size_t) ntile * cap));
       MDP_HIP(c, c->tmask.reserve((size_t) ntile * cap));
@@ -2964,7 +3072,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   for (int q = 0; q <= 4; q++) c->lj_class_base[q] = q ? nunit : 0; // everything in class 0
   // the tile kernel is latency-bound (measured: t = 0.65 ms + 3.96 ms / resident workgroups per CU), so the
   // common case is sized for FIVE workgroups per CU; the rare larger unions get their own launch
-  int kSmallUnion = 1279; // (1279 + 1) * 24 B = 30 KB: five workgroups and their allocation granules fit 160 KB
+  int kSmallUnion = 1210; // (1210 + 1) * 24 B + 1.5 KB of static LDS = 30.6 KB: five workgroups and their allocation granules fit 160 KB
   if (const char *e = getenv("MDP_TILE_SMALL")) kSmallUnion = atoi(e) > 0 ? atoi(e) : kSmallUnion; // (tests)
   c->tile_small = tiled ? (c->tile_maxu < kSmallUnion ? c->tile_maxu : kSmallUnion) : 0;
   if (nunit > 0 && tiled && c->tile_maxu > kSmallUnion) {
@@ -3375,7 +3483,8 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
         c->tile_nu.p, c->lj_off.p, pruned ? c->lj_len_in.p : nullptr, pruned ? c->lj_split_in.p : c->lj_split.p,    \
         pruned ? c->lj16_in.p : c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p,                         \
         c->fnbr.p,                                                                                                  \
-        c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0);                                \
+        c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0,                                 \
+        c->ovf.p + (size_t) 5 * c->ovf_stride, c->lj_fix_stamp.p, c->lj_stamp);                                     \
   } while (0)
 #define MDP_LJT(EVV, GV, WV)                                                                                        \
   do {                                                                                                              \
@@ -3412,6 +3521,43 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
   return MDP_OK;
 }
 
+// behind the Lennard-Jones tile launches of a compute: the corrections of the pairs on the cubic inner spline, for the
+// tiles those launches listed (normally none: the kernel reads the count on the device and leaves)
+static int launch_lj_cubic(mdp_ctx *c, int eflag, int vflag)
+{
+  if (!c->lj_tiled || c->ntile <= 0) return MDP_OK;
+  const bool pruned = c->prune_valid;
+  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const size_t lds = (size_t) capL * 3 * sizeof(double);
+  // a workgroup per listed tile, from the count an earlier compute published (any grid covers the list: the kernel
+  // strides over it; a crystal lists nothing and gets 256 workgroups that leave at once)
+  int *h_count = (int *) (c->h_pinned + 45);
+  long long want = (long long) *h_count + *h_count / 4 + 256;
+  const int grid = (int) (want < c->ntile ? want : c->ntile);
+  const int *fix_list = c->ovf.p + (size_t) 5 * c->ovf_stride;
+#define MDP_LJC(CLV, EVV)                                                                                            \
+  do {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                              \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_cubic_kernel<CLV, EVV>,                                   \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                         \
+    rebo_lj_cubic_kernel<CLV, EVV><<<grid, 256, lds, c->stream>>>(                                                    \
+        c->lj_fixtab.p, fix_list, c->nlocal, c->nclus, c->xq.p, c->tile_cap, c->tu.p, c->tile_nu.p, c->lj_off.p,      \
+        pruned ? c->lj_len_in.p : nullptr, pruned ? c->lj_split_in.p : c->lj_split.p,                                 \
+        pruned ? c->lj16_in.p : c->lj16.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, h_count);                      \
+  } while (0)
+  const bool ev = eflag || vflag;
+  if (c->cluster == 1) {
+    if (ev) MDP_LJC(1, true);
+    else MDP_LJC(1, false);
+  } else {
+    if (ev) MDP_LJC(2, true);
+    else MDP_LJC(2, false);
+  }
+#undef MDP_LJC
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
 // parts: bit 0 = interior centres, bit 1 = boundary centres (+ the overflow pass, which must follow both)
 static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
 {
@@ -3432,12 +3578,13 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
   int total = 0;
   for (int k = 0; k < MDP_NCLASS; k++) total += c->h_class_count[k];
   const int grid = total > 0 ? (total / 8 + 1 < 64 ? total / 8 + 1 : 64) : 0; // grid-stride; normally nothing to do
+  mdp_time_mark(c, 1); // (marks 1 -> 2: the general kernel, i.e. the centres that outgrew their lane group)
   if (grid)
     rebo_centre_general_kernel<false><<<grid, 256, 0, st>>>(c->rebomos, c->ovf.p, -1, c->nlocal, c->xq.p,
                                                             c->cand_off.p, c->cand.p, c->amask.p, c->fnbr.p,
                                                             c->fown.p, nullptr, nullptr, c->acc.p, c->flags.p,
                                                             eflag, vflag, (int *) (c->h_pinned + 40) + 4 * c->ovf_par,
-                                                            c->ovf_stride);
+                                                            c->ovf_stride, (int *) (c->h_pinned + 44));
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -3474,6 +3621,7 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
   }
   if (!c->rebo_packed) MDP_TRY(mdp_rebomos_repack(c));
   MDP_TRY(mdp_acc_begin(c, eflag || vflag));
+  c->lj_stamp = c->lj_stamp >= 0x7ffffff0 ? 1 : c->lj_stamp + 1; // (the tiles' "listed in this compute" words: never 0)
   mdp_time_mark(c, 0);
   if (vflag & MDP_VFLAG_ATOM) {
     MDP_HIP(c, c->vatom.reserve((size_t) 6 * c->nall + 6));
@@ -3494,11 +3642,13 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
     MDP_TRY(launch_centres_vatom(c, eflag, vflag));
   else
     MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
-  mdp_time_mark(c, 1);
+  if (va) mdp_time_mark(c, 1);
+  mdp_time_mark(c, 2);
   if (va) {
-    mdp_time_mark(c, 2);
+    mdp_time_mark(c, 3);
     c->prune_valid = false; // (these paths walk the rows as built)
     for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, false, eflag, vflag, false));
+    MDP_TRY(launch_lj_cubic(c, eflag, vflag));
     if (c->nlocal) {
       rebo_gather_kernel<8><<<(c->nlocal + 31) / 32, 256, 0, st>>>(c->nlocal, c->cand_off.p, c->amask.p, c->rev.p,
                                                                    c->fnbr.p, c->fown.p, c->f.p, c->eatom.p, eflag,
@@ -3533,11 +3683,12 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
         c->prune_valid = false;
     } else
       c->prune_valid = false;
-    mdp_time_mark(c, 2); // (a row pruning, when one was due, lies between marks 1 and 2)
+    mdp_time_mark(c, 3); // (a row pruning, when one was due, lies between marks 2 and 3)
     for (int k = 0; k < 4; k++) MDP_TRY(launch_lj(c, k, /*gather=*/true, eflag, vflag, false));
+    MDP_TRY(launch_lj_cubic(c, eflag, vflag));
   }
   MDP_HIP(c, hipGetLastError());
-  mdp_time_mark(c, 3);
+  mdp_time_mark(c, 4);
   return mdp_acc_end(c, eflag || vflag);
 }
 

@@ -56,7 +56,7 @@ EXPORTS = [
     "mdp_md_final_integrate", "mdp_md_final_initial_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
-    "mdp_md_neighbor_stats", "mdp_md_prune_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
+    "mdp_md_neighbor_stats", "mdp_md_class_stats", "mdp_md_prune_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
     "mdp_device_bytes", "mdp_host_release", "mdp_rebomos_check_host_list",
     "mdp_dd_setup", "mdp_dd_reneighbor", "mdp_dd_migrate_begin", "mdp_dd_migrate_pack", "mdp_dd_migrate_end",
     "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
@@ -90,7 +90,8 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _lib = C.CDLL(LIB_PATH)
+        # (MDP_LIB_PATH: another build of the same library -- A/B runs of two kernel versions on one box)
+        _lib = C.CDLL(os.environ.get("MDP_LIB_PATH") or LIB_PATH)
         _lib.mdp_last_error.restype = C.c_char_p
         _lib.mdp_md_ptr.restype = C.c_void_p
         _lib.mdp_device_bytes.restype = C.c_double
@@ -422,6 +423,12 @@ class Context:
         out = (C.c_longlong * 8)()
         self._ck(self.L.mdp_md_neighbor_stats(self.h, out))
         return list(out)
+
+    def md_class_stats(self):
+        """how the last compute's work was spread over the kernel classes (see mdpair_hip.h)"""
+        out = (C.c_longlong * 32)()
+        self._ck(self.L.mdp_md_class_stats(self.h, out))
+        return [int(v) for v in out]
 
     def md_prune_stats(self):
         """dynamic pruning of the tile rows: prunings, late prunings, active, buffer (see mdpair_hip.h)"""
