@@ -394,6 +394,27 @@ int mdp_md_integrate_check(mdp_ctx *ctx, int with_final, int *moved, int *danger
  * (diagnostics): {members of the neighbour union, Mo / first-type members} of every 32-atom tile, 2 ints per tile */
 int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
 
+/* ---- host mode with the integrator on the device (the plugins' `fix nve/mdp`) -----------------------------------------
+ * The reference's styles run under the host's fix nve, which reads atom->f and writes atom->x / atom->v on the host
+ * every step (LAMMPS Verlet::run; the reference repository itself registers a fix style from a plugin,
+ * USER-BFIELD/bfieldplugin.cpp:15-29, virtuals fix_bfield.h:33-38).  With these calls a host-mode context does the two
+ * half-kicks and the drift on the device: between two reneighborings of the host nothing per atom crosses the link.
+ * Needs the periodic images kept by the library (mdp_set_box_host, one periodic rank).  Sequence:
+ *     mdp_hnve_setup (once: dt, force->ftm2v, atom->mass[1..ntypes])
+ *     at every reneighboring: mdp_set_atoms_host (+ skin / list check as before), mdp_hnve_upload_v(atom->v)
+ *     per step: mdp_hnve_initial -> [compute with f == NULL: forces stay on the device] -> mdp_hnve_final
+ *     mdp_hnve_download(x, v, f) before anything on the host reads them (reneighboring, thermo / dump steps)
+ * mdp_hnve_initial: *moved = an owned atom has moved half the host's skin minus a margin since the last
+ * mdp_set_atoms_host, as seen by the PREVIOUS call (no wait for the kernel just queued) -- the host reneighbors at its
+ * next step; *dangerous = one was beyond half the skin already.  mdp_*_compute_host / mdp_aeam_force_host accept
+ * f == NULL while the integrator is on (per-atom tallies then need f).  mdp_hnve_off: back to plain host mode. */
+int mdp_hnve_setup(mdp_ctx *ctx, double dt, double ftm2v, const double *mass_per_type /* [ntypes+1], 1-based */, int ntypes);
+int mdp_hnve_off(mdp_ctx *ctx);
+int mdp_hnve_upload_v(mdp_ctx *ctx, const double *v /* [nlocal][3], the host's atom order */);
+int mdp_hnve_initial(mdp_ctx *ctx, int *moved, int *dangerous);
+int mdp_hnve_final(mdp_ctx *ctx);
+int mdp_hnve_download(mdp_ctx *ctx, double *x, double *v, double *f /* [nlocal][3] each, or NULL */);
+
 /* per-phase device time of the last compute in ms (HIP events on the compute stream):
  * rebomos: [0]=REBO centre kernels of the lane-group classes, [1]=the general kernel (centres that outgrew their lane
  * group since the list build), [2]=row pruning (0 unless one was due), [3]=LJ+gather kernel;

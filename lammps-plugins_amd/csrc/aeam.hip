@@ -2083,7 +2083,9 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
     return mdp_fail(c, MDP_ESTATE, "aeam: call mdp_aeam_density_host first");
   if (c->nlocal == 0) return MDP_OK; // every force term starts from an owned atom (pair_aeam.cpp:337)
   const bool local_halo = c->host_ghosts_derived; // images filled and folded here, owned atoms' results only go back
-  if ((!fp_all && !local_halo) || !f) return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: fp / f missing for %d atoms", c->nall);
+  // (f may be NULL while the integrator lives on the device too, mdp_hnve_*: needs the images kept by the library)
+  if ((!fp_all && !local_halo) || (!f && !(c->hn_on && local_halo)))
+    return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: fp / f missing for %d atoms", c->nall);
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;
@@ -2108,6 +2110,12 @@ int mdp_aeam_force_host(mdp_ctx *c, int eflag, int vflag, const double *fp_all, 
   if (local_halo) {
     MDP_TRY(mdp_host_ghost_fold(c, 3, c->f.p));
     if (vflag & MDP_VFLAG_ATOM) MDP_TRY(mdp_host_ghost_fold(c, 6, c->vatom.p));
+  }
+  if (!f) { // forces stay with the device integrator; totals only when asked for
+    if ((eflag & MDP_EFLAG_ATOM) || (vflag & MDP_VFLAG_ATOM))
+      return mdp_fail(c, MDP_EINVAL, "mdp_aeam_force_host: per-atom tallies without f");
+    if (!(eflag || vflag)) return MDP_OK;
+    return aeam_fetch(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr);
   }
   MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 10 * nall + 16));
   double *hf = c->h_down, *he = hf + (size_t) 3 * nall, *hv = he + nall;

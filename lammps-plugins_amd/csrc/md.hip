@@ -286,6 +286,14 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
   }
 }
 
+// mass of every owned atom in the device's atom order (host mode: type[] is in the host's order, perm maps positions)
+__global__ void hn_rmass_kernel(const int nlocal, const int *__restrict__ type, const int *__restrict__ perm,
+                                const double *__restrict__ mass_type, double *__restrict__ rmass)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < nlocal) rmass[p] = mass_type[type[perm ? perm[p] : p] & 15];
+}
+
 __global__ void nve_final_kernel(int nlocal, double dtf, const double *__restrict__ rmass,
                                  const double *__restrict__ f, double *__restrict__ v)
 {
@@ -981,6 +989,159 @@ int mdp_md_compute_end(mdp_ctx *c, int eflag, int vflag)
   MDP_TRY(mdp_md_aeam_density(c, eflag));
   MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
   return mdp_md_fold_self_ghost_f(c);
+}
+
+// ---- fix nve on the device for a HOST-mode context ------------------------------------------------------------------
+// The plugins' `fix nve/mdp` (plugin/fix_nve_mdp.cpp; the reference repository registers a fix style from a plugin the
+// same way, USER-BFIELD/bfieldplugin.cpp:15-29): between two reneighborings of the host the owned atoms' positions,
+// velocities and forces stay on the device -- nothing per atom crosses the link in a step.  Needs the images kept by the
+// library (mdp_set_box_host on one periodic rank), since the ghosts must follow their owners without the host.
+int mdp_hnve_setup(mdp_ctx *c, double dt, double ftm2v, const double *mass_type, int ntypes)
+{
+  if (!c || !(dt > 0.0) || !mass_type || ntypes < 1 || ntypes > 15) return MDP_EINVAL;
+  if (c->md) return mdp_fail(c, MDP_ESTATE, "mdp_hnve_setup: a resident-mode context integrates through mdp_md_*");
+  c->hn_dt = dt;
+  c->hn_dtf = 0.5 * dt * ftm2v;
+  for (int t = 0; t < 16; t++) c->hn_mass[t] = t >= 1 && t <= ntypes ? mass_type[t] : 1.0;
+  MDP_HIP(c, hipSetDevice(c->device));
+  MDP_HIP(c, c->hn_mass_dev.reserve(16));
+  MDP_HIP(c, hipMemcpy(c->hn_mass_dev.p, c->hn_mass, sizeof c->hn_mass, hipMemcpyHostToDevice));
+  c->hn_on = true;
+  c->hn_v_current = false;
+  return MDP_OK;
+}
+
+int mdp_hnve_off(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  c->hn_on = false;
+  c->hn_v_current = false;
+  return MDP_OK;
+}
+
+// after every mdp_set_atoms_host (the host re-sorted or exchanged atoms): the owned atoms' velocities, host order
+int mdp_hnve_upload_v(mdp_ctx *c, const double *v)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->hn_on) return mdp_fail(c, MDP_ESTATE, "mdp_hnve_setup not called");
+  if (!c->atoms_set) return mdp_fail(c, MDP_ESTATE, "atoms not set");
+  if (c->nghost > 0 && !c->host_ghosts_derived)
+    return mdp_fail(c, MDP_ESTATE, "the device integrator needs the images kept by the library (mdp_set_box_host, one periodic rank)");
+  const int n = c->nlocal;
+  if (n > 0 && !v) return mdp_fail(c, MDP_EINVAL, "mdp_hnve_upload_v: v missing for %d owned atoms", n);
+  MDP_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->v.reserve((size_t) 3 * n + 3));
+  MDP_HIP(c, c->rmass.reserve(n + 1));
+  MDP_HIP(c, c->xhold.reserve((size_t) 3 * n + 3));
+  if (n) {
+    if (c->host_sort) {
+      MDP_HIP(c, c->host_stage.reserve((size_t) 10 * c->nall + 16));
+      MDP_TRY(mdp_host_upload(c, c->host_stage.p, v, sizeof(double) * 3 * n));
+      MDP_TRY(mdp_to_device_order(c, n, 3, c->host_stage.p, c->v.p));
+    } else
+      MDP_TRY(mdp_host_upload(c, c->v.p, v, sizeof(double) * 3 * n));
+    hn_rmass_kernel<<<nblk(n), 256, 0, st>>>(n, c->type.p, c->host_sort ? c->host_perm.p : nullptr, c->hn_mass_dev.p, c->rmass.p);
+    hold_kernel<<<nblk(n), 256, 0, st>>>(n, c->xq.p, c->xhold.p);
+    MDP_HIP(c, hipGetLastError());
+  }
+  MDP_HIP(c, hipStreamSynchronize(st));
+  c->dd.moved_pending = false;
+  c->hn_v_current = true;
+  return MDP_OK;
+}
+
+// initial_integrate.  *moved / *dangerous: has an owned atom moved half the host's skin (minus a margin: the answer is
+// that of the PREVIOUS call, read without waiting for this one) / beyond half the skin since the last mdp_set_atoms_host
+int mdp_hnve_initial(mdp_ctx *c, int *moved, int *dangerous)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->hn_on || !c->hn_v_current) return mdp_fail(c, MDP_ESTATE, "mdp_hnve_upload_v not called for the current atoms");
+  MDP_HIP(c, hipSetDevice(c->device));
+  MdpDomain &D = c->dd;
+  int *h = (int *) (c->h_pinned + 28);
+  if (!D.ev_moved) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_moved, hipEventDisableTiming));
+  int m = 0, dg = 0;
+  if (D.moved_pending) {
+    MDP_HIP(c, hipEventSynchronize(D.ev_moved));
+    m = h[0];
+    dg = h[1];
+    D.moved_pending = false;
+  }
+  if (moved) *moved = m;
+  if (dangerous) *dangerous = dg;
+  const int n = c->nlocal;
+  if (n) {
+    h[0] = h[1] = 0;
+    const double hard = 0.5 * c->skin;
+    double trig = hard - 0.1 * mdp_margin_scale(c);
+    if (trig < 0.5 * hard) trig = 0.5 * hard;
+    MdpStyleCheck sc; // (host mode: the style checks its own lists in its compute, mdp_rebomos_host_precheck)
+    nve_advance_kernel<false, true><<<nblk(n), 256, 0, c->stream>>>(n, c->hn_dtf, c->hn_dt, c->rmass.p, c->f.p, c->v.p, c->xq.p,
+                                                                    c->xhold.p, trig * trig, hard * hard, h, sc, 0);
+    MDP_HIP(c, hipGetLastError());
+    MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+    D.moved_pending = true;
+  }
+  MDP_TRY(mdp_host_refresh_ghosts(c));  // Comm::forward_comm of x on one periodic rank
+  MDP_TRY(mdp_rebomos_host_precheck(c)); // (the style's own displacement check of the compute that follows)
+  if (c->host_check_armed) MDP_HIP(c, hipStreamSynchronize(c->stream)); // ... whose words that compute reads at once
+  return MDP_OK;
+}
+
+int mdp_hnve_final(mdp_ctx *c)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->hn_on || !c->hn_v_current) return mdp_fail(c, MDP_ESTATE, "mdp_hnve_upload_v not called for the current atoms");
+  MDP_HIP(c, hipSetDevice(c->device));
+  if (c->nlocal)
+    nve_final_kernel<<<nblk(c->nlocal), 256, 0, c->stream>>>(c->nlocal, c->hn_dtf, c->rmass.p, c->f.p, c->v.p);
+  MDP_HIP(c, hipGetLastError());
+  return MDP_OK;
+}
+
+// owned atoms' x / v / f in the host's order (any of them NULL: not wanted); complete on return
+int mdp_hnve_download(mdp_ctx *c, double *x, double *v, double *f)
+{
+  if (!c) return MDP_EINVAL;
+  if (!c->hn_on || !c->hn_v_current) return mdp_fail(c, MDP_ESTATE, "mdp_hnve_upload_v not called for the current atoms");
+  const int n = c->nlocal;
+  if (!n) return MDP_OK;
+  MDP_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  MDP_HIP(c, c->host_stage.reserve((size_t) 10 * c->nall + 16));
+  MDP_TRY(mdp_host_pinned_reserve(c, (size_t) 9 * n + 16));
+  double *s0 = c->host_stage.p, *s1 = s0 + (size_t) 3 * n, *s2 = s1 + (size_t) 3 * n;
+  double *h0 = c->h_down, *h1 = h0 + (size_t) 3 * n, *h2 = h1 + (size_t) 3 * n;
+  const double *dx = nullptr, *dv = c->v.p, *df = c->f.p;
+  if (x) {
+    xq_to_x3_kernel<<<nblk(n), 256, 0, st>>>(n, c->xq.p, c->xraw.p);
+    dx = c->xraw.p;
+    if (c->host_sort) {
+      MDP_TRY(mdp_to_host_order(c, n, 3, c->xraw.p, s0));
+      dx = s0;
+    }
+    MDP_HIP(c, hipMemcpyAsync(h0, dx, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  }
+  if (v) {
+    if (c->host_sort) {
+      MDP_TRY(mdp_to_host_order(c, n, 3, c->v.p, s1));
+      dv = s1;
+    }
+    MDP_HIP(c, hipMemcpyAsync(h1, dv, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  }
+  if (f) {
+    if (c->host_sort) {
+      MDP_TRY(mdp_to_host_order(c, n, 3, c->f.p, s2));
+      df = s2;
+    }
+    MDP_HIP(c, hipMemcpyAsync(h2, df, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st));
+  }
+  MDP_HIP(c, hipStreamSynchronize(st));
+  if (x) memcpy(x, h0, sizeof(double) * 3 * n);
+  if (v) memcpy(v, h1, sizeof(double) * 3 * n);
+  if (f) memcpy(f, h2, sizeof(double) * 3 * n);
+  return MDP_OK;
 }
 
 int mdp_md_thermo(mdp_ctx *c, double out[9])

@@ -588,6 +588,8 @@ static int host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes)
   return MDP_OK;
 }
 
+int mdp_host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes) { return host_upload(c, d_dst, h_src, bytes); }
+
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles)
 {
   if (ndoubles <= c->h_down_cap) return MDP_OK;
@@ -1099,6 +1101,12 @@ static int host_refresh_ghosts(mdp_ctx *c)
   return MDP_OK;
 }
 
+extern "C++" int mdp_host_refresh_ghosts(mdp_ctx *c)
+{
+  if (!c->host_ghosts_derived || c->nghost <= 0) return MDP_OK;
+  return host_refresh_ghosts(c);
+}
+
 extern "C++" int mdp_host_ghost_scalar(mdp_ctx *c, double *d_a)
 {
   if (!c->host_ghosts_derived || c->nghost <= 0) return MDP_OK;
@@ -1329,13 +1337,19 @@ int mdp_rebomos_compute_host(mdp_ctx *c, int eflag, int vflag, double *f, double
     for (int k = 0; k < 6; k++) c->last_virial[k] = 0.0;
     return MDP_OK;
   }
-  if (!f) return mdp_fail(c, MDP_EINVAL, "mdp_rebomos_compute_host: f missing for %d owned atoms", c->nlocal);
+  // f may be NULL while the integrator lives on the device too (mdp_hnve_*): the forces then stay where their reader is
+  if (!f && !c->hn_on) return mdp_fail(c, MDP_EINVAL, "mdp_rebomos_compute_host: f missing for %d owned atoms", c->nlocal);
   MDP_HIP(c, hipSetDevice(c->device));
   if ((eflag & MDP_EFLAG_ATOM) && !eatom) eflag &= ~MDP_EFLAG_ATOM;
   if ((vflag & MDP_VFLAG_ATOM) && !vatom) vflag &= ~MDP_VFLAG_ATOM;
   MDP_TRY(mdp_rebomos_run(c, eflag, vflag, /*zero_f=*/true));
   hipStream_t st = c->stream;
   const int nlocal = c->nlocal;
+  if (!f) { // nothing per atom crosses the link; the totals only when asked for (overflow bits are sticky until then)
+    if (eflag & MDP_EFLAG_ATOM) return mdp_fail(c, MDP_EINVAL, "mdp_rebomos_compute_host: per-atom energy without f");
+    if (!(eflag || vflag)) return MDP_OK;
+    return fetch_acc(c, (eflag & MDP_EFLAG_GLOBAL) ? eng_vdwl : nullptr, (vflag & MDP_VFLAG_GLOBAL) ? virial : nullptr);
+  }
   // results come back through the staging buffer and are ADDED on the host (LAMMPS semantics)
   const double *df = c->f.p, *de = c->eatom.p, *dv = c->vatom.p;
   if (c->host_sort && nlocal > 0) { // back to the host's atom order (owned atoms permute among themselves)

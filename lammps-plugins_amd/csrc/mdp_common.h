@@ -322,6 +322,12 @@ struct mdp_ctx {
   DevBuf<int> tile_flag;          // [0] a union outgrew tile_cap   [1] largest union   [2] most row entries of a tile
   DevBuf<unsigned short> lj16;    // cluster rows, indices into the tile's union
   DevBuf<int> is_center;          // [nall]
+  // fix nve on the device for a host-mode context (mdp_hnve_*, the plugins' `fix nve/mdp`)
+  bool hn_on = false;
+  double hn_dt = 0.0, hn_dtf = 0.0;
+  double hn_mass[16] = {};
+  DevBuf<double> hn_mass_dev;
+  bool hn_v_current = false;      // c->v / c->rmass match the atoms of the last mdp_set_atoms_host
   int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
   bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
   bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too
@@ -478,6 +484,8 @@ void mdp_time_mark(mdp_ctx *c, int k);
 void mdp_span_begin(mdp_ctx *c, int k); // per-phase device time as independent (begin, end) event pairs: aeam
 void mdp_span_end(mdp_ctx *c, int k);
 int mdp_host_pinned_reserve(mdp_ctx *c, size_t ndoubles); // c->h_down: pinned download buffer (host mode)
+int mdp_host_upload(mdp_ctx *c, void *d_dst, const void *h_src, size_t bytes); // pageable host array -> device, pipelined through pinned staging
+int mdp_host_refresh_ghosts(mdp_ctx *c);                  // host mode, images kept by the library: owner + count * h of this step
 int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double hardsq); // integrate kernel (+ displacement check)
 void mdp_host_add(double *dst, const double *src, size_t n); // dst += src, threaded for large arrays
 int mdp_host_download_add(mdp_ctx *c, double *h_dst, double *h_stage, const double *d_src, size_t n); // chunked D2H + add

@@ -56,7 +56,8 @@ EXPORTS = [
     "mdp_md_final_integrate", "mdp_md_final_initial_integrate", "mdp_md_compute", "mdp_md_compute_begin", "mdp_md_compute_end", "mdp_md_pack_x", "mdp_md_unpack_x", "mdp_md_pack_scalar",
     "mdp_md_unpack_scalar", "mdp_md_pack_ghost_f", "mdp_md_unpack_add_f", "mdp_md_fold_self_ghost_f",
     "mdp_md_aeam_density", "mdp_md_aeam_force", "mdp_md_thermo", "mdp_md_download", "mdp_md_upload_x", "mdp_md_ptr",
-    "mdp_md_neighbor_stats", "mdp_md_class_stats", "mdp_md_prune_stats", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
+    "mdp_md_neighbor_stats", "mdp_md_class_stats", "mdp_md_prune_stats", "mdp_hnve_setup", "mdp_hnve_off", "mdp_hnve_upload_v",
+    "mdp_hnve_initial", "mdp_hnve_final", "mdp_hnve_download", "mdp_rebomos_list_info", "mdp_set_timing", "mdp_get_timing",
     "mdp_device_bytes", "mdp_host_release", "mdp_rebomos_check_host_list",
     "mdp_dd_setup", "mdp_dd_reneighbor", "mdp_dd_migrate_begin", "mdp_dd_migrate_pack", "mdp_dd_migrate_end",
     "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
@@ -423,6 +424,31 @@ class Context:
         out = (C.c_longlong * 8)()
         self._ck(self.L.mdp_md_neighbor_stats(self.h, out))
         return list(out)
+
+    # ---------------- host mode with the integrator on the device (fix nve/mdp)
+    def hnve_setup(self, dt, ftm2v, mass_per_type):
+        m = np.ascontiguousarray(mass_per_type, dtype=np.float64)
+        self._ck(self.L.mdp_hnve_setup(self.h, C.c_double(dt), C.c_double(ftm2v), _dp(m), C.c_int(len(m) - 1)))
+
+    def hnve_off(self):
+        self._ck(self.L.mdp_hnve_off(self.h))
+
+    def hnve_upload_v(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        self._ck(self.L.mdp_hnve_upload_v(self.h, _dp(v)))
+
+    def hnve_initial(self):
+        m, d = C.c_int(0), C.c_int(0)
+        self._ck(self.L.mdp_hnve_initial(self.h, C.byref(m), C.byref(d)))
+        return bool(m.value), bool(d.value)
+
+    def hnve_final(self):
+        self._ck(self.L.mdp_hnve_final(self.h))
+
+    def hnve_download(self, nlocal, want=("x", "v", "f")):
+        out = {k: np.zeros((nlocal, 3)) for k in want}
+        self._ck(self.L.mdp_hnve_download(self.h, _dp(out.get("x")), _dp(out.get("v")), _dp(out.get("f"))))
+        return out
 
     def md_class_stats(self):
         """how the last compute's work was spread over the kernel classes (see mdpair_hip.h)"""

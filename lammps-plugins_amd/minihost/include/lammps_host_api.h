@@ -44,6 +44,9 @@ class Force;
 class Neighbor;
 class NeighList;
 class Pair;
+class Update;
+class Output;
+class Fix;
 
 namespace NeighConst {
   enum { REQ_DEFAULT = 0, REQ_FULL = 1 << 0, REQ_GHOST = 1 << 1 };
@@ -124,7 +127,19 @@ class Comm {
 class Force {
  public:
   int newton_pair = 1;
+  double ftm2v = 1.0 / 1.0364269e-4; // metal units
   Pair *pair = nullptr;
+};
+
+class Update { // the members of LAMMPS' Update a fix style reads
+ public:
+  bigint ntimestep = 0, laststep = 0;
+  double dt = 0.001;
+};
+
+class Output { // next step on which the host prints thermo / writes dumps (whichever comes first)
+ public:
+  bigint next = 0, next_thermo = 0;
 };
 
 class NeighList {
@@ -139,6 +154,7 @@ class Neighbor {
   double skin = 2.0;
   int pgsize = 100000, oneatom = 2000;
   int ago = 0; // steps since the list was built (0: built this step)
+  int every = 1, delay = 0, dist_check = 1; // neigh_modify every / delay / check
   int request_flags = 0;
   Pair *requestor = nullptr;
   void add_request(Pair *pair, int flags = 0)
@@ -157,6 +173,8 @@ class LAMMPS {
   Domain *domain = nullptr;
   Force *force = nullptr;
   Neighbor *neighbor = nullptr;
+  Update *update = nullptr;
+  Output *output = nullptr;
   MPI_Comm world = 0;
 };
 
@@ -164,7 +182,7 @@ class Pointers {
  public:
   explicit Pointers(LAMMPS *ptr) :
       lmp(ptr), memory(ptr->memory), error(ptr->error), atom(ptr->atom), comm(ptr->comm), domain(ptr->domain), force(ptr->force),
-      neighbor(ptr->neighbor), world(ptr->world)
+      neighbor(ptr->neighbor), update(ptr->update), output(ptr->output), world(ptr->world)
   {
   }
   virtual ~Pointers() = default;
@@ -178,6 +196,8 @@ class Pointers {
   Domain *&domain;
   Force *&force;
   Neighbor *&neighbor;
+  Update *&update;
+  Output *&output;
   MPI_Comm &world;
 };
 
@@ -210,6 +230,7 @@ class Pair : protected Pointers {
   virtual int pack_reverse_comm(int, int, double *) { return 0; }
   virtual void unpack_reverse_comm(int, int *, double *) {}
   virtual double memory_usage() { return 0.0; }
+  virtual void *extract(const char *, int &) { return nullptr; }
 
   void init(); // host side: init_style + init_one for all i<=j, fills cutsq
 
@@ -228,6 +249,40 @@ class Pair : protected Pointers {
   }
   void ev_setup(int eflag, int vflag);
   void virial_fdotr_compute();
+};
+
+// the part of LAMMPS' Fix a time-integration fix style touches (fix.h of the 2 Aug 2023 release; the reference
+// repository's own plugin fix, USER-BFIELD/fix_bfield.h:33-38, overrides the same virtuals)
+namespace FixConst {
+  enum { INITIAL_INTEGRATE = 1 << 0, POST_INTEGRATE = 1 << 1, PRE_EXCHANGE = 1 << 2, PRE_NEIGHBOR = 1 << 3,
+         POST_NEIGHBOR = 1 << 4, PRE_FORCE = 1 << 5, PRE_REVERSE = 1 << 6, POST_FORCE = 1 << 7, FINAL_INTEGRATE = 1 << 8,
+         END_OF_STEP = 1 << 9 };
+}
+
+class Fix : protected Pointers {
+ public:
+  char *id = nullptr, *style = nullptr;
+  int igroup = 0, groupbit = 1;
+  int time_integrate = 0;
+  int force_reneighbor = 0;     // 1: Neighbor::decide() reneighbors on the step next_reneighbor names
+  bigint next_reneighbor = -1;
+
+  Fix(LAMMPS *lmp, int narg, char **arg) : Pointers(lmp)
+  {
+    id = strdup(narg > 0 ? arg[0] : "");
+    style = strdup(narg > 2 ? arg[2] : "");
+  }
+  ~Fix() override
+  {
+    free(id);
+    free(style);
+  }
+  virtual int setmask() = 0;
+  virtual void init() {}
+  virtual void setup(int) {}
+  virtual void initial_integrate(int) {}
+  virtual void final_integrate() {}
+  virtual void reset_dt() {}
 };
 
 } // namespace LAMMPS_NS

@@ -177,10 +177,14 @@ struct Host {
   NeighList list;
   PeriodicComm comm;
   Domain domain;
+  Update update;
+  Output output;
   Pair *pair = nullptr;
+  Fix *fix = nullptr; // a time-integration fix style from a plugin (fix nve/mdp); built-in nve / nvt: fix_style
 
   // registry of plugin styles
   std::map<std::string, lammpsplugin_factory1 *> pair_styles;
+  std::map<std::string, lammpsplugin_factory2 *> fix_styles;
   std::vector<void *> handles;
 
   // box: lo, prd, tilt (xy,xz,yz)
@@ -226,6 +230,8 @@ struct Host {
     lmp.domain = &domain;
     lmp.force = &force;
     lmp.neighbor = &neighbor;
+    lmp.update = &update;
+    lmp.output = &output;
     comm.h = this;
   }
 
@@ -596,16 +602,23 @@ struct Host {
     if (fix_style.empty()) error.warning(FLERR, "No fixes with time integration, atoms won't move");
     pair->init();
     force.pair = pair;
+    update.dt = dt;
+    update.ntimestep = step;
+    update.laststep = step + nsteps;
     skin = neighbor.skin;
     wrap_owned();
     build_ghosts();
     build_neighbor_lists();
+    set_vviews();
+    if (fix) fix->init(); // (LAMMPS::init: force->init() before modify->init())
     printf("Neighbor list info ...\n  update: every = 1 steps, delay = 0 steps, check = yes\n");
     printf("  max neighbors/atom: %d, page size: %d\n  master list distance cutoff = %g\n  ghost atom cutoff = %g\n",
            neighbor.oneatom, neighbor.pgsize, pair->cutforce + skin, comm_cutoff());
     printf("  pair %s, perpetual\n      attributes: full, newton on%s\n", "style", (neighbor.request_flags & NeighConst::REQ_GHOST) ? ", ghost" : "");
     const int every = thermo_every;
+    output.next = output.next_thermo = step; // (setup: thermo of the initial state)
     compute_forces(1, 2);
+    if (fix) fix->setup(2);
     print_thermo_header();
     print_thermo();
     const double dtf = 0.5 * dt * FTM2V;
@@ -614,6 +627,37 @@ struct Host {
     int nbuild0 = nbuilds;
     for (long k = 1; k <= nsteps; k++) {
       step = first + k;
+      update.ntimestep = step;
+      { // Output::next: the next thermo step, or the last step of the run
+        long nt = every > 0 ? (step + every - 1) / every * every : first + nsteps;
+        output.next = output.next_thermo = std::min<long>(nt, first + nsteps);
+      }
+      if (fix) { // Verlet::run with a time-integration fix style from a plugin
+        fix->initial_integrate(2);
+        // Neighbor::decide(): fixes that ask for a reneighboring on this step, then every / delay / check
+        bool nflag = fix->force_reneighbor && fix->next_reneighbor == step;
+        if (!nflag) {
+          neighbor.ago++;
+          if (neighbor.ago >= neighbor.delay && neighbor.ago % neighbor.every == 0) nflag = neighbor.dist_check ? check_distance() : true;
+        }
+        if (nflag) {
+          wrap_owned();
+          build_ghosts();
+          build_neighbor_lists();
+        }
+        const bool out = every > 0 && (step % every == 0);
+        const bool last = k == nsteps;
+        if (out || last)
+          compute_forces(1, 2);
+        else { // (the style adds nothing to the host's f on such a step -- its reader is on the device: no force_clear
+               //  of 24 bytes per atom, no fold of ghost forces.  Verlet::force_clear of a real LAMMPS is a memset per step.)
+          sync_domain();
+          pair->compute(0, 0);
+        }
+        fix->final_integrate();
+        if (out || last) print_thermo();
+        continue;
+      }
       const int n = atom.nlocal;
       double tscale = 1.0;
       if (fix_style == "nvt") { // single Nose-Hoover thermostat, half step
@@ -1044,27 +1088,33 @@ struct Script {
       void *sym = dlsym(dso, "lammpsplugin_init");
       if (!sym) H.error.all(FLERR, "Plugin symbol lookup failure in file " + w[2] + ": lammpsplugin_init");
       H.handles.push_back(dso);
-      const size_t before = H.pair_styles.size();
+      const size_t before = H.pair_styles.size() + H.fix_styles.size();
       // registration callback: the host behind the LAMMPS* it is handed
       struct Trampoline {
         static void regfunc(lammpsplugin_t *p, void *lmp)
         {
           Host *host = g_host;
           if (!host || lmp != (void *) &host->lmp || !p || !p->style || !p->name) return;
-          if (strcmp(p->style, "pair") != 0) {
-            fprintf(stderr, "WARNING: plugin style %s/%s ignored (minilmp hosts pair styles only)\n", p->style, p->name);
+          const bool is_pair = strcmp(p->style, "pair") == 0, is_fix = strcmp(p->style, "fix") == 0;
+          if (!is_pair && !is_fix) {
+            fprintf(stderr, "WARNING: plugin style %s/%s ignored (minilmp hosts pair and fix styles only)\n", p->style, p->name);
             return;
           }
           if (strcmp(p->version, LAMMPS_VERSION) != 0)
             fprintf(stderr, "WARNING: plugin %s was compiled for LAMMPS version %s, host is %s\n", p->name, p->version,
                     LAMMPS_VERSION);
-          host->pair_styles[p->name] = p->creator.v1;
+          if (is_fix && host->fix_styles.count(p->name)) { // (LAMMPS' own message for a style that is loaded already)
+            fprintf(stderr, "WARNING: Ignoring load of fix style %s: must unload existing %s plugin first\n", p->name, p->name);
+            return;
+          }
+          if (is_pair) host->pair_styles[p->name] = p->creator.v1;
+          else host->fix_styles[p->name] = p->creator.v2;
           printf("Loading plugin: %s by %s\n", p->info, p->author);
         }
       };
       g_host = &H;
       reinterpret_cast<lammpsplugin_initfunc>(sym)(&H.lmp, dso, (void *) &Trampoline::regfunc);
-      printf("Loaded %zu plugins from %s\n", H.pair_styles.size() - before, w[2].c_str());
+      printf("Loaded %zu plugins from %s\n", H.pair_styles.size() + H.fix_styles.size() - before, w[2].c_str());
     } else if (c == "pair_style") {
       need(2);
       if (!H.pair_styles.count(w[1])) H.error.all(FLERR, "Unrecognized pair style '" + w[1] + "' (load its plugin first)");
@@ -1085,6 +1135,9 @@ struct Script {
       for (size_t k = 1; k + 1 < w.size(); k += 2) {
         if (w[k] == "one") H.neighbor.oneatom = std::stoi(w[k + 1]);
         if (w[k] == "page") H.neighbor.pgsize = std::stoi(w[k + 1]);
+        if (w[k] == "every") H.neighbor.every = std::max(1, std::stoi(w[k + 1]));
+        if (w[k] == "delay") H.neighbor.delay = std::max(0, std::stoi(w[k + 1]));
+        if (w[k] == "check") H.neighbor.dist_check = w[k + 1] == "yes" ? 1 : 0;
       }
     } else if (c == "set") {
       // set region ID type/fraction T f seed  (own RNG -- not LAMMPS' RanMars)
@@ -1134,8 +1187,16 @@ struct Script {
         H.nvt_t1 = std::stod(w[6]);
         H.nvt_damp = std::stod(w[7]);
         H.nvt_eta_dot = 0.0;
+      } else if (H.fix_styles.count(w[3])) { // a fix style from a plugin: fix ID group style args
+        delete H.fix;
+        std::vector<char *> args;
+        for (size_t k = 1; k < w.size(); k++) args.push_back(const_cast<char *>(w[k].c_str()));
+        H.fix = static_cast<Fix *>(H.fix_styles[w[3]](&H.lmp, (int) args.size(), args.data()));
+        if (!(H.fix->setmask() & (FixConst::INITIAL_INTEGRATE | FixConst::FINAL_INTEGRATE)) || !H.fix->time_integrate)
+          H.error.all(FLERR, "minilmp hosts time-integration fix styles only");
+        H.fix_style = "plugin";
       } else
-        H.error.all(FLERR, "minilmp supports fix nve|nvt only");
+        H.error.all(FLERR, "minilmp supports fix nve|nvt and time-integration fix styles of loaded plugins only");
     } else if (c == "timestep") {
       need(2);
       H.dt = std::stod(w[1]);

@@ -21,6 +21,8 @@
 #include "memory.h"
 #include "neigh_list.h"
 #include "neighbor.h"
+#include "output.h"
+#include "update.h"
 #include "utils.h"
 
 #include <cstring>
@@ -43,6 +45,7 @@ PairAEAM::PairAEAM(LAMMPS *lmp) : Pair(lmp)
   rho = fp = nullptr;
   cutforcesq = cutmax = 0.0;
   dev = nullptr;
+  nve_linked = 0;
   potfile = nullptr;
   tables_built = false;
   nelements = 0;
@@ -209,6 +212,7 @@ void PairAEAM::compute(int eflag, int vflag)
   }
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  const bool linked = nve_linked && comm->nprocs == 1;
   int rc;
   // the box of this step: on one periodic rank the library keeps the images itself (positions, fp, their share of the
   // three-body forces), as Comm::forward_comm / reverse_comm would
@@ -230,10 +234,15 @@ void PairAEAM::compute(int eflag, int vflag)
       if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
     }
     nall_uploaded = nall;
-  } else {
+    // fix nve/mdp integrates on the device: the velocities go with the atoms (the host's are current on this step)
+    if (linked) {
+      rc = mdp_hnve_upload_v(dev, nlocal ? atom->v[0] : nullptr);
+      if (rc != MDP_OK) fail_one(rc, "velocity upload");
+    }
+  } else if (!linked) {
     rc = mdp_set_positions_host(dev, nall ? atom->x[0] : nullptr);
     if (rc != MDP_OK) fail_one(rc, "position upload");
-  }
+  } // (linked: the device moved the atoms itself, mdp_hnve_initial)
 
   const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
   const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0) | (vflag_atom ? MDP_VFLAG_ATOM : 0);
@@ -247,9 +256,20 @@ void PairAEAM::compute(int eflag, int vflag)
   // communicate the derivative of the embedding function (pair_aeam.cpp:307)
   if (!local_halo) comm->forward_comm(this);
 
-  rc = mdp_aeam_force_host(dev, ef, vf, local_halo ? nullptr : fp, nall ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
-                           (vflag_atom && vatom) ? vatom[0] : nullptr);
+  // (linked to fix nve/mdp: the forces' only reader is on the device too -- unless the host tallies or writes this step)
+  const bool f_stays = linked && local_halo && !ef && !vf && update->ntimestep != output->next;
+  rc = mdp_aeam_force_host(dev, ef, vf, local_halo ? nullptr : fp, (nall && !f_stays) ? atom->f[0] : nullptr, &eng_vdwl,
+                           virial, eatom, (vflag_atom && vatom) ? vatom[0] : nullptr);
   if (rc != MDP_OK) fail_one(rc, "force pass");
+}
+
+void *PairAEAM::extract(const char *str, int &dim)
+{
+  // what fix nve/mdp needs of this style: its device context and the switch that keeps x, v and f there
+  dim = 0;
+  if (strcmp(str, "mdp_ctx") == 0) return (void *) &dev;
+  if (strcmp(str, "mdp_nve_linked") == 0) return (void *) &nve_linked;
+  return nullptr;
 }
 
 /* ---- per-pair comm callbacks, same packing as pair_aeam.cpp:946-990 ---------------------------- */

@@ -35,8 +35,10 @@ class PairAEAM : public Pair {
   int pack_reverse_comm(int, int, double *) override;
   void unpack_reverse_comm(int, int *, double *) override;
   double memory_usage() override;
+  void *extract(const char *, int &) override;
 
  protected:
+  int nve_linked;             // set by fix nve/mdp: x, v and f of the owned atoms stay on the device between reneighborings
   int nmax;                   // allocated size of the per-atom host arrays
   double cutforcesq, cutmax;
   double *rho, *fp;           // host mirrors: rho (owned), fp = Fptmp*F' (owned, then ghosts via forward_comm)

@@ -24,6 +24,8 @@
 #include "memory.h"
 #include "neigh_list.h"
 #include "neighbor.h"
+#include "output.h"
+#include "update.h"
 #include "utils.h"
 
 #include <cstring>
@@ -44,6 +46,7 @@ PairREBOMoS::PairREBOMoS(LAMMPS *lmp) : Pair(lmp)
   no_virial_fdotr = 1;
 
   dev = nullptr;
+  nve_linked = 0;
   params_read = false;
   cut3rebo = 0.0;
   nall_uploaded = -1;
@@ -174,6 +177,7 @@ void PairREBOMoS::compute(int eflag, int vflag)
   ev_init(eflag, vflag);
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  const bool linked = nve_linked && comm->nprocs == 1;
   int rc;
   // the box of this step: on one periodic rank the library gives the images their positions itself, as
   // Comm::forward_comm does (owner + whole box vectors), and takes the owned atoms' positions only
@@ -195,16 +199,32 @@ void PairREBOMoS::compute(int eflag, int vflag)
                                      cut3rebo + neighbor->skin);
     if (rc != MDP_OK) fail_one(rc, "neighbor list check");
     nall_uploaded = nall;
-  } else {
+    // fix nve/mdp integrates on the device: the velocities go with the atoms (the host's are current on this step)
+    if (linked) {
+      rc = mdp_hnve_upload_v(dev, nlocal ? atom->v[0] : nullptr);
+      if (rc != MDP_OK) fail_one(rc, "velocity upload");
+    }
+  } else if (!linked) {
     rc = mdp_set_positions_host(dev, nall ? atom->x[0] : nullptr);
     if (rc != MDP_OK) fail_one(rc, "position upload");
-  }
+  } // (linked: the device moved the atoms itself, mdp_hnve_initial)
 
   const int ef = (eflag_global ? MDP_EFLAG_GLOBAL : 0) | (eflag_atom ? MDP_EFLAG_ATOM : 0);
   const int vf = (vflag_global ? MDP_VFLAG_GLOBAL : 0) | (vflag_atom ? MDP_VFLAG_ATOM : 0);
-  rc = mdp_rebomos_compute_host(dev, ef, vf, nlocal ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
+  // the forces' only reader is on the device too -- unless the host tallies or writes something this step
+  const bool f_stays = linked && !ef && !vf && update->ntimestep != output->next;
+  rc = mdp_rebomos_compute_host(dev, ef, vf, (nlocal && !f_stays) ? atom->f[0] : nullptr, &eng_vdwl, virial, eatom,
                                 (vflag_atom && vatom) ? vatom[0] : nullptr);
   if (rc != MDP_OK) fail_one(rc, "compute");
+}
+
+void *PairREBOMoS::extract(const char *str, int &dim)
+{
+  // what fix nve/mdp needs of this style: its device context and the switch that keeps x, v and f there
+  dim = 0;
+  if (strcmp(str, "mdp_ctx") == 0) return (void *) &dev;
+  if (strcmp(str, "mdp_nve_linked") == 0) return (void *) &nve_linked;
+  return nullptr;
 }
 
 double PairREBOMoS::memory_usage()

@@ -31,9 +31,11 @@ class PairREBOMoS : public Pair {
   void init_style() override;
   double init_one(int, int) override;
   double memory_usage() override;
+  void *extract(const char *, int &) override;
 
  protected:
   mdp_ctx *dev;                 // device context (one GPU per rank)
+  int nve_linked;               // set by fix nve/mdp: x, v and f of the owned atoms stay on the device between reneighborings
   mdp_rebomos_params params;    // the 61 file scalars after mixing
   bool params_read;
   double cut3rebo;              // 3 * rcmax_MM, the list cutoff the style asks the host for

@@ -69,7 +69,7 @@ def test_argument_checks_keep_reference_messages(script, msg):
 def test_plugin_registers_and_refuses_to_run_without_gpu():
     from lammps_plugins_amd.host import capi
     rc, out, err = _run(script_file="examples/in.rebomos-bulk.mi355x")
-    assert "Loaded 1 plugins from rebomosplugin.so" in out
+    assert "Loaded 2 plugins from rebomosplugin.so" in out          # pair rebomos + fix nve/mdp
     assert "Created 288 atoms" in out
     if capi.lib().mdp_device_count() == 0:
         assert rc == 1 and "needs a HIP device; there is no CPU fallback" in err
