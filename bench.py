@@ -372,6 +372,8 @@ def run_job(E, job, par):
             ev = 1 if thermo_every and n % thermo_every == 0 else 0
             if dist is None:
                 rebuild = "auto"
+            elif native:
+                rebuild = "halo"      # the collective decision rides with the position exchange (mdp_dd_comm_step_begin)
             else:
                 rebuild = bool(check_every and n % check_every == 0 and dom.needs_rebuild(margin))
             b0 = dom.builds
@@ -485,7 +487,8 @@ def run_job(E, job, par):
                    if dist is not None else "none (one GPU)",
                    "initial_temp_K": job["temp"], "skin": skin, "thermo_every": thermo_every,
                    "displacement_check": "every step, deferred on-device flag" if dist is None
-                   else f"every {check_every} steps, collective",
+                   else ("every step, every rank's flag gathered behind the position exchange (no blocking collective)"
+                         if native else f"every {check_every} steps, collective"),
                    "reneighborings_in_timed_region": rebuilds, "reneighbor_wall_ms": round(reneighbor_ms, 3),
                    "dangerous_builds": int(dom.dangerous),
                    "inner_skin": (float(os.environ["MDP_INNER_SKIN"]) if "MDP_INNER_SKIN" in os.environ
@@ -631,10 +634,11 @@ def main():
         rccl_ranks = int(round(float(one.item())))
         if rccl_ranks != world or dist.get_world_size() != world:
             raise SystemExit(f"bench.py: {world} ranks started, the collective saw {rccl_ranks}: no result")
-    # transport of the bricks' exchanges: "torch" = all-to-all through torch.distributed (RCCL), the default;
-    # MDP_BENCH_TRANSPORT=native = grouped ncclSend/ncclRecv inside libmdpair_hip.so (csrc/comm_rccl.hip; the
-    # process group then only distributes the communicator id)
-    native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "torch") == "native" and not stage_host
+    # transport of the bricks' exchanges: "native" (the default) = grouped ncclSend/ncclRecv inside libmdpair_hip.so
+    # (csrc/comm_rccl.hip: whole steps in two library calls, the `check yes` decision riding with the halo; the process
+    # group then only distributes the communicator id); MDP_BENCH_TRANSPORT=torch = all-to-all through torch.distributed
+    # (RCCL) with a collective displacement check every --check-every steps
+    native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "native") == "native" and not stage_host
     par = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, dev=dev, stage_host=stage_host, native=native,
                backend=backend, self_remote=self_remote)
 

@@ -381,6 +381,22 @@ int mdp_dd_comm_reverse(mdp_ctx *ctx);          /* Comm::reverse_comm of f (AEAM
 int mdp_dd_comm_aeam_exchange_begin(mdp_ctx *ctx, int with_reverse);
 int mdp_dd_comm_aeam_exchange_end(mdp_ctx *ctx);
 int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 max */);
+/* A whole step of a multi-GPU run in two calls (what the LAMMPS host does around Pair::compute in Verlet::run:
+ * initial_integrate, neighbor->decide, exchange / borders or forward_comm, force, final_integrate;
+ * log.rebomos-bulk.4:22,65-67 is such a run on four ranks).  The `neigh_modify every 1 check yes` decision is collective
+ * without a collective of the host's: every rank's "an owned atom moved beyond the trigger" word of a step is gathered
+ * behind that step's position exchange and read -- the same value on all ranks -- at the next step.
+ *   _begin: with_final = complete the half-kick a deferred step left; force_rebuild: -1 decide from the gathered word,
+ *           0 never, 1 reneighbor now; *reneighbored = 1 when the call reneighbored.  Integrates, reneighbors or starts
+ *           the position exchange, launches what needs no remote ghost of this step.
+ *   _end:   waits for the exchange, runs the rest of the compute (aeam: fp / ghost-force exchange behind the interior
+ *           pair forces when possible, the same exchanges in the blocking order otherwise), final half-kick now
+ *           (defer_final = 0) or fused into the next _begin (1).
+ * mdp_dd_comm_step_info: out[0] = aeam steps on the phased order, [1] = 1 if ghost forces travel, [2] = 1 if the last
+ * _begin reneighbored, [3] = reneighborings so far, [4] = checks that saw an owned atom beyond half the skin. */
+int mdp_dd_comm_step_begin(mdp_ctx *ctx, int with_final, int force_rebuild, int eflag, int vflag, int *reneighbored);
+int mdp_dd_comm_step_end(mdp_ctx *ctx, int eflag, int vflag, int defer_final);
+int mdp_dd_comm_step_info(mdp_ctx *ctx, long long out[8]);
 
 /* `neigh_modify every 1 delay 0 check yes` (sample.in:17-18, log.rebomos-bulk.1:46) without a host round trip per
  * step: *moved = outcome of the check launched by the PREVIOUS call (0 right after a reneighboring), then a check of

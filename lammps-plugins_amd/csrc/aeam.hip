@@ -1440,10 +1440,15 @@ __global__ void ang_list_kernel(const int nnonangular, int nlocal, const double4
   }
 }
 
-// count[1] = first tile whose union holds a remote ghost (index >= remote_start); tiles before it need no halo
+// count[1] = first tile whose union holds a remote ghost (index >= remote_start); tiles before it need no halo.
+// count[3], count[4] = largest union and most row entries among the tiles that reach none: the shell atoms of a brick
+// lie on a thin slab, 32 consecutive ones spread wider than 32 interior atoms and their unions are the largest of the
+// build -- the launches over the interior tiles size their LDS staging by their own maxima.
 __global__ __launch_bounds__(256) void tile_first_remote_kernel(const int ntile, const int cap, const int remote_start,
                                                                 const int *__restrict__ tile_nu,
-                                                                const int *__restrict__ tu, int *__restrict__ count)
+                                                                const int *__restrict__ tu,
+                                                                const long long *__restrict__ lj_off,
+                                                                int *__restrict__ count)
 {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1452,7 +1457,15 @@ __global__ __launch_bounds__(256) void tile_first_remote_kernel(const int ntile,
   const int nU = tile_nu[2 * t];
   int hit = 0;
   for (int u = lane; u < nU; u += 64) hit |= mem[u] >= remote_start;
-  if (__any(hit) && lane == 0) atomicMin(&count[1], t);
+  if (lane != 0) return;
+  if (__any(hit)) {
+    atomicMin(&count[1], t);
+  } else {
+    // (thousands of atomics on one word serialise: only a tile that would raise the maximum sends one)
+    const int rows = (int) (lj_off[(size_t) (t + 1) * kTile] - lj_off[(size_t) t * kTile]);
+    if (nU > __hip_atomic_load(&count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&count[3], nU);
+    if (rows > __hip_atomic_load(&count[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&count[4], rows);
+  }
 }
 
 inline int nblk(long long n, int per) { return (int) ((n + per - 1) / per); }
@@ -1481,14 +1494,14 @@ int mdp_aeam_prepare(mdp_ctx *c)
   MDP_HIP(c, c->rho.reserve(c->nall + 1));
   MDP_HIP(c, c->fp.reserve(c->nall + 1));
   MDP_HIP(c, c->ang_list.reserve(c->nlocal + 1));
-  MDP_HIP(c, c->ang_count.reserve(4));
+  MDP_HIP(c, c->ang_count.reserve(8));
   // resident mode: tile lists next to the CSR list (which the angular kernels and the steps
   // that tally energy / virial keep using).  The bin grid of the list build just done is still current.
   c->aeam_tiled = false;
   c->aeam_split = 0;
   c->aeam_ang_remote = false;
   c->aeam_phase = 0;
-  c->f_prezeroed = false; // (the atom arrays were rebuilt or re-ordered)
+  c->f_prezeroed = c->f_zero_remote_due = false; // (the atom arrays were rebuilt or re-ordered)
   const char *e = getenv("MDP_AEAM_TILE");
   // (tile kernels: up to MDP_AEAM_MAXT types -- their parameter block lives in the kernel arguments / in LDS)
   if ((c->md || c->aeam_device_lists) && c->nlocal > 0 && !(e && atoi(e) == 0) && c->aeam.ntypes <= MDP_AEAM_MAXT) {
@@ -1507,29 +1520,43 @@ int mdp_aeam_prepare(mdp_ctx *c)
     // angular centres; with remote ghosts (multi-GPU): the first tile that reaches one -- the tiles before it run
     // while the halo is in flight (domain.hip stores the shell atoms of the brick behind the interior ones)
     const bool remote = c->md && c->remote_start < c->nall;
-    const int init[3] = {0, remote && c->aeam_tiled ? c->ntile : 0, 0};
+    const int init[5] = {0, remote && c->aeam_tiled ? c->ntile : 0, 0, 0, 0};
     MDP_TRY(mdp_write_small(c, c->ang_count.p, init, sizeof init));
     if (remote && c->aeam_tiled)
       tile_first_remote_kernel<<<nblk(c->ntile, 4), 256, 0, st>>>(c->ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
-                                                                  c->tu.p, c->ang_count.p);
+                                                                  c->tu.p, c->lj_off.p, c->ang_count.p);
     if (c->nlocal)
       ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam.nnonangular, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p,
                                                             remote && c->aeam_tiled ? kTile * c->aeam_cl : 0);
     MDP_HIP(c, hipGetLastError());
-    int h[3] = {0, 0, 0};
+    int h[5] = {0, 0, 0, 0, 0};
     MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof h, h));
     c->h_ang_count = h[0];
     c->aeam_split = remote && c->aeam_tiled ? h[1] : 0;
+    c->tile_maxu_in = c->aeam_split > 0 ? h[3] : 0;
+    c->tile_rowmax_in = c->aeam_split > 0 ? h[4] : 0;
     c->aeam_ang_remote = remote && h[0] > 0 && (c->aeam_tiled ? h[2] != 0 : true);
     if (getenv("MDP_DEBUG"))
-      fprintf(stderr, "[mdp] aeam: %d angular centres; tiles [0, %d) of %d reach no remote ghost; ghost forces %s\n", h[0],
-              c->aeam_split, c->ntile, c->aeam_ang_remote ? "travel" : "stay");
+      fprintf(stderr, "[mdp] aeam: %d angular centres; tiles [0, %d) of %d reach no remote ghost (largest union %d of %d, rows %d of %d); ghost forces %s\n",
+              h[0], c->aeam_split, c->ntile, c->tile_maxu_in, c->tile_maxu, c->tile_rowmax_in, c->tile_rowmax,
+              c->aeam_ang_remote ? "travel" : "stay");
   }
   if (!c->aeam_tiled && !c->csr_full) { // no tile lists after all (a union outgrew LDS): the CSR kernels need every row
     c->csr_want_full = true;
     MDP_TRY(mdp_md_build_master_list(c));
   }
   return MDP_OK;
+}
+
+// largest union / most row entries of the tiles [.., t_end): the interior tiles' own maxima when the range lies before
+// the first tile that reaches a remote ghost (tile_first_remote_kernel)
+static inline int aeam_range_maxu(const mdp_ctx *c, const int t_end)
+{
+  return c->aeam_split > 0 && t_end <= c->aeam_split && c->tile_maxu_in > 0 ? c->tile_maxu_in : c->tile_maxu;
+}
+static inline int aeam_range_rowmax(const mdp_ctx *c, const int t_end)
+{
+  return c->aeam_split > 0 && t_end <= c->aeam_split && c->tile_rowmax_in > 0 ? c->tile_rowmax_in : c->tile_rowmax;
 }
 
 // Persistent density kernel (above): geometry of the launch over the tiles [t_begin, t_end).  *done stays false when
@@ -1553,8 +1580,8 @@ static int aeam_ptile_launch(mdp_ctx *c, const int t_begin, const int t_end, boo
     c->num_cu = n > 0 ? n : 256;
   }
   const AeamDev &A = c->aeam;
-  const int capL = (c->tile_maxu + 1 + 7) & ~7;
-  const int rowcapB = (2 * c->tile_rowmax + 15) & ~15;
+  const int capL = (aeam_range_maxu(c, t_end) + 1 + 7) & ~7;
+  const int rowcapB = (2 * aeam_range_rowmax(c, t_end) + 15) & ~15;
   const size_t sub_bytes = (size_t) capL * 3 * 8 + rowcapB;
   const int nr = A.nr[0]; // rows 1..nr of the (0,0) pair's table are addressed: m in [1, nr-1] and m+1
   const char *ens = getenv("MDP_AEAM_PT_NSUB");
@@ -1670,7 +1697,7 @@ static int aeam_density_tiles(mdp_ctx *c, const int t_begin, const int t_end)
   bool persistent = false;
   MDP_TRY(aeam_ptile_launch(c, t_begin, t_end, &persistent));
   if (persistent) return MDP_OK;
-  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const int capL = (aeam_range_maxu(c, t_end) + 1 + 7) & ~7;
   const bool multi = c->aeam.ntypes != 2; // per-entry types and an LDS parameter block (see par_fill)
   const size_t lds = (size_t) capL * 3 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
 #define MDP_ATD(CLV, MV)                                                                                             \
@@ -1700,7 +1727,7 @@ static int aeam_force_tiles(mdp_ctx *c, const int t_begin, const int t_end, cons
 {
   hipStream_t st = c->stream;
   if (t_end <= t_begin) return MDP_OK;
-  const int capL = (c->tile_maxu + 1 + 7) & ~7;
+  const int capL = (aeam_range_maxu(c, t_end) + 1 + 7) & ~7;
   const bool multi = c->aeam.ntypes != 2;
   const size_t lds = (size_t) capL * 4 * sizeof(double) + (multi ? kParBytes + (size_t) capL * sizeof(int) : 0);
   const bool ev = eflag || vflag;

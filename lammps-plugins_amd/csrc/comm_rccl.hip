@@ -96,6 +96,8 @@ int exchange_counts(mdp_ctx *c, const std::vector<int> &send, std::vector<int> &
   return MDP_OK;
 }
 
+constexpr int kFlagP2PRanks = 16;
+
 // ragged all-to-all of `width` doubles per record; segments in rank order on both sides
 int exchange(mdp_ctx *c, const double *sbuf, const int *scnt, double *rbuf, const int *rcnt, int width, hipStream_t st)
 {
@@ -120,6 +122,29 @@ int exchange(mdp_ctx *c, const double *sbuf, const int *scnt, double *rbuf, cons
   const ncclResult_t end = R->GroupEnd();
   if (first != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclSend/ncclRecv -> %s", R->GetErrorString(first));
   if (end != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclGroupEnd -> %s", R->GetErrorString(end));
+  return MDP_OK;
+}
+
+// The RCCL kernel of an exchange gets a head start over the compute kernel it is to overlap: measured on one MI355X
+// (profiles/r05_multi_gpu_step), a RCCL kernel that reaches the device a few microseconds AFTER a compute kernel that
+// fills it ends only when that kernel's grid has drained (a compute stream whose CU mask leaves 8 or 16 compute units
+// free changed nothing), one that is running already when the compute kernel arrives ends in its own time.  So the
+// context's stream waits for an event the communication stream records right in front of the RCCL kernel; that costs
+// the compute stream one cross-queue hand-over (about 18 us in the one-rank rehearsal).  Worth it where the kernel
+// behind the exchange is long -- aeam: ONE density kernel over the interior tiles (0.27 ms at 1.0 M atoms), ONE force
+// kernel (0.48 ms) -- and not for rebomos, whose first interior kernel ends after 0.04 ms with 0.12 ms of interior
+// centres still to come.  MDP_COMM_LEAD=0 / 1 forces it off / on for every style.
+int comm_lead(mdp_ctx *c)
+{
+  static const int lead = [] {
+    const char *e = getenv("MDP_COMM_LEAD");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  if (lead == 0 || (lead < 0 && c->cfg.style != 2)) return MDP_OK;
+  MdpDomain &D = c->dd;
+  if (!D.ev_lead) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_lead, hipEventDisableTiming));
+  MDP_HIP(c, hipEventRecord(D.ev_lead, D.comm_stream));
+  MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_lead, 0));
   return MDP_OK;
 }
 
@@ -156,7 +181,12 @@ int mdp_dd_comm_init(mdp_ctx *c, const void *id128)
   ncclComm_t comm = nullptr;
   MDP_NCCL(c, R->CommInitRank(&comm, D.G.nranks, id, D.G.rank));
   D.nccl_comm = comm;
-  if (!D.comm_stream) MDP_HIP(c, hipStreamCreateWithFlags(&D.comm_stream, hipStreamNonBlocking));
+  if (!D.comm_stream) {
+    // highest priority: the (one-workgroup) RCCL kernels must find a slot while a compute kernel fills the device
+    int least = 0, greatest = 0;
+    MDP_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    MDP_HIP(c, hipStreamCreateWithPriority(&D.comm_stream, hipStreamNonBlocking, greatest));
+  }
   if (!D.ev_packed) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_packed, hipEventDisableTiming));
   if (!D.ev_arrived) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_arrived, hipEventDisableTiming));
   return MDP_OK;
@@ -172,7 +202,8 @@ int mdp_dd_comm_destroy(mdp_ctx *c)
   D.comm_stream = nullptr;
   if (D.ev_packed) (void) hipEventDestroy(D.ev_packed);
   if (D.ev_arrived) (void) hipEventDestroy(D.ev_arrived);
-  D.ev_packed = D.ev_arrived = nullptr;
+  if (D.ev_lead) (void) hipEventDestroy(D.ev_lead);
+  D.ev_packed = D.ev_arrived = D.ev_lead = nullptr;
   D.sbuf.release();
   D.rbuf.release();
   D.cnt_dev.release();
@@ -227,13 +258,42 @@ int mdp_dd_comm_forward_begin(mdp_ctx *c)
 {
   MDP_TRY(comm_require(c));
   MdpDomain &D = c->dd;
-  if (!D.nsend && !D.nrecv) return MDP_OK;
+  if (!D.nsend && !D.nrecv && !D.step_mode) return MDP_OK; // (step mode: the all-gather below is collective)
   MDP_HIP(c, D.sbuf.reserve((size_t) 3 * D.nsend + 8));
   MDP_HIP(c, D.rbuf.reserve((size_t) 3 * D.nrecv + 8));
   MDP_TRY(mdp_dd_forward_pack(c, D.sbuf.p));
   MDP_HIP(c, hipEventRecord(D.ev_packed, c->stream));
   MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
-  MDP_TRY(exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream));
+  MDP_TRY(comm_lead(c));
+  // the ranks' "an atom of mine has moved beyond the trigger" words of this step travel WITH the positions (the
+  // integrate kernel of this step wrote this rank's; mdp_dd_forward_unpack reduces them for the next step's decision):
+  // one more double to and from every rank in the same group of ncclSend/ncclRecv -- one RCCL kernel per step -- up to
+  // kFlagP2PRanks ranks, an all-gather behind the positions on larger communicators
+  const bool flags = D.flagbuf.p && D.step_mode;
+  const int n = D.G.nranks;
+  if (flags && n <= kFlagP2PRanks) {
+    RcclApi *R = rccl();
+    MDP_NCCL(c, R->GroupStart());
+    const int rc = exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream);
+    ncclResult_t first = ncclSuccess; // (the group is always closed: see exchange())
+    for (int q = 0; q < n && first == ncclSuccess && rc == MDP_OK; q++) {
+      first = R->Send(D.flagbuf.p + D.flag_par, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+      if (first == ncclSuccess)
+        first = R->Recv(D.flagbuf.p + 2 + q, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+    }
+    const ncclResult_t end = R->GroupEnd();
+    if (rc != MDP_OK) return rc;
+    if (first != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclSend/ncclRecv -> %s", R->GetErrorString(first));
+    if (end != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclGroupEnd -> %s", R->GetErrorString(end));
+    D.fwd_gathered = true;
+  } else {
+    MDP_TRY(exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream));
+    if (flags) {
+      MDP_NCCL(c, rccl()->AllGather(D.flagbuf.p + D.flag_par, D.flagbuf.p + 2, 1, ncclDouble, (ncclComm_t) D.nccl_comm,
+                                    D.comm_stream));
+      D.fwd_gathered = true;
+    }
+  }
   MDP_HIP(c, hipEventRecord(D.ev_arrived, D.comm_stream));
   D.fwd_pending = true;
   return MDP_OK;
@@ -243,7 +303,7 @@ int mdp_dd_comm_forward_end(mdp_ctx *c)
 {
   MDP_TRY(comm_require(c));
   MdpDomain &D = c->dd;
-  if (!D.nsend && !D.nrecv) return MDP_OK;
+  if (!D.nsend && !D.nrecv && !D.step_mode) return MDP_OK;
   MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_arrived, 0));
   D.fwd_pending = false;
   return mdp_dd_forward_unpack(c, D.rbuf.p);
@@ -291,13 +351,15 @@ int mdp_dd_comm_aeam_exchange_begin(mdp_ctx *c, int with_reverse)
   if (!D.nsend && !D.nrecv) return MDP_OK;
   const int n = D.G.nranks;
   RcclApi *R = rccl();
-  // sbuf: [fp out: nsend][f in: 3 nsend]   rbuf: [fp in: nrecv][f out: 3 nrecv]
+  // sbuf: [fp out: nsend][f in: 3 nsend]
   MDP_HIP(c, D.sbuf.reserve((size_t) 4 * D.nsend + 8));
-  MDP_HIP(c, D.rbuf.reserve((size_t) 4 * D.nrecv + 8));
   MDP_TRY(mdp_dd_forward_scalar_pack(c, D.sbuf.p));
-  if (with_reverse) MDP_TRY(mdp_dd_reverse_pack(c, D.rbuf.p + D.nrecv));
+  // the remote ghosts lie in rank order behind the self-images: their forces leave from f itself and their fp arrives
+  // in fp itself (the interior tiles that run meanwhile touch neither)
+  double *gf = c->f.p + 3 * (size_t) (c->nlocal + D.nself), *gfp = c->fp.p + (size_t) (c->nlocal + D.nself);
   MDP_HIP(c, hipEventRecord(D.ev_packed, c->stream));
   MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
+  MDP_TRY(comm_lead(c));
   MDP_NCCL(c, R->GroupStart());
   ncclResult_t first = ncclSuccess; // (the group is always closed: see exchange())
   size_t so = 0, ro = 0;
@@ -305,10 +367,10 @@ int mdp_dd_comm_aeam_exchange_begin(mdp_ctx *c, int with_reverse)
     const size_t ns = (size_t) D.bord_send[q], nr = (size_t) D.bord_recv[q];
     if (ns) first = R->Send(D.sbuf.p + so, ns, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
     if (nr && first == ncclSuccess)
-      first = R->Recv(D.rbuf.p + ro, nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+      first = R->Recv(gfp + ro, nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
     if (with_reverse) {
       if (nr && first == ncclSuccess)
-        first = R->Send(D.rbuf.p + D.nrecv + 3 * ro, 3 * nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+        first = R->Send(gf + 3 * ro, 3 * nr, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
       if (ns && first == ncclSuccess)
         first = R->Recv(D.sbuf.p + D.nsend + 3 * so, 3 * ns, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
     }
@@ -333,8 +395,101 @@ int mdp_dd_comm_aeam_exchange_end(mdp_ctx *c)
   D.fwd_pending = false;
   const int rev = D.aeam_pending == 2;
   D.aeam_pending = 0;
-  MDP_TRY(mdp_dd_forward_scalar_unpack(c, D.rbuf.p));
-  if (rev) MDP_TRY(mdp_dd_reverse_unpack(c, D.sbuf.p + D.nsend));
+  if (rev) MDP_TRY(mdp_dd_reverse_unpack(c, D.sbuf.p + D.nsend)); // (fp arrived in place)
+  return MDP_OK;
+}
+
+// ---- a whole step in two calls ------------------------------------------------------------------------------------
+// What a host does around Pair::compute in a step of a multi-GPU run (Verlet::run: initial_integrate, neighbor->decide,
+// comm->exchange / borders or forward_comm, force, final_integrate), with the `neigh_modify every 1 check yes` decision
+// taken from the word that travelled with the previous step's halo (MdpDomain::flagbuf): no blocking call, no
+// collective of the host's own, identical on all ranks.
+//   _begin: integrate (with the final half-kick a deferred step left, with_final), decide, reneighbor or start the
+//           position exchange, then everything of the compute that needs no remote ghost of this step
+//           (rebomos: interior centres; aeam: density of the interior tiles).      force_rebuild: -1 decide, 0 no, 1 yes
+//   _end:   the exchange arrives, the rest of the compute -- aeam with its fp / ghost-force exchange behind the interior
+//           pair forces when the step is on the phased order -- and the final half-kick (or its deferral, defer_final)
+int mdp_dd_comm_step_begin(mdp_ctx *c, int with_final, int force_rebuild, int eflag, int vflag, int *reneighbored)
+{
+  MDP_TRY(comm_require(c));
+  MdpDomain &D = c->dd;
+  if (reneighbored) *reneighbored = 0;
+  if (!D.flagbuf.p) {
+    MDP_HIP(c, D.flagbuf.reserve((size_t) 2 + D.G.nranks + 8));
+    MDP_HIP(c, hipMemsetAsync(D.flagbuf.p, 0, sizeof(double) * ((size_t) 2 + D.G.nranks + 8), c->stream));
+  }
+  D.step_mode = true;
+  // the answer the previous step's halo brought (complete long ago: its unpack kernel ran before that step's forces)
+  int glob = 0;
+  if (D.glob_pending) {
+    MDP_HIP(c, hipEventSynchronize(D.ev_glob_ref));
+    glob = *(int *) (c->h_pinned + 46);
+    D.glob_pending = false;
+  }
+  int moved = 0, dangerous = 0;
+  const bool rebuild = force_rebuild > 0 || (force_rebuild < 0 && glob);
+  if (rebuild) {
+    // (no check of the new positions: they are about to become the reference)
+    MDP_TRY(mdp_md_advance(c, with_final != 0, nullptr, 0.0, 0.0));
+    D.moved_pending = false;
+    MDP_TRY(mdp_dd_comm_reneighbor(c));
+    if (c->cfg.style == 2) { // the reverse exchange of a step is skipped by all ranks alike when nobody has ghost forces
+      int st[4] = {0, 0, 0, 0};
+      MDP_TRY(mdp_md_aeam_state(c, st));
+      double v = st[3] ? 1.0 : 0.0;
+      MDP_TRY(mdp_dd_comm_allreduce(c, &v, 1, 1));
+      D.ghost_forces = v > 0.0;
+    }
+    D.fresh_ghosts = true;
+    if (reneighbored) *reneighbored = 1;
+  } else {
+    MDP_TRY(mdp_md_integrate_check(c, with_final, &moved, &dangerous)); // (this rank's word for the peers; `moved` itself is not used)
+    if (dangerous) D.dangerous++;
+    D.fresh_ghosts = false;
+    MDP_TRY(mdp_dd_comm_forward_begin(c));
+  }
+  return mdp_md_compute_begin(c, eflag, vflag);
+}
+
+int mdp_dd_comm_step_end(mdp_ctx *c, int eflag, int vflag, int defer_final)
+{
+  MDP_TRY(comm_require(c));
+  MdpDomain &D = c->dd;
+  if (!D.fresh_ghosts) MDP_TRY(mdp_dd_comm_forward_end(c));
+  if (c->cfg.style == 1) {
+    MDP_TRY(mdp_md_compute_end(c, eflag, vflag));
+  } else {
+    MDP_TRY(mdp_md_aeam_density(c, eflag)); // B: the rest of passes 1 + 2 (+ three-body forces when A ran)
+    int st[4] = {0, 0, 0, 0};
+    MDP_TRY(mdp_md_aeam_state(c, st));
+    if (st[0] & 4) { // on the phased order: fp out and ghost forces back behind the interior pair forces
+      D.steps_phased++;
+      MDP_TRY(mdp_dd_comm_aeam_exchange_begin(c, D.ghost_forces ? 1 : 0));
+      MDP_TRY(mdp_md_aeam_force_begin(c, eflag, vflag));
+      MDP_TRY(mdp_dd_comm_aeam_exchange_end(c));
+      MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
+    } else { // this rank's rows were due for pruning (or a per-atom-virial step): the SAME exchanges, in the same order
+      MDP_TRY(mdp_dd_comm_forward_scalar(c));
+      MDP_TRY(mdp_md_aeam_force(c, eflag, vflag));
+      if (D.ghost_forces) MDP_TRY(mdp_dd_comm_reverse(c));
+      else MDP_TRY(mdp_md_fold_self_ghost_f(c));
+    }
+  }
+  if (defer_final) return mdp_md_defer_final(c);
+  return mdp_md_final_integrate(c);
+}
+
+// [0] = aeam steps on the phased order so far, [1] = ghost forces travel (aeam), [2] = the last _begin reneighbored,
+// [3] = reneighborings, [4] = checks that saw an owned atom beyond half the skin ("dangerous builds")
+int mdp_dd_comm_step_info(mdp_ctx *c, long long out[8])
+{
+  if (!c || !out) return MDP_EINVAL;
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  out[0] = c->dd.steps_phased;
+  out[1] = c->dd.ghost_forces ? 1 : 0;
+  out[2] = c->dd.fresh_ghosts ? 1 : 0;
+  out[3] = c->dd.reneighbors;
+  out[4] = c->dd.dangerous;
   return MDP_OK;
 }
 

@@ -155,16 +155,25 @@ __global__ __launch_bounds__(256) void dd_order_key_kernel(const DdGeom G, const
   double lam[3];
   dd_x2lamda(G, x.x, x.y, x.z, lam);
   unsigned c[3];
-#pragma unroll
-  for (int d = 0; d < 3; d++) c[d] = dd_cell10(lam[d] * G.g[d] - G.me[d]);
   unsigned long long shell = 0;
+  double u[3], lo[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int d = 0; d < 3; d++) u[d] = lam[d] * G.g[d] - G.me[d];
   if (shell_last) {
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-      const double u = lam[d] * G.g[d] - G.me[d], w = G.cutl[d] * G.g[d];
-      if ((G.g[d] > 1 || G.self_remote) && (u < w || u >= 1.0 - w)) shell = 1ull << 62;
+      const double w = G.cutl[d] * G.g[d];
+      if (G.g[d] > 1 || G.self_remote) {
+        if (u[d] < w || u[d] >= 1.0 - w) shell = 1ull << 62;
+        if (w < 0.45) lo[d] = w;
+      }
     }
   }
+  // interior atoms: the curve fills the INTERIOR box (the brick minus its shell) -- the brick's own curve leaves it for
+  // excursions through the shell, and 32 consecutive interior atoms either side of one are two clumps with a union of
+  // nearly twice the size (the largest union sizes the LDS staging of every tile of a launch)
+#pragma unroll
+  for (int d = 0; d < 3; d++) c[d] = dd_cell10(shell ? u[d] : (u[d] - lo[d]) / (1.0 - 2.0 * lo[d]));
   key[i] = shell | ((unsigned long long) mdp_hilbert30(c[0], c[1], c[2]) << 32) | (unsigned) tag[i];
 }
 
@@ -837,7 +846,7 @@ int mdp_md_moved_async(mdp_ctx *c, int *moved, int *dangerous)
   if (!D.ev_moved) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_moved, hipEventDisableTiming));
   int m = 0, dg = 0;
   if (D.moved_pending) {
-    MDP_HIP(c, hipEventSynchronize(D.ev_moved));
+    MDP_HIP(c, hipEventSynchronize(D.ev_moved_ref ? D.ev_moved_ref : D.ev_moved));
     m = h[0];
     dg = h[1];
     D.moved_pending = false;
@@ -853,6 +862,7 @@ int mdp_md_moved_async(mdp_ctx *c, int *moved, int *dangerous)
   dd_moved_kernel<<<grid, 256, 0, st>>>(c->nlocal, trig * trig, hard * hard, c->xq.p, c->xhold.p, h);
   MDP_HIP(c, hipGetLastError());
   MDP_HIP(c, hipEventRecord(D.ev_moved, st));
+  D.ev_moved_ref = D.ev_moved;
   D.moved_pending = true;
   return MDP_OK;
 }
@@ -869,7 +879,7 @@ int mdp_md_integrate_check(mdp_ctx *c, int with_final, int *moved, int *dangerou
   if (!D.ev_moved) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_moved, hipEventDisableTiming));
   int m = 0, dg = 0;
   if (D.moved_pending) {
-    MDP_HIP(c, hipEventSynchronize(D.ev_moved));
+    MDP_HIP(c, hipEventSynchronize(D.ev_moved_ref ? D.ev_moved_ref : D.ev_moved));
     m = h[0];
     dg = h[1];
     D.moved_pending = false;
@@ -882,7 +892,14 @@ int mdp_md_integrate_check(mdp_ctx *c, int with_final, int *moved, int *dangerou
   double trig = hard - 0.1 * mdp_margin_scale(c);
   if (trig < 0.5 * hard) trig = 0.5 * hard;
   MDP_TRY(mdp_md_advance(c, with_final != 0, h, trig * trig, hard * hard));
-  MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+  // the integrate kernel wrote h; when mdp_md_advance has recorded the style-check event behind that kernel (no remote
+  // ghosts), that event serves this reader too
+  if (c->sflag_armed && c->sflag_committed[c->sflag_set]) {
+    D.ev_moved_ref = c->ev_sflag[c->sflag_set];
+  } else {
+    MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+    D.ev_moved_ref = D.ev_moved;
+  }
   D.moved_pending = true;
   return MDP_OK;
 }

@@ -215,9 +215,11 @@ template <bool FINAL, bool CHECK>
 __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const double *__restrict__ rmass,
                                    double *__restrict__ f, double *__restrict__ v, double4 *__restrict__ xq,
                                    const mdp_hold_t *__restrict__ xhold, const double trigsq, const double hardsq,
-                                   int *__restrict__ flag, const MdpStyleCheck SC, const int zero_f)
+                                   int *__restrict__ flag, const MdpStyleCheck SC, const int zero_f,
+                                   double *__restrict__ dflag_set = nullptr, double *__restrict__ dflag_clear = nullptr)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (CHECK && dflag_clear && i == 0) *dflag_clear = 0.0; // (the word of the next step; this step's was cleared a step ago)
   bool t = false, h = false, sa = false, sah = false, sp = false, sph = false;
   if (SC.acc) { // what acc_zero_kernel does
     for (int k = i; k < SC.nacc; k += gridDim.x * 256) SC.acc[k] = 0.0;
@@ -275,7 +277,10 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
     }
   }
   if (CHECK) { // (pinned host words zeroed by the host before the launch: plain idempotent stores)
-    if (__ballot(t) && (threadIdx.x & 63) == 0) flag[0] = 1;
+    if (__ballot(t) && (threadIdx.x & 63) == 0) {
+      flag[0] = 1;
+      if (dflag_set) *dflag_set = 1.0; // the same answer for the peers: travels with this step's halo
+    }
     if (__ballot(h) && (threadIdx.x & 63) == 0) flag[1] = 1;
   }
   if (SC.flag && (threadIdx.x & 63) == 0) {
@@ -398,9 +403,15 @@ __global__ void pack_x_kernel(int n, const int *__restrict__ sendlist, const dou
 
 // SC: the style-level displacement checks of the arriving remote ghosts (MdpStyleCheck; flag words [4..7])
 __global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf, double4 *__restrict__ xq,
-                                const MdpStyleCheck SC)
+                                const MdpStyleCheck SC, const double *__restrict__ gflag = nullptr, const int ngflag = 0,
+                                int *__restrict__ h_glob = nullptr, double *__restrict__ fzero = nullptr)
 {
   const int k = blockIdx.x * 256 + threadIdx.x;
+  if (h_glob && k == 0) { // the ranks' "moved" words as gathered behind this halo -> one pinned word (MdpDomain::flagbuf)
+    double m = 0.0;
+    for (int q = 0; q < ngflag; q++) m = gflag[q] > m ? gflag[q] : m;
+    *h_glob = m > 0.0 ? 1 : 0;
+  }
   bool sa = false, sah = false, sp = false, sph = false;
   if (k < n) {
     const size_t i = (size_t) first + k;
@@ -409,6 +420,7 @@ __global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf
     x.y = buf[3 * (size_t) k + 1];
     x.z = buf[3 * (size_t) k + 2];
     xq[i] = x;
+    if (fzero) fzero[3 * i] = fzero[3 * i + 1] = fzero[3 * i + 2] = 0.0; // (force_clear of a style that accumulates, see mdp_md_advance)
     if (SC.xa) {
       const double dx = x.x - SC.xa[3 * i], dy = x.y - SC.xa[3 * i + 1], dz = x.z - SC.xa[3 * i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
@@ -838,14 +850,24 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
   // of the images when every ghost is a periodic self-image (one GPU).  The flag is dropped by whatever rebuilds or
   // re-orders the atom arrays before the compute (mdp_aeam_prepare) -- the compute then clears f itself.
   const int nself = c->remote_start >= c->nlocal && c->remote_start <= c->nall ? c->remote_start - c->nlocal : c->nghost;
-  const bool zero_f = c->cfg.style == 2 && c->nlocal > 0 && nself == c->nghost && c->neigh_set && c->f.p;
+  // Bricks whose whole step runs in the library (mdp_dd_comm_step_begin): the forces of the remote ghosts are cleared by
+  // the halo unpack of the step (mdp_md_unpack_x), which every such step runs before its first force kernel.
+  const bool zero_f = c->cfg.style == 2 && c->nlocal > 0 && c->neigh_set && c->f.p &&
+                      (nself == c->nghost || (c->dd.step_mode && c->dd.nccl_comm));
+  // (several GPUs, library transport: this rank's "moved" word for the peers, see MdpDomain::flagbuf)
+  double *dset = nullptr, *dclr = nullptr;
+  if (flag && c->dd.flagbuf.p && c->dd.nccl_comm) {
+    c->dd.flag_par ^= 1;
+    dset = c->dd.flagbuf.p + c->dd.flag_par;
+    dclr = c->dd.flagbuf.p + (c->dd.flag_par ^ 1);
+  }
   if (c->nlocal) {
     const int g = nblk(c->nlocal);
     MdpStyleCheck sc;
     mdp_sflag_arm(c, sc);
 #define MDP_ADV(FV, CV)                                                                                               \
   nve_advance_kernel<FV, CV><<<g, 256, 0, c->stream>>>(c->nlocal, dtf, c->cfg.dt, c->rmass.p, c->f.p, c->v.p, c->xq.p, \
-                                                      c->xhold.p, trigsq, hardsq, flag, sc, zero_f ? 1 : 0)
+                                                      c->xhold.p, trigsq, hardsq, flag, sc, zero_f ? 1 : 0, dset, dclr)
     if (with_final) {
       if (flag) MDP_ADV(true, true);
       else MDP_ADV(true, false);
@@ -864,6 +886,7 @@ int mdp_md_advance(mdp_ctx *c, bool with_final, int *flag, double trigsq, double
                                                              zero_f ? c->f.p : nullptr);
   MDP_HIP(c, hipGetLastError());
   c->f_prezeroed = zero_f;
+  c->f_zero_remote_due = zero_f && nself != c->nghost; // (mdp_md_unpack_x of this step clears the remote ghosts' forces)
   return MDP_OK;
 }
 
@@ -911,7 +934,7 @@ int mdp_md_aeam_density(mdp_ctx *c, int eflag)
   MDP_TRY(mdp_aeam_run_density(c, eflag));
   // forward comm of fp on one rank: periodic self-images copy their owner's value -- normally done by the embedding
   // kernel itself (aeam_img_fp)
-  if (c->nghost && !c->aeam_img_fp)
+  if (c->nghost && !c->aeam_img_fp && !(c->dd.on && c->dd.nself == 0)) // (a brick without periodic self-images: nothing to copy)
     ghost_scalar_refresh_kernel<<<nblk(c->nghost), 256, 0, c->stream>>>(c->nlocal, c->nghost, c->ghost_owner.p,
                                                                         c->fp.p);
   MDP_HIP(c, hipGetLastError());
@@ -1063,7 +1086,7 @@ int mdp_hnve_initial(mdp_ctx *c, int *moved, int *dangerous)
   if (!D.ev_moved) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_moved, hipEventDisableTiming));
   int m = 0, dg = 0;
   if (D.moved_pending) {
-    MDP_HIP(c, hipEventSynchronize(D.ev_moved));
+    MDP_HIP(c, hipEventSynchronize(D.ev_moved_ref ? D.ev_moved_ref : D.ev_moved));
     m = h[0];
     dg = h[1];
     D.moved_pending = false;
@@ -1081,6 +1104,7 @@ int mdp_hnve_initial(mdp_ctx *c, int *moved, int *dangerous)
                                                                     c->xhold.p, trig * trig, hard * hard, h, sc, 0);
     MDP_HIP(c, hipGetLastError());
     MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+    D.ev_moved_ref = D.ev_moved;
     D.moved_pending = true;
   }
   MDP_TRY(mdp_host_refresh_ghosts(c));  // Comm::forward_comm of x on one periodic rank
@@ -1434,9 +1458,30 @@ int mdp_md_unpack_x(mdp_ctx *c, int first_ghost, int n, const double *d_buf)
     sc = c->sflag_chk;
     sc.acc = nullptr;
   }
-  if (n) unpack_x_kernel<<<nblk(n), 256, 0, c->stream>>>(n, c->nlocal + first_ghost, d_buf, c->xq.p, sc);
+  // (library transport with the displacement words gathered behind this halo: reduced here, read by the next step)
+  MdpDomain &D = c->dd;
+  const bool glob = D.flagbuf.p && D.nccl_comm && D.fwd_gathered;
+  int *h_glob = (int *) (c->h_pinned + 46);
+  if (n || glob)
+    unpack_x_kernel<<<nblk(n > 0 ? n : 1), 256, 0, c->stream>>>(n, c->nlocal + first_ghost, d_buf, c->xq.p, sc,
+                                                                glob ? D.flagbuf.p + 2 : nullptr, glob ? D.G.nranks : 0,
+                                                                glob ? h_glob : nullptr,
+                                                                c->f_zero_remote_due ? c->f.p : nullptr);
+  c->f_zero_remote_due = false;
   MDP_HIP(c, hipGetLastError());
+  // one event behind this kernel serves both readers of its pinned words (an event record costs the stream ~5 us)
   if (c->sflag_armed) MDP_TRY(mdp_sflag_commit(c));
+  if (glob) {
+    if (c->sflag_armed) {
+      D.ev_glob_ref = c->ev_sflag[c->sflag_set];
+    } else {
+      if (!D.ev_glob) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_glob, hipEventDisableTiming));
+      MDP_HIP(c, hipEventRecord(D.ev_glob, c->stream));
+      D.ev_glob_ref = D.ev_glob;
+    }
+    D.glob_pending = true;
+    D.fwd_gathered = false;
+  }
   return MDP_OK;
 }
 

@@ -202,16 +202,31 @@ struct MdpDomain {
   DevBuf<double> sendshift, v_tmp;
   DevBuf<double4> xq_tmp;
   // deferred displacement trigger of the host-level skin (neigh_modify check yes)
-  hipEvent_t ev_moved = nullptr;
+  hipEvent_t ev_moved = nullptr, ev_moved_ref = nullptr; // (_ref: ev_moved, or the style-check event behind the same kernel)
   bool moved_pending = false;
   // RCCL transport inside the library (comm_rccl.hip)
   void *nccl_comm = nullptr;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_lead = nullptr;
   DevBuf<double> sbuf, rbuf, abuf; // abuf: the all-reduce's own words
   bool fwd_pending = false;        // a position exchange is in flight between _forward_begin and _forward_end
   int aeam_pending = 0;            // the aeam fp (1) / fp + ghost force (2) exchange is in flight
   DevBuf<int> cnt_dev;
+  // The collective `check yes` decision rides with the halo (mdp_dd_comm_step_begin / _end): the integrate kernel of a
+  // step leaves "an owned atom of this rank has moved beyond the trigger" in a device word (two words alternate: the
+  // kernel sets one and clears the other), an all-gather of that word follows the position exchange on the
+  // communication stream, the halo unpack reduces the ranks' words into a pinned word, and every rank reads the SAME
+  // answer at its next step -- no blocking thermo call, no host-side collective.
+  DevBuf<double> flagbuf;          // [0..1] this rank's word of the even / odd steps, [2 .. 2 + nranks) the ranks' words as gathered
+  int flag_par = 0;
+  hipEvent_t ev_glob = nullptr, ev_glob_ref = nullptr; // (_ref: ev_glob, or the style-check event recorded behind the same kernel)
+  bool glob_pending = false;
+  bool step_mode = false;          // the host drives whole steps (mdp_dd_comm_step_begin / _end): the words are gathered every step
+  bool fwd_gathered = false;       // the all-gather of the words was queued behind the position exchange in flight
+  bool fresh_ghosts = false;       // the border exchange of a reneighboring carried the current positions
+  bool ghost_forces = true;        // aeam: some rank has an angular centre next to a remote ghost (decided per reneighboring)
+  long long dangerous = 0;         // step mode: checks that saw an owned atom beyond half the skin
+  long long steps_phased = 0;      // aeam steps whose exchanges travelled behind the interior tiles
 };
 
 constexpr int MDP_UP_RING = 2;      // host-mode upload: pinned staging chunks in flight
@@ -302,6 +317,7 @@ struct mdp_ctx {
   // hold 16-bit indices into it (lj16), so every global gather is amortised over ~7 uses
   bool lj_tiled = false;
   int ntile = 0, tile_cap = 0, tile_maxu = 0, tile_rowmax = 0; // (rowmax: most row entries of one tile, generic builder)
+  int tile_maxu_in = 0, tile_rowmax_in = 0; // the same among the tiles that reach no remote ghost (aeam, bricks)
   int lj_class_base[5] = {0, 0, 0, 0, 0}; // ranges of cl_order: small / large unions (the last two are empty)
   bool lj_ordered = false;        // cl_order in use (otherwise natural order, everything in class 0)
   int tile_small = 0;             // largest union of the "small" launch classes
@@ -330,6 +346,7 @@ struct mdp_ctx {
   bool hn_v_current = false;      // c->v / c->rmass match the atoms of the last mdp_set_atoms_host
   int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
   bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
+  bool f_zero_remote_due = false; // ... except the remote ghosts' part, which this step's halo unpack clears (bricks, step mode)
   bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too
   DevBuf<int> lj_fix_stamp;       // [ntile] stamp of the compute that last listed the tile for rebo_lj_cubic_kernel
   int lj_stamp = 0;

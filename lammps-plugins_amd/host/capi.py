@@ -65,7 +65,7 @@ EXPORTS = [
     "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_integrate_check", "mdp_md_download_int", "mdp_md_download_x_all",
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
-    "mdp_dd_comm_allreduce", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
+    "mdp_dd_comm_allreduce", "mdp_dd_comm_step_begin", "mdp_dd_comm_step_end", "mdp_dd_comm_step_info", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
     "mdp_md_defer_final", "mdp_md_list_state", "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
 ]
 
@@ -563,6 +563,21 @@ class Context:
 
     def dd_comm_aeam_exchange_end(self):
         self._ck(self.L.mdp_dd_comm_aeam_exchange_end(self.h))
+
+    def dd_comm_step_begin(self, with_final=False, force_rebuild=-1, eflag=0, vflag=0):
+        r = C.c_int(0)
+        self._ck(self.L.mdp_dd_comm_step_begin(self.h, C.c_int(1 if with_final else 0), C.c_int(force_rebuild), C.c_int(eflag),
+                                               C.c_int(vflag), C.byref(r)))
+        return bool(r.value)
+
+    def dd_comm_step_end(self, eflag=0, vflag=0, defer_final=False):
+        self._ck(self.L.mdp_dd_comm_step_end(self.h, C.c_int(eflag), C.c_int(vflag), C.c_int(1 if defer_final else 0)))
+
+    def dd_comm_step_info(self):
+        out = (C.c_longlong * 8)()
+        self._ck(self.L.mdp_dd_comm_step_info(self.h, out))
+        return dict(aeam_phased=int(out[0]), ghost_forces=bool(out[1]), reneighbored=bool(out[2]), reneighbors=int(out[3]),
+                    dangerous=int(out[4]))
 
     def dd_comm_allreduce(self, values, op=0):
         v = np.ascontiguousarray(values, dtype=np.float64).copy()

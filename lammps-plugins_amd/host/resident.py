@@ -333,9 +333,27 @@ class DeviceDomain:
         half-kicks in one pass (mdp_md_final_initial_integrate; same arithmetic) -- for steps after which nothing
         reads the velocities; thermo() / compute() / reneighbor() / flush() complete it otherwise."""
         ctx = self.ctx
+        if self.native and self.tr is not None:
+            # The library's own transport drives the whole step in two calls (mdp_dd_comm_step_begin / _end): integrate,
+            # decide, reneighbor or exchange, compute, final kick.  rebuild="halo" (or "auto"): the collective `check yes`
+            # decision comes from the word that travelled with the previous step's halo -- no blocking call here.
+            force = -1 if isinstance(rebuild, str) else (1 if rebuild else 0)
+            ren = ctx.dd_comm_step_begin(self._final_pending, force, eflag, vflag)
+            self._final_pending = False
+            if ren:
+                info = ctx.dd_info()
+                self.nlocal, self.nself, self.nsend, self.nrecv = info["nlocal"], info["nself"], info["nsend"], info["nrecv"]
+                self.nghost = self.nself + self.nrecv
+                self.builds += 1
+            ctx.dd_comm_step_end(eflag, vflag, defer_final)
+            self._final_pending = bool(defer_final)
+            si = ctx.dd_comm_step_info()
+            self.aeam_overlapped, self.ghost_forces, self.dangerous = si["aeam_phased"], si["ghost_forces"], si["dangerous"]
+            return
         if isinstance(rebuild, str):        # "auto": one GPU, deferred on-device flag read every step
             if self.tr is not None:
-                raise ValueError("rebuild='auto' is for one-GPU runs; several ranks decide collectively (needs_rebuild)")
+                raise ValueError("rebuild='auto' is for one-GPU runs; the torch / thread transports decide collectively "
+                                 "(needs_rebuild); the library's transport takes rebuild='halo'")
             rebuild, late = ctx.md_integrate_check(self._final_pending)   # integrate + check in one pass
             self.dangerous += int(late)
         elif self._final_pending:

@@ -459,6 +459,64 @@ def test_rccl_transport_inside_the_library_on_one_gpu(style, oracle):
 
 
 @pytest.mark.parametrize("style", ["rebomos", "aeam"])
+def test_whole_steps_in_the_library_with_the_check_flag_riding_in_the_halo(style):
+    """mdp_dd_comm_step_begin / _end (one-rank communicator, every image remote): integrate, the `check yes` decision
+    from the word gathered behind the PREVIOUS step's position exchange, reneighbor or exchange, compute, final kick --
+    two library calls per step, no blocking check.  A drifting hot system reneighbors by itself several times; the
+    trajectory is the one-GPU run's (whose own deferred flag fires on the same evidence)."""
+    if style == "rebomos":
+        s = S.jitter(S.replicate(S.rebomos_bulk_cell(), (2, 2, 1)), 0.05, seed=27)
+        v0 = S.gaussian_velocities(s, 300.0, seed=5) + np.array([60.0, -30.0, 20.0])   # < 0.1 A per step: never late
+        st = capi.STYLE_REBOMOS
+    else:
+        s = S.jitter(S.fcc_cell(4.045, 12, frac_type2=0.05, seed=19), 0.04, seed=20)
+        s.mass[1:3] = capi.AeamFile(POT_AEAM).mass[:2]
+        v0 = S.gaussian_velocities(s, 600.0, seed=6) + np.array([40.0, 25.0, -30.0])
+        st = capi.STYLE_AEAM
+    steps = 60
+
+    def run(native):
+        if st == capi.STYLE_REBOMOS:
+            ctx, cutghost = _rebo_ctx()
+            skin, map_ = 2.0, MAP
+        else:
+            ctx = capi.Context(0)
+            af = capi.AeamFile(POT_AEAM)
+            tabs = af.build()
+            ctx.aeam_set_tables(tabs)
+            ctx._af = (af, tabs)
+            skin, map_ = 1.0, None
+            cutghost = float(af.cut_table(tabs).max()) + skin
+        tr = resident.NativeTransport(1, 0) if native else None
+        d = resident.DeviceDomain(ctx, st, s, cutghost, skin, map_, v0=v0, transport=tr, self_remote=native)
+        d.compute(0, 0)
+        for step in range(1, steps + 1):
+            last = step == steps
+            d.step(1 if last else 0, 1 if last else 0, rebuild="halo" if native else "auto", defer_final=not last)
+        th = d.thermo()
+        tags, a = _by_tag(d, ("x", "v"))
+        order = np.argsort(tags)
+        info = ctx.dd_comm_step_info() if native else None
+        builds, late = d.builds, d.dangerous
+        ctx.close()
+        return th, a["x"][order], a["v"][order], builds, late, info
+
+    pth, px, pv, pb, pl, _ = run(False)
+    nth, nx, nv, nb, nl, info = run(True)
+    assert pb >= 3 and nb >= 3 and abs(nb - pb) <= 1          # both reneighbored by themselves, on the same evidence
+    assert nl == 0 and pl == 0                                 # ... and never late
+    assert info["reneighbors"] == nb
+    if style == "aeam":
+        assert info["aeam_phased"] > 0
+    dx = nx - px
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(nv - pv).max() < 1e-7
+    assert nth["pe"] == pytest.approx(pth["pe"], rel=1e-10)
+    assert nth["ke"] == pytest.approx(pth["ke"], rel=1e-9)
+
+
+@pytest.mark.parametrize("style", ["rebomos", "aeam"])
 def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch):
     """Dynamic pruning of the tile rows (tile_prune_kernel): a hot run with a narrow buffer prunes every few steps;
     positions and velocities after 60 steps must agree with the run that walks the rows as built to rounding (the
