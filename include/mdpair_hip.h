@@ -155,6 +155,14 @@ int mdp_set_skin(mdp_ctx *ctx, double skin);
  * any difference.  Call at every reneighboring after mdp_set_atoms_host.  MDP_SKIP_LIST_CHECK=1 disables it. */
 int mdp_rebomos_check_host_list(mdp_ctx *ctx, int inum, const int *ilist, const int *numneigh, int *const *firstneigh,
                                 double cutneigh);
+/* rebomos, host mode: 1 = candidates (REBO_neigh, pair_rebomos.cpp:281-352) and Lennard-Jones rows (FLJ, :490-495)
+ * are taken from the HOST's full + ghost neighbor list, handed over with mdp_set_neighbors_host (inum + gnum rows,
+ * entries masked with NEIGHMASK as the reference does, :328-330) at every reneighboring -- subsets of what the host
+ * listed, so `neigh_modify exclude` and special-bond settings act as in the reference instead of stopping the run
+ * (mdp_rebomos_check_host_list is then not called).  The device keeps the host's atom order and the host's ghosts
+ * (no mdp_set_box_host images, no fix nve/mdp) and pays the upload of the list: ~640 entries per atom at the
+ * reference's 13.4 A list cutoff.  Call before mdp_set_atoms_host.  0 (default): lists from the positions. */
+int mdp_rebomos_host_list(mdp_ctx *ctx, int on);
 /* aeam, host mode: 1 = the style builds its lists on the device from the positions, exactly as rebomos does
  * (bins, tile lists, CSR rows of the angular centres) and the host only reports its skin (mdp_set_skin) at every
  * reneighboring; the device keeps its own Hilbert-sorted copy of the atoms and returns results in the host's order.

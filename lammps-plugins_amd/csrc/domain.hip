@@ -587,8 +587,7 @@ int mdp_dd_migrate_end(mdp_ctx *c, int narrive, const double *d_buf)
   MDP_HIP(c, D.tag_tmp.reserve(room + 1));
   MDP_HIP(c, c->rmass.reserve((size_t) nnew + 1));
   if (ntot) {
-    const char *esh = getenv("MDP_AEAM_SHELL_LAST"); // (0: plain Hilbert order, for comparison)
-    const int shell_last = c->cfg.style == 2 && !(esh && atoi(esh) == 0);
+    const int shell_last = c->cfg.style == 2;
     dd_order_key_kernel<<<nblk(ntot), 256, 0, st>>>(G, ntot, c->xq.p, c->tag.p, D.dest.p, D.key_a.p, D.idx_a.p,
                                                     shell_last);
     MDP_HIP(c, hipGetLastError());

@@ -678,7 +678,8 @@ static int host_sort_atoms(mdp_ctx *c)
   const char *e = getenv("MDP_HOST_SORT");
   // rebomos always builds its own lists; aeam does when the host asked for device lists (mdp_aeam_device_lists)
   const bool own_lists = (c->have_rebomos && !c->have_aeam) || (c->have_aeam && c->aeam_device_lists);
-  c->host_sort = !c->md && own_lists && c->nlocal > 0 && !(e && atoi(e) == 0);
+  // (lists from the host's rows, mdp_rebomos_host_list: the rows speak of the host's atom indices, the order stays)
+  c->host_sort = !c->md && own_lists && c->nlocal > 0 && !(e && atoi(e) == 0) && !c->rebo_host_list;
   if (!c->host_sort) return MDP_OK;
   hipStream_t st = c->stream;
   MDP_HIP(c, c->sort_keys_a.reserve(nall + 1));
@@ -1273,6 +1274,17 @@ int mdp_set_skin(mdp_ctx *c, double skin)
   c->skin = skin;
   c->skin_set = true;
   c->rebo_packed = false;
+  return MDP_OK;
+}
+
+int mdp_rebomos_host_list(mdp_ctx *c, int on)
+{
+  if (!c) return MDP_EINVAL;
+  if (c->md) return mdp_fail(c, MDP_ESTATE, "mdp_rebomos_host_list: host mode only");
+  c->rebo_host_list = on != 0;
+  c->neigh_set = false;
+  c->rebo_packed = false;
+  c->atoms_set = false; // (the storage order depends on it: the next mdp_set_atoms_host decides)
   return MDP_OK;
 }
 

@@ -260,6 +260,7 @@ struct mdp_ctx {
   int map[16];
   DevBuf<double4> xq;   // x,y,z, w = element / type-1 as double
   DevBuf<double> xraw;  // staging for host x [nall][3]
+  bool rebo_host_list = false;  // host mode, rebomos: candidates and LJ rows from the host's neighbor list (mdp_rebomos_host_list)
   bool host_sort = false;       // host mode, rebomos: device storage order = Hilbert order (host_perm: device -> host index)
   DevBuf<int> host_perm;
   DevBuf<double> host_stage;    // per-atom results back in host order before the download

@@ -2544,6 +2544,216 @@ __global__ __launch_bounds__(256) void cand_compact_kernel(const int nall, const
   for (int k = s; k < n; k += RP_L) cand[b + k] = src[k];
 }
 
+// ---- lists from the HOST's neighbor list (MDP_REBOMOS_HOST_LIST=1, mdp_rebomos_host_list) -------------------------
+// The reference walks the rows LAMMPS built (REBO_neigh, pair_rebomos.cpp:328-330; FLJ, :490-495, both masked with
+// NEIGHMASK), so whatever the host left out of them -- `neigh_modify exclude`, special bonds with weight 0 -- is no
+// pair of the style.  These two kernels take their candidates from those rows (CSR copy on the device,
+// mdp_set_neighbors_host) instead of the bin grid and produce exactly what cand_build_kernel / tile_scan_kernel
+// produce; everything behind them is shared.  Rows of ghost atoms are used where the host has them (REQ_GHOST).
+template <int MODE> // 0: owned atoms (+ marks the ghosts that neighbour them), 1: the marked ghosts
+__global__ __launch_bounds__(256) void cand_csr_kernel(const RebomosDev P, const int nall, const int nlocal,
+                                                       const double4 *__restrict__ xq,
+                                                       const long long *__restrict__ nb_off,
+                                                       const int *__restrict__ nb, int *__restrict__ cnt,
+                                                       int *__restrict__ stage_all, int *__restrict__ is_centre,
+                                                       const int mark_from)
+{
+  const int lane = threadIdx.x & 63;
+  const int s = lane % RP_L;
+  const int glane0 = lane - s;
+  const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L + (MODE == 1 ? nlocal : 0);
+  bool have = i64 < (MODE == 0 ? nlocal : nall);
+  const int i = have ? (int) i64 : 0;
+  if (MODE == 1 && have && !is_centre[i]) have = false;
+  const double4 xi = xq[i];
+  const int ti = (int) xi.w;
+  if (ti < 0) have = false;
+  const long long b = have ? nb_off[i] : 0;
+  const int len = have ? (int) (nb_off[i + 1] - b) : 0;
+  const int lenw = wave_max_int(len);
+  int *stage = have ? stage_all + (size_t) i * kCandStride : nullptr;
+  const unsigned long long below = (1ull << s) - 1ull;
+  int n = 0;
+  for (int base = 0; base < lenw; base += RP_L) {
+    const int k = base + s;
+    bool keep = false;
+    int j = 0;
+    if (k < len) {
+      j = nb[b + k];
+      const double4 xj = xq[j];
+      const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+      const int tj = (int) xj.w;
+      keep = j != i && tj >= 0 && (dx * dx + dy * dy + dz * dz) <= P.cand_cutsq[ti * 2 + tj];
+    }
+    const unsigned long long bk = (__ballot(keep) >> glane0) & 0xFFFFull;
+    if (keep) {
+      const int pos = n + __popcll(bk & below);
+      if (pos < kCandStride) stage[pos] = j;
+      if (MODE == 0 && j >= mark_from) is_centre[j] = 1;
+    }
+    n += __popcll(bk);
+  }
+  if (have && s == 0) cnt[i] = n;
+}
+
+// tile_scan_kernel with the union gathered from the host rows of the tile's atoms: the same atom is listed by many of
+// them, so the members go through a hash table in LDS (key = atom index, value = the 16-bit cluster mask | element
+// class << 16) and are compacted element 0 first.  tile_sort_kernel orders every segment by atom index afterwards, so
+// the order of insertion leaves no trace.
+template <int CL>
+__global__ __launch_bounds__(256) void tile_scan_csr_kernel(const RebomosDev P, const int nclus, const int nlocal,
+                                                            const double4 *__restrict__ xq,
+                                                            const long long *__restrict__ nb_off,
+                                                            const int *__restrict__ nb, const int cap,
+                                                            int *__restrict__ tu, unsigned short *__restrict__ tmask,
+                                                            int *__restrict__ tile_nu, int *__restrict__ cnt,
+                                                            int *__restrict__ split, int *__restrict__ tile_flag)
+{
+  constexpr int NA = MDP_TILE * CL;
+  extern __shared__ int s_dyn[];
+  const int HS = 2 * cap; // (power of two: cap is)
+  int *s_key = s_dyn;                                       // [HS]
+  int *s_val = s_dyn + HS;                                  // [HS]
+  unsigned short *s_fm = (unsigned short *) (s_dyn + 2 * HS); // [cap] masks in final order
+  __shared__ double4 s_xa[NA];
+  __shared__ double s_cut[NA][2];
+  __shared__ int s_count, s_over, s_rowsum, s_w0[4], s_w1[4];
+  const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int h = tid; h < HS; h += 256) {
+    s_key[h] = -1;
+    s_val[h] = 0;
+  }
+  if (tid == 0) s_count = s_over = s_rowsum = 0;
+  if (tid < NA) {
+    const int ia = t * NA + tid;
+    bool valid = ia < nlocal;
+    const double4 xa = xq[valid ? ia : (nlocal > 0 ? nlocal - 1 : 0)];
+    int ta = (int) xa.w;
+    if (ta < 0) valid = false;
+    ta = ta > 1 ? 1 : ta;
+    s_xa[tid] = xa;
+    s_cut[tid][0] = valid ? P.ljlist_cutsq[ta * 2 + 0] : -1.0;
+    s_cut[tid][1] = valid ? P.ljlist_cutsq[ta * 2 + 1] : -1.0;
+  }
+  __syncthreads();
+  // every wave walks the rows of NA/4 atoms, 64 entries a trip
+  for (int a = wave; a < NA; a += 4) {
+    const int ia = t * NA + a;
+    if (ia >= nlocal || s_cut[a][0] < 0.0) continue; // (wave-uniform)
+    const double4 xa = s_xa[a];
+    const long long b = nb_off[ia];
+    const int len = (int) (nb_off[ia + 1] - b);
+    for (int k = lane; k < len; k += 64) {
+      const int j = nb[b + k];
+      const double4 xj = xq[j];
+      int tj = (int) xj.w;
+      tj = tj > 1 ? 1 : tj;
+      if (tj < 0 || j == ia) continue; // (the host lists no atom in its own row; guarded anyway)
+      const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
+      if (!(dx * dx + dy * dy + dz * dz <= s_cut[a][tj])) continue;
+      const int val = (1 << (a / CL)) | (tj << 16);
+      unsigned h = ((unsigned) j * 2654435761u) & (unsigned) (HS - 1);
+      for (int probe = 0; probe < HS; probe++) {
+        const int old = atomicCAS(&s_key[h], -1, j);
+        if (old == -1) {
+          if (atomicAdd(&s_count, 1) >= cap - 1) s_over = 1; // (slot nU is the kernels' dummy entry: nU <= cap - 1)
+        }
+        if (old == -1 || old == j) {
+          atomicOr(&s_val[h], val);
+          break;
+        }
+        h = (h + 1) & (unsigned) (HS - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (s_over) {
+    if (tid == 0) {
+      atomicOr(&tile_flag[0], 1);
+      tile_nu[2 * t] = tile_nu[2 * t + 1] = 0;
+    }
+    if (tid < MDP_TILE) cnt[t * MDP_TILE + tid] = split[t * MDP_TILE + tid] = 0;
+    return;
+  }
+  // compaction: thread tid owns the slots [tid * HS/256, (tid+1) * HS/256)
+  const int per = HS / 256;
+  int m0 = 0, m1 = 0;
+  for (int q = 0; q < per; q++) {
+    const int h = tid * per + q;
+    if (s_key[h] >= 0) {
+      if ((s_val[h] >> 16) & 1) m1++;
+      else m0++;
+    }
+  }
+  int i0 = m0, i1 = m1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u0 = __shfl_up(i0, o, 64), u1 = __shfl_up(i1, o, 64);
+    if (lane >= o) {
+      i0 += u0;
+      i1 += u1;
+    }
+  }
+  if (lane == 63) {
+    s_w0[wave] = i0;
+    s_w1[wave] = i1;
+  }
+  __syncthreads();
+  const int N0 = s_w0[0] + s_w0[1] + s_w0[2] + s_w0[3];
+  const int N1 = s_w1[0] + s_w1[1] + s_w1[2] + s_w1[3];
+  const int nU = N0 + N1;
+  int p0 = i0 - m0, p1 = N0 + i1 - m1;
+  for (int w = 0; w < wave; w++) {
+    p0 += s_w0[w];
+    p1 += s_w1[w];
+  }
+  int *mem = tu + (size_t) t * cap;
+  unsigned short *mm = tmask + (size_t) t * cap;
+  for (int q = 0; q < per; q++) {
+    const int h = tid * per + q;
+    const int j = s_key[h];
+    if (j < 0) continue;
+    const int v = s_val[h];
+    const int u = ((v >> 16) & 1) ? p1++ : p0++;
+    mem[u] = j;
+    mm[u] = (unsigned short) (v & 0xFFFF);
+    s_fm[u] = (unsigned short) (v & 0xFFFF);
+  }
+  __syncthreads();
+  // row lengths: as tile_scan_kernel
+  const int gq = tid / 16, sq = tid % 16;
+  int c0 = 0, c1 = 0;
+  for (int u = sq; u < nU; u += 16) {
+    const int bit = (s_fm[u] >> gq) & 1;
+    c0 += u < N0 ? bit : 0;
+    c1 += u < N0 ? 0 : bit;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    c0 += __shfl_xor(c0, o, 64);
+    c1 += __shfl_xor(c1, o, 64);
+  }
+  int q0 = (c0 + 15) & ~15, q1 = (c1 + 15) & ~15;
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    q0 = max(q0, __shfl_xor(q0, o, 64));
+    q1 = max(q1, __shfl_xor(q1, o, 64));
+  }
+  const int kc = t * MDP_TILE + gq;
+  if (sq == 0) {
+    cnt[kc] = q0 + q1;
+    split[kc] = q0;
+    atomicAdd(&s_rowsum, q0 + q1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    tile_nu[2 * t] = nU;
+    tile_nu[2 * t + 1] = N0;
+    atomicMax(&tile_flag[1], nU);
+    atomicMax(&tile_flag[2], s_rowsum);
+  }
+}
+
 // positions at list-build time (all atoms, ghosts included) and the displacement trigger
 __global__ void hold_all_kernel(const int nall, const double4 *__restrict__ xq, mdp_hold_t *__restrict__ xhold)
 {
@@ -2882,14 +3092,18 @@ int mdp_rebomos_repack(mdp_ctx *c)
   hipStream_t st = c->stream;
   MDP_HIP(c, c->cand_cnt.reserve(nall + 1));
   MDP_HIP(c, c->cand_off.reserve(nall + 2));
-  int cl = MDP_CLUSTER;
-  if (const char *e = getenv("MDP_CLUSTER")) cl = atoi(e);
-  if (cl != 1 && cl != 2 && cl != 4) cl = MDP_CLUSTER;
+  // candidates and rows from the host's neighbor list instead of the bin grid (mdp_rebomos_host_list): see
+  // cand_csr_kernel.  One atom per row then: the two atoms of a cluster share a row, and a pair the host excluded for
+  // one of them must not come in through the other.
+  const bool from_host = c->rebo_host_list;
+  if (from_host && (!c->neigh_set || !c->nb_off.p || c->md))
+    return mdp_fail(c, MDP_ESTATE, "rebomos: lists from the host's neighbor list were asked for (mdp_rebomos_host_list) but no list was handed over (mdp_set_neighbors_host)");
+  const int cl = from_host ? 1 : MDP_CLUSTER;
   // Lennard-Jones list layout: tiles of 16 two-atom rows; MDP_LJ_TILE=0: per-cluster lists of global indices (the
   // fallback when a union outgrows LDS).  (Tiles of 32 one-atom rows evaluate 25 % fewer pairs and measured slower,
   // 1.35 against 1.28 ms at 3.98 M atoms -- every LDS read and row index then serves one atom: DESIGN.md section 4.)
-  bool want16 = cl == 2;
-  if (const char *e = getenv("MDP_LJ_TILE")) want16 = want16 && atoi(e) != 0;
+  bool want16 = cl == 2 || from_host;
+  if (const char *e = getenv("MDP_LJ_TILE")) want16 = want16 && (atoi(e) != 0 || from_host);
   c->cluster = cl;
   const int nclus = (nlocal + cl - 1) / cl;
   c->nclus = nclus;
@@ -2927,32 +3141,39 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_TRY(mdp_bin_atoms(c, ljcut, c->bbox_lo, c->bbox_hi));
   const int Rc = candcut <= 0.5 * ljcut ? 1 : 2; // cells are >= ljcut/2 wide
   // Resident runs know which ghosts are periodic images of owned atoms (owner, shift): those are no centres of their
-  // own, the gather of their owned neighbours reads the owner centre's slots instead (rev_kernel).  MDP_IMAGE_CENTRES=1
-  // computes them as before (A/B switch).
-  static const bool image_centres = getenv("MDP_IMAGE_CENTRES") && atoi(getenv("MDP_IMAGE_CENTRES")) != 0;
+  // own, the gather of their owned neighbours reads the owner centre's slots instead (rev_kernel).
   // Host mode knows the same once the library keeps the images itself (mdp_set_box_host): every ghost is one.
   const bool host_images = !c->md && c->host_ghosts_derived && c->ghost_owner.p && c->host_tag_dev.p;
-  const int self_end = image_centres ? nlocal
-                       : host_images ? nall
+  const int self_end = host_images ? nall
                        : (c->md && c->ghost_owner.p && c->tag.p && c->remote_start > nlocal)
                            ? (c->remote_start < nall ? c->remote_start : nall) : nlocal;
   const int *tag_dev = host_images ? c->host_tag_dev.p : c->tag.p; // tags in the device's atom order
   const int per_block = 256 / RP_L;
   const int nghost = nall - nlocal;
-  static const bool two_pass = getenv("MDP_CAND_TWO_PASS") && atoi(getenv("MDP_CAND_TWO_PASS")) != 0; // (A/B, tests)
+  static const bool two_pass_env = getenv("MDP_CAND_TWO_PASS") && atoi(getenv("MDP_CAND_TWO_PASS")) != 0; // (A/B, tests)
+  const bool two_pass = two_pass_env && !from_host;
   int *stage = nullptr;
   if (!two_pass) {
     MDP_HIP(c, c->cand_stage.reserve((size_t) nall * kCandStride + kCandStride));
     stage = c->cand_stage.p;
   }
-  if (nlocal)
-    cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
-        c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        stage, c->is_center.p, self_end);
-  if (nghost)
-    cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
-        c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-        stage, c->is_center.p, self_end);
+  if (from_host) {
+    if (nlocal)
+      cand_csr_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
+          c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_cnt.p, stage, c->is_center.p, self_end);
+    if (nghost)
+      cand_csr_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
+          c->rebomos, nall, nlocal, c->xq.p, c->nb_off.p, c->nb.p, c->cand_cnt.p, stage, c->is_center.p, self_end);
+  } else {
+    if (nlocal)
+      cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
+          c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
+          stage, c->is_center.p, self_end);
+    if (nghost)
+      cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
+          c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
+          stage, c->is_center.p, self_end);
+  }
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
   // Lennard-Jones lists: tile lists for the default cluster size, unless switched off or a union outgrows LDS
@@ -2978,7 +3199,21 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                                    c->cell_start.p, cap, c->tu.p, c->tmask.p, c->tile_nu.p,           \
                                                    c->lj_cnt.p, c->lj_split.p, c->tile_flag.p);                       \
   } while (0)
-      if (cl == 1) MDP_TS(1);
+      if (from_host) {
+        const size_t ldsh = (size_t) 18 * cap; // hash table of 2 cap (key, value) slots + cap masks
+#define MDP_TSH(CLV)                                                                                                  \
+  do {                                                                                                                \
+    if (ldsh > 48 * 1024)                                                                                             \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_csr_kernel<CLV>,                                        \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsh));                        \
+    tile_scan_csr_kernel<CLV><<<ntile, 256, ldsh, st>>>(c->rebomos, nclus, nlocal, c->xq.p, c->nb_off.p, c->nb.p, cap,   \
+                                                        c->tu.p, c->tmask.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p, \
+                                                        c->tile_flag.p);                                              \
+  } while (0)
+        if (cl == 1) MDP_TSH(1);
+        else MDP_TSH(2);
+#undef MDP_TSH
+      } else if (cl == 1) MDP_TS(1);
       else MDP_TS(2);
 #undef MDP_TS
       MDP_HIP(c, hipGetLastError());
@@ -3012,6 +3247,8 @@ int mdp_rebomos_repack(mdp_ctx *c)
     for (int k = 0; k < ntile; k++) hist[h[2 * k] / 200 < 8 ? h[2 * k] / 200 : 8]++;
     for (int k = 0; k < 9; k++) fprintf(stderr, "[mdp]   union %4d.. : %d tiles\n", 200 * k, hist[k]);
   }
+  if (nclus && !tiled && from_host)
+    return mdp_fail(c, MDP_ENOTIMPL, "rebomos: lists from the host's neighbor list need the tile lists (two-atom clusters, unions within LDS)");
   if (nclus && !tiled) {
     const int gb = (nclus + 15) / 16;
 #define MDP_CB(CLV, FILLV, OFFP, OUTP)                                                                              \

@@ -65,7 +65,7 @@ EXPORTS = [
     "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_integrate_check", "mdp_md_download_int", "mdp_md_download_x_all",
     "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
-    "mdp_dd_comm_allreduce", "mdp_dd_comm_step_begin", "mdp_dd_comm_step_end", "mdp_dd_comm_step_info", "mdp_aeam_device_lists", "mdp_aeam_check_host_list",
+    "mdp_dd_comm_allreduce", "mdp_dd_comm_step_begin", "mdp_dd_comm_step_end", "mdp_dd_comm_step_info", "mdp_aeam_device_lists", "mdp_rebomos_host_list", "mdp_aeam_check_host_list",
     "mdp_md_defer_final", "mdp_md_list_state", "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
 ]
 
@@ -263,6 +263,9 @@ class Context:
 
     def set_skin(self, skin):
         self._ck(self.L.mdp_set_skin(self.h, C.c_double(skin)))
+
+    def rebomos_host_list(self, on=True):
+        self._ck(self.L.mdp_rebomos_host_list(self.h, C.c_int(1 if on else 0)))
 
     def aeam_device_lists(self, on=True):
         self._ck(self.L.mdp_aeam_device_lists(self.h, C.c_int(1 if on else 0)))

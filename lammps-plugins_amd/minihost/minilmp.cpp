@@ -208,6 +208,7 @@ struct Host {
 
   // neighbor storage
   std::vector<int> nb_store, ilist_v, numneigh_v;
+  std::vector<std::pair<int, int>> excl_types; // neigh_modify exclude type M N
   std::vector<int *> firstneigh_v;
   double skin = 2.0;
   int nbuilds = 0;
@@ -450,6 +451,10 @@ struct Host {
       std::vector<int> fill(head.begin(), head.end() - 1);
       for (int i = 0; i < nall; i++) order[fill[bin_of[i]]++] = i;
     }
+    std::vector<char> excl((size_t) (nt + 1) * (nt + 1), 0);
+    for (const auto &e : excl_types)
+      if (e.first >= 1 && e.first <= nt && e.second >= 1 && e.second <= nt)
+        excl[(size_t) e.first * (nt + 1) + e.second] = excl[(size_t) e.second * (nt + 1) + e.first] = 1;
     nb_store.clear();
     numneigh_v.assign(nall, 0);
     std::vector<size_t> start(nall, 0);
@@ -472,7 +477,7 @@ struct Host {
           const size_t b1 = std::min(c[0] + 2, nb[0] - 1) + (size_t) nb[0] * (y + (size_t) nb[1] * z);
           for (int p = head[b0]; p < head[b1 + 1]; p++) {
             const int j = order[p];
-            if (j == i) continue;
+            if (j == i || excl[(size_t) ti * (nt + 1) + types[j]]) continue;
             const double *xj = xs.data() + 3 * (size_t) j;
             const double dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
             if (dx * dx + dy * dy + dz * dz <= ctab[(size_t) ti * (nt + 1) + types[j]]) nb_store.push_back(j);
@@ -1133,6 +1138,13 @@ struct Script {
       H.neighbor.skin = std::stod(w[1]);
     } else if (c == "neigh_modify") {
       for (size_t k = 1; k + 1 < w.size(); k += 2) {
+        if (w[k] == "exclude") { // neigh_modify exclude type M N: no list entries between atoms of types M and N
+          if (k + 3 >= w.size() || w[k + 1] != "type") H.error.all(FLERR, "minilmp supports `neigh_modify exclude type M N` only");
+          const int a = std::stoi(w[k + 2]), b = std::stoi(w[k + 3]);
+          H.excl_types.push_back({a, b});
+          k += 2;
+          continue;
+        }
         if (w[k] == "one") H.neighbor.oneatom = std::stoi(w[k + 1]);
         if (w[k] == "page") H.neighbor.pgsize = std::stoi(w[k + 1]);
         if (w[k] == "every") H.neighbor.every = std::max(1, std::stoi(w[k + 1]));

@@ -159,6 +159,11 @@ void PairREBOMoS::init_style()
 
   open_device();
   nall_uploaded = -1;
+  // MDP_REBOMOS_HOST_LIST=1: the lists are subsets of the rows LAMMPS built (exclusions and special bonds act as in the
+  // reference) instead of being built from the positions -- see mdp_rebomos_host_list
+  const char *ehl = getenv("MDP_REBOMOS_HOST_LIST");
+  host_list = ehl && atoi(ehl) != 0;
+  if (mdp_rebomos_host_list(dev, host_list ? 1 : 0) != MDP_OK) fail_one(MDP_EINVAL, "list mode");
 }
 
 double PairREBOMoS::init_one(int i, int j)
@@ -178,10 +183,13 @@ void PairREBOMoS::compute(int eflag, int vflag)
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   const bool linked = nve_linked && comm->nprocs == 1;
+  if (linked && host_list)
+    error->all(FLERR, "Pair style rebomos (MI355X): fix nve/mdp keeps the atoms on the device and cannot be combined with MDP_REBOMOS_HOST_LIST=1");
   int rc;
   // the box of this step: on one periodic rank the library gives the images their positions itself, as
   // Comm::forward_comm does (owner + whole box vectors), and takes the owned atoms' positions only
-  rc = mdp_set_box_host(dev, comm->nprocs == 1 ? domain->h : nullptr);
+  // (lists from the host's rows: the rows index the host's own ghosts, which then come up with the positions)
+  rc = mdp_set_box_host(dev, comm->nprocs == 1 && !host_list ? domain->h : nullptr);
   if (rc != MDP_OK) fail_one(rc, "box");
   if (neighbor->ago == 0 || nall != nall_uploaded) {
     // the host rebuilt its list this step: atoms may have migrated / been re-sorted
@@ -191,13 +199,18 @@ void PairREBOMoS::compute(int eflag, int vflag)
     // the device builds its own trimmed lists from the positions; the host's list (requested in
     // init_style for API parity and for the ghost shell it implies) only contributes its skin
     if (list->inum != nlocal) error->one(FLERR, "Pair style rebomos (MI355X): neighbor list does not match nlocal");
-    rc = mdp_set_skin(dev, neighbor->skin);
-    if (rc != MDP_OK) fail_one(rc, "skin upload");
-    // ... which is only the reference's result when the host's list is the plain geometric one: the reference
-    // walks the host's entries (pair_rebomos.cpp:328-330, 490-495), so exclusions or special bonds must stop the run
-    rc = mdp_rebomos_check_host_list(dev, list->inum, list->ilist, list->numneigh, list->firstneigh,
-                                     cut3rebo + neighbor->skin);
-    if (rc != MDP_OK) fail_one(rc, "neighbor list check");
+    if (host_list) {
+      rc = mdp_set_neighbors_host(dev, list->inum, list->gnum, list->ilist, list->numneigh, list->firstneigh, neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "neighbor list upload");
+    } else {
+      rc = mdp_set_skin(dev, neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "skin upload");
+      // ... which is only the reference's result when the host's list is the plain geometric one: the reference
+      // walks the host's entries (pair_rebomos.cpp:328-330, 490-495), so exclusions or special bonds must stop the run
+      rc = mdp_rebomos_check_host_list(dev, list->inum, list->ilist, list->numneigh, list->firstneigh,
+                                       cut3rebo + neighbor->skin);
+      if (rc != MDP_OK) fail_one(rc, "neighbor list check");
+    }
     nall_uploaded = nall;
     // fix nve/mdp integrates on the device: the velocities go with the atoms (the host's are current on this step)
     if (linked) {

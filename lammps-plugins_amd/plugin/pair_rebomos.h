@@ -35,6 +35,7 @@ class PairREBOMoS : public Pair {
 
  protected:
   mdp_ctx *dev;                 // device context (one GPU per rank)
+  bool host_list = false;       // MDP_REBOMOS_HOST_LIST=1: lists from the rows LAMMPS built (mdp_rebomos_host_list)
   int nve_linked;               // set by fix nve/mdp: x, v and f of the owned atoms stay on the device between reneighborings
   mdp_rebomos_params params;    // the 61 file scalars after mixing
   bool params_read;
