@@ -1419,6 +1419,15 @@ __global__ void pair_der_kernel(const int npair, const int nm1, const int *__res
 
 // owned angular centres; count[0] = their number, count[2] = 1 when one of them sits in a tile at or behind
 // count[1] = the first tile whose union reaches a remote ghost (its row may then hold one: ghost forces must travel)
+// the list is there already (mdp_md_build_master_list selected the same atoms for their CSR rows): only count[2]
+__global__ void ang_reach_kernel(const int n, const int *__restrict__ list, int *__restrict__ count,
+                                 const int atoms_per_tile)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool reach = k < n && list[k] / atoms_per_tile >= count[1];
+  if (__any(reach) && (threadIdx.x & 63) == 0) count[2] = 1;
+}
+
 __global__ void ang_list_kernel(const int nnonangular, int nlocal, const double4 *__restrict__ xq, int *__restrict__ list,
                                 int *__restrict__ count, const int atoms_per_tile)
 {
@@ -1520,12 +1529,17 @@ int mdp_aeam_prepare(mdp_ctx *c)
     // angular centres; with remote ghosts (multi-GPU): the first tile that reaches one -- the tiles before it run
     // while the halo is in flight (domain.hip stores the shell atoms of the brick behind the interior ones)
     const bool remote = c->md && c->remote_start < c->nall;
-    const int init[5] = {0, remote && c->aeam_tiled ? c->ntile : 0, 0, 0, 0};
+    const bool have_list = c->ang_list_n >= 0; // (selected for the CSR rows of this very build: the same atoms)
+    const int init[5] = {have_list ? c->ang_list_n : 0, remote && c->aeam_tiled ? c->ntile : 0, 0, 0, 0};
+    c->ang_list_n = -1;
     MDP_TRY(mdp_write_small(c, c->ang_count.p, init, sizeof init));
     if (remote && c->aeam_tiled)
       tile_first_remote_kernel<<<nblk(c->ntile, 4), 256, 0, st>>>(c->ntile, c->tile_cap, c->remote_start, c->tile_nu.p,
                                                                   c->tu.p, c->lj_off.p, c->ang_count.p);
-    if (c->nlocal)
+    if (have_list) {
+      if (init[0] && remote && c->aeam_tiled)
+        ang_reach_kernel<<<nblk(init[0], 256), 256, 0, st>>>(init[0], c->ang_list.p, c->ang_count.p, kTile * c->aeam_cl);
+    } else if (c->nlocal)
       ang_list_kernel<<<nblk(c->nlocal, 256), 256, 0, st>>>(c->aeam.nnonangular, c->nlocal, c->xq.p, c->ang_list.p, c->ang_count.p,
                                                             remote && c->aeam_tiled ? kTile * c->aeam_cl : 0);
     MDP_HIP(c, hipGetLastError());

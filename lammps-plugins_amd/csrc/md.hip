@@ -46,11 +46,16 @@ __global__ void cell_assign_kernel(const Grid g, int nall, const double4 *__rest
   val[i] = i;
 }
 
-__global__ void cell_bounds_kernel(int nall, const unsigned *__restrict__ key_sorted, int *__restrict__ cell_start)
+__global__ void cell_bounds_kernel(int nall, const unsigned *__restrict__ key_sorted, int *__restrict__ cell_start,
+                                   const int *__restrict__ perm, const double4 *__restrict__ xq,
+                                   double4 *__restrict__ xq_cell)
 {
   // cell_start[c] .. cell_start[c+1] delimit cell c in the sorted order; filled for every cell
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= nall) return;
+  // positions in cell order: the list builders sweep runs of cells, i.e. runs of p -- one coalesced load of
+  // xq_cell[p] instead of the dependent pair perm[p] -> xq[perm[p]] (tile_scan_kernel)
+  xq_cell[p] = xq[perm[p]];
   const unsigned k = key_sorted[p];
   const unsigned kprev = p == 0 ? 0u : key_sorted[p - 1];
   if (p == 0)
@@ -191,18 +196,25 @@ __global__ __launch_bounds__(256) void nbuild_list_kernel(const Grid g, const Cu
   if (!FILL && lane == 0) cnt[i] = n;
 }
 
-__global__ void ang_select_kernel(const int nlocal, const int min_type, const double4 *__restrict__ xq,
-                                  int *__restrict__ list, int *__restrict__ count)
+// a workgroup looks at kAngChunk atoms and sends ONE atomic for them: at 0.76 % Si one per wave still meant ~7 000
+// atomics on one word, 70 us of a reneighboring (they are served one after the other)
+constexpr int kAngChunk = 4096;
+__global__ __launch_bounds__(256) void ang_select_kernel(const int nlocal, const int min_type,
+                                                         const double4 *__restrict__ xq, int *__restrict__ list,
+                                                         int *__restrict__ count)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  const bool sel = i < nlocal && (int) xq[i < nlocal ? i : 0].w >= min_type;
-  const unsigned long long b = __ballot(sel); // one atomic per wave (thousands on one counter cost 70 us)
-  if (!b) return;
-  const int leader = __ffsll((long long) b) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(count, __popcll(b));
-  base = __shfl(base, leader, 64);
-  if (sel) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+  __shared__ int s_n, s_base, s_idx[kAngChunk];
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int i0 = blockIdx.x * kAngChunk;
+  for (int k = threadIdx.x; k < kAngChunk; k += 256) {
+    const int i = i0 + k;
+    if (i < nlocal && (int) xq[i].w >= min_type) s_idx[atomicAdd(&s_n, 1)] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
+  __syncthreads();
+  for (int k = threadIdx.x; k < s_n; k += 256) list[s_base + k] = s_idx[k];
 }
 
 // fix nve on the device.  FINAL: the final_integrate of the step just finished and the initial_integrate of the next
@@ -599,7 +611,9 @@ int mdp_bin_atoms(mdp_ctx *c, double cutoff, const double lo[3], const double hi
   MDP_HIP(c, c->scan_tmp.reserve(tmp + 16));
   MDP_HIP(c, rocprim::radix_sort_pairs(c->scan_tmp.p, tmp, c->sort_keys_a.p, c->sort_keys_b.p, c->cell_of.p,
                                        c->cell_perm.p, (size_t) nall, 0, bits, st));
-  cell_bounds_kernel<<<nblk(nall), 256, 0, st>>>(nall, c->sort_keys_b.p, c->cell_start.p);
+  MDP_HIP(c, c->xq_cell.reserve((size_t) nall + 1));
+  cell_bounds_kernel<<<nblk(nall), 256, 0, st>>>(nall, c->sort_keys_b.p, c->cell_start.p, c->cell_perm.p, c->xq.p,
+                                                 c->xq_cell.p);
   cell_tail_kernel<<<1, 256, 0, st>>>(nall, (int) ncell, c->sort_keys_b.p, c->cell_start.p);
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
@@ -624,14 +638,20 @@ int mdp_md_build_master_list(mdp_ctx *c)
     MDP_HIP(c, c->ang_count.reserve(4));
     MDP_HIP(c, hipMemsetAsync(c->ang_count.p, 0, sizeof(int), st));
     MDP_HIP(c, hipMemsetAsync(c->nb_cnt.p, 0, sizeof(int) * (nall + 1), st));
-    if (nlocal) ang_select_kernel<<<nblk(nlocal), 256, 0, st>>>(nlocal, ct.min_type, c->xq.p, c->ang_list.p, c->ang_count.p);
+    if (nlocal)
+      ang_select_kernel<<<(nlocal + kAngChunk - 1) / kAngChunk, 256, 0, st>>>(nlocal, ct.min_type, c->xq.p, c->ang_list.p,
+                                                                             c->ang_count.p);
     MDP_TRY(mdp_read_one(c, c->ang_count.p, sizeof(int), &nsel));
+    // (aeam: these ARE the owned angular centres, min_type = nnonangular -- mdp_aeam_prepare takes the list as it is)
+    c->ang_list_n = c->cfg.style == 2 && ct.min_type == c->aeam.nnonangular ? nsel : -1;
     if (nsel)
       nbuild_list_kernel<false><<<(nsel + 3) / 4, 256, 0, st>>>(g, ct, nsel, c->ang_list.p, c->xq.p, c->cell_perm.p,
                                                                 c->cell_start.p, c->nb_cnt.p, nullptr, nullptr);
-  } else
+  } else {
+    c->ang_list_n = -1;
     nbuild_kernel<false><<<nblk(nall), 256, 0, st>>>(g, ct, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
                                                       c->nb_cnt.p, nullptr, nullptr);
+  }
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_i64(c, c->nb_cnt.p, c->nb_off.p, nall));
   long long tot[2] = {0, 0};

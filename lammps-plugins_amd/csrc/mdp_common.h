@@ -259,6 +259,7 @@ struct mdp_ctx {
   bool atoms_set = false;
   int map[16];
   DevBuf<double4> xq;   // x,y,z, w = element / type-1 as double
+  DevBuf<double4> xq_cell; // the same in cell order (xq[cell_perm[p]]), as of the last mdp_bin_atoms
   DevBuf<double> xraw;  // staging for host x [nall][3]
   bool rebo_host_list = false;  // host mode, rebomos: candidates and LJ rows from the host's neighbor list (mdp_rebomos_host_list)
   bool host_sort = false;       // host mode, rebomos: device storage order = Hilbert order (host_perm: device -> host index)
@@ -346,6 +347,7 @@ struct mdp_ctx {
   DevBuf<double> hn_mass_dev;
   bool hn_v_current = false;      // c->v / c->rmass match the atoms of the last mdp_set_atoms_host
   int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
+  int ang_list_n = -1;            // >= 0: ang_list holds exactly the owned angular centres of the current atoms (mdp_md_build_master_list)
   bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
   bool f_zero_remote_due = false; // ... except the remote ghosts' part, which this step's halo unpack clears (bricks, step mode)
   bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too

@@ -1999,7 +1999,8 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
                                                         const int *__restrict__ cell_start, const int cap,
                                                         int *__restrict__ tu, unsigned short *__restrict__ tmask,
                                                         int *__restrict__ tile_nu, int *__restrict__ cnt,
-                                                        int *__restrict__ split, int *__restrict__ tile_flag)
+                                                        int *__restrict__ split, int *__restrict__ tile_flag,
+                                                        const double4 *__restrict__ xq_cell)
 {
   constexpr int NA = MDP_TILE * CL;
   extern __shared__ int s_dyn[];
@@ -2083,20 +2084,39 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
     s_off[tid] = wbase + incl - len;
     if (tid == 0) s_off[kRows] = total;
     __syncthreads();
+    // the candidate of the NEXT trip is located and its two loads (position in cell order, atom index) are in flight
+    // while the current one is tested against the tile's atoms: a trip was two dependent round trips to memory in
+    // front of 32 distance tests, at five waves per SIMD
+    const auto locate = [&](const int gi) {
+      int lo = 0, hi = kRows; // s_off[lo] <= gi < s_off[hi]  (rows past nr are empty: offset = total)
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= gi) lo = mid;
+        else hi = mid;
+      }
+      return s_pb[lo] + gi - s_off[lo];
+    };
+    double4 xn = make_double4(0.0, 0.0, 0.0, -1.0);
+    int jn = 0;
+    if (wave * 64 + lane < total) {
+      const int p = locate(wave * 64 + lane);
+      xn = xq_cell[p];
+      jn = perm[p];
+    }
     for (int g0 = wave * 64; g0 < total && !over; g0 += 256) {
       const int gi = g0 + lane;
       unsigned m = 0;
       int j = 0, tj = 0;
+      const double4 xj = xn;
+      const int jcur = jn;
+      if (gi + 256 < total) {
+        const int p = locate(gi + 256);
+        xn = xq_cell[p];
+        jn = perm[p];
+      }
       if (gi < total) {
-        int lo = 0, hi = kRows; // s_off[lo] <= gi < s_off[hi]  (rows past nr are empty: offset = total)
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-          const int mid = (lo + hi) >> 1;
-          if (s_off[mid] <= gi) lo = mid;
-          else hi = mid;
-        }
-        j = perm[s_pb[lo] + gi - s_off[lo]];
-        const double4 xj = xq[j];
+        j = jcur;
         tj = (int) xj.w;
         tj = tj > 1 ? 1 : tj;
         if (tj >= 0) {
@@ -2461,7 +2481,8 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
                                                          const int *__restrict__ cell_start, int *__restrict__ cnt,
                                                          const int *__restrict__ off, int *__restrict__ cand,
                                                          int *__restrict__ is_centre,
-                                                         const int mark_from /* ghosts below it are periodic images of owned atoms: no centres (rev_kernel) */)
+                                                         const int mark_from /* ghosts below it are periodic images of owned atoms: no centres (rev_kernel) */,
+                                                         const double4 *__restrict__ xq_cell /* xq[perm[p]]: coalesced, and no load depends on another */)
 {
   const int lane = threadIdx.x & 63;
   const int s = lane % RP_L;
@@ -2513,7 +2534,7 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
         int j = 0;
         if (p < pe) {
           j = perm[p];
-          const double4 xj = xq[j];
+          const double4 xj = xq_cell[p];
           const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
           const int tj = (int) xj.w;
           keep = j != i && tj >= 0 && (dx * dx + dy * dy + dz * dz) <= P.cand_cutsq[ti * 2 + tj];
@@ -2538,10 +2559,11 @@ __global__ __launch_bounds__(256) void cand_compact_kernel(const int nall, const
   const long long i64 = (long long) blockIdx.x * (256 / RP_L) + threadIdx.x / RP_L;
   if (i64 >= nall) return;
   const int i = (int) i64, b = off[i];
-  int n = off[i + 1] - b;
-  n = n < kCandStride ? n : kCandStride;
+  const int n = off[i + 1] - b;
   const int *__restrict__ src = stage + (size_t) i * kCandStride;
-  for (int k = s; k < n; k += RP_L) cand[b + k] = src[k];
+  // (a row longer than the stride: the build is refused by rev_kernel, but the kernels queued behind this one walk the
+  //  row first -- its tail repeats a valid index instead of holding whatever the buffer held)
+  for (int k = s; k < n; k += RP_L) cand[b + k] = src[k < kCandStride ? k : kCandStride - 1];
 }
 
 // ---- lists from the HOST's neighbor list (MDP_REBOMOS_HOST_LIST=1, mdp_rebomos_host_list) -------------------------
@@ -3168,11 +3190,11 @@ int mdp_rebomos_repack(mdp_ctx *c)
     if (nlocal)
       cand_build_kernel<0><<<(nlocal + per_block - 1) / per_block, 256, 0, st>>>(
           c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-          stage, c->is_center.p, self_end);
+          stage, c->is_center.p, self_end, c->xq_cell.p);
     if (nghost)
       cand_build_kernel<1><<<(nghost + per_block - 1) / per_block, 256, 0, st>>>(
           c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, c->cand_cnt.p, nullptr,
-          stage, c->is_center.p, self_end);
+          stage, c->is_center.p, self_end, c->xq_cell.p);
   }
   MDP_HIP(c, hipGetLastError());
   MDP_TRY(mdp_scan_exclusive_int(c, c->cand_cnt.p, c->cand_off.p, nall));
@@ -3197,7 +3219,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
                                      (int) lds));                                                                     \
     tile_scan_kernel<CLV><<<ntile, 256, lds, st>>>(c->grid, c->rebomos, nclus, nlocal, c->xq.p, c->cell_perm.p,         \
                                                    c->cell_start.p, cap, c->tu.p, c->tmask.p, c->tile_nu.p,           \
-                                                   c->lj_cnt.p, c->lj_split.p, c->tile_flag.p);                       \
+                                                   c->lj_cnt.p, c->lj_split.p, c->tile_flag.p, c->xq_cell.p);         \
   } while (0)
       if (from_host) {
         const size_t ldsh = (size_t) 18 * cap; // hash table of 2 cap (key, value) slots + cap masks
@@ -3286,7 +3308,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   else if (nall)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
-        c->cand.p, c->is_center.p, self_end);
+        c->cand.p, c->is_center.p, self_end, c->xq_cell.p);
   if (tiled) MDP_TRY(tile_sort_launch(c, ntile));
   if (tiled)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
@@ -3427,14 +3449,14 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
                                        (int) lds));
       tile_scan_kernel<1><<<ntile, 256, lds, st>>>(c->grid, P, nclus, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
                                                    cap, c->tu.p, c->tmask.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p,
-                                                   c->tile_flag.p);
+                                                   c->tile_flag.p, c->xq_cell.p);
     } else {
       if (lds > 48 * 1024)
         MDP_HIP(c, hipFuncSetAttribute((const void *) tile_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) lds));
       tile_scan_kernel<2><<<ntile, 256, lds, st>>>(c->grid, P, nclus, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p,
                                                    cap, c->tu.p, c->tmask.p, c->tile_nu.p, c->lj_cnt.p, c->lj_split.p,
-                                                   c->tile_flag.p);
+                                                   c->tile_flag.p, c->xq_cell.p);
     }
     MDP_HIP(c, hipGetLastError());
     int tf[3] = {0, 0, 0};
