@@ -332,7 +332,7 @@ def run_job(E, job, par):
         pot = af.build()
         ctx.aeam_set_tables(pot)
         ctx._af = af
-        style, skin, map_ = capi.STYLE_AEAM, 1.0, None
+        style, skin, map_ = capi.STYLE_AEAM, 1.0, None     # sample.in:17
         cutghost = float(af.cut_table(pot).max()) + skin
         s.mass[1:3] = af.mass[:2]
     if dist is None:
@@ -455,7 +455,8 @@ def run_job(E, job, par):
     step_achieved = B_ALG[wl] * s.n / world / (ms_per_step * 1e-3) / 1e9
     flops_path = FLOP_ALG[wl] * dom.nlocal / (kall * 1e-3) / 1e12 if kall > 0 else 0.0
     flops_step = FLOP_ALG[wl] * s.n / world / (ms_per_step * 1e-3) / 1e12
-    ent, traffic_note = pmc_entry(wl, rep, world)
+    # (counter traffic is stored per lattice configuration: an off-lattice variant of the same size has no entry of its own)
+    ent, traffic_note = pmc_entry(wl + ("_" + "_".join(sorted(dis)) if dis else ""), rep, world)
     traffic = ent.get("bytes_per_step") if ent else None
     dname = max(single, key=lambda k: single[k])
     dms = float(single[dname])
