@@ -784,7 +784,9 @@ void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc)
   MdpStyleCheckMeta &m = c->sflag_meta[set];
   m = MdpStyleCheckMeta();
   const double scale = mdp_margin_scale(c);
-  if (c->cfg.style == 1 && c->rebo_packed && !c->check_now && c->xhold_all.p && c->skin_inner > 0.0) {
+  // (rebomos: resident runs, and host mode with the integrator on the device -- mdp_hnve_initial)
+  const bool rebo = c->cfg.style == 1 || (!c->md && c->have_rebomos && !c->have_aeam);
+  if (rebo && c->rebo_packed && !c->check_now && c->xhold_all.p && c->skin_inner > 0.0) {
     double trig = 0.5 * c->skin_inner - kStaleMargin * scale;
     if (trig < 0.25 * c->skin_inner) trig = 0.25 * c->skin_inner;
     const double hard = 0.5 * c->skin_inner;
@@ -805,7 +807,7 @@ void mdp_sflag_arm(mdp_ctx *c, MdpStyleCheck &sc)
     m.prune_epoch = c->prune_epoch;
   }
   sc.flag = (m.has_style || m.has_prune) ? h : nullptr;
-  if (c->neigh_set && c->acc.p && c->flags.p) { // the compute that follows finds its accumulators reset
+  if (c->md && c->neigh_set && c->acc.p && c->flags.p) { // the compute that follows finds its accumulators reset
     sc.acc = c->acc.p;
     sc.nacc = MDP_ACC_STRIDE * (1 + MDP_ACC_SLOTS);
     sc.flags = c->flags.p;
@@ -1119,17 +1121,29 @@ int mdp_hnve_initial(mdp_ctx *c, int *moved, int *dangerous)
     const double hard = 0.5 * c->skin;
     double trig = hard - 0.1 * mdp_margin_scale(c);
     if (trig < 0.5 * hard) trig = 0.5 * hard;
-    MdpStyleCheck sc; // (host mode: the style checks its own lists in its compute, mdp_rebomos_host_precheck)
+    // rebomos: the style's own displacement checks (device-built lists, pruned rows) ride in this kernel and are read
+    // by the NEXT compute, as in resident runs (MdpStyleCheck; every ghost is an image that moves with its owner) --
+    // a check of its own in front of every compute had the host wait for the stream once per step
+    MdpStyleCheck sc;
+    c->hn_deferred_check = !c->md && c->have_rebomos && !c->have_aeam && c->host_ghosts_derived;
+    if (c->hn_deferred_check) mdp_sflag_arm(c, sc);
     nve_advance_kernel<false, true><<<nblk(n), 256, 0, c->stream>>>(n, c->hn_dtf, c->hn_dt, c->rmass.p, c->f.p, c->v.p, c->xq.p,
                                                                     c->xhold.p, trig * trig, hard * hard, h, sc, 0);
     MDP_HIP(c, hipGetLastError());
-    MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
-    D.ev_moved_ref = D.ev_moved;
+    if (c->hn_deferred_check && c->sflag_armed) { // one event behind the kernel serves both readers of its words
+      MDP_TRY(mdp_sflag_commit(c));
+      D.ev_moved_ref = c->ev_sflag[c->sflag_set];
+    } else {
+      MDP_HIP(c, hipEventRecord(D.ev_moved, c->stream));
+      D.ev_moved_ref = D.ev_moved;
+    }
     D.moved_pending = true;
   }
   MDP_TRY(mdp_host_refresh_ghosts(c));  // Comm::forward_comm of x on one periodic rank
-  MDP_TRY(mdp_rebomos_host_precheck(c)); // (the style's own displacement check of the compute that follows)
-  if (c->host_check_armed) MDP_HIP(c, hipStreamSynchronize(c->stream)); // ... whose words that compute reads at once
+  if (!c->hn_deferred_check) {
+    MDP_TRY(mdp_rebomos_host_precheck(c)); // (the style's own displacement check of the compute that follows)
+    if (c->host_check_armed) MDP_HIP(c, hipStreamSynchronize(c->stream)); // ... whose words that compute reads at once
+  }
   return MDP_OK;
 }
 

@@ -347,6 +347,7 @@ struct mdp_ctx {
   DevBuf<double> hn_mass_dev;
   bool hn_v_current = false;      // c->v / c->rmass match the atoms of the last mdp_set_atoms_host
   int ovf_par = 0;                // which of the two sets of pinned overflow counts (h_pinned + 40) this compute uses
+  bool hn_deferred_check = false; // host mode + device integrator, rebomos: the style checks ride in the integrate kernel, read a compute late
   int ang_list_n = -1;            // >= 0: ang_list holds exactly the owned angular centres of the current atoms (mdp_md_build_master_list)
   bool f_prezeroed = false;       // f[0 .. nall) was cleared by the integrate kernel / image refresh of this step (aeam)
   bool f_zero_remote_due = false; // ... except the remote ghosts' part, which this step's halo unpack clears (bricks, step mode)

@@ -3542,7 +3542,8 @@ static int rebomos_lists_stale(mdp_ctx *c, bool &stale)
     if (c->prune_valid && h[2]) c->prune_stale = true;
     return MDP_OK;
   }
-  if (!c->md || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
+  const bool deferred_host = !c->md && c->hn_on && c->hn_deferred_check && !c->check_now; // (mdp_hnve_initial armed it)
+  if ((!c->md && !deferred_host) || c->check_now) { // immediate (host mode; resident mode right after the host rewrote the positions)
     mdp_sflag_drop(c); // (words of a check armed before the positions were rewritten)
     c->check_now = false;
     MDP_TRY(rebomos_check_launch(c, 0.5 * c->skin_inner));
