@@ -430,7 +430,9 @@ int mdp_md_download_int(mdp_ctx *ctx, const char *name, int *out);
  *     mdp_hnve_download(x, v, f) before anything on the host reads them (reneighboring, thermo / dump steps)
  * mdp_hnve_initial: *moved = an owned atom has moved half the host's skin minus a margin since the last
  * mdp_set_atoms_host, as seen by the PREVIOUS call (no wait for the kernel just queued) -- the host reneighbors at its
- * next step; *dangerous = one was beyond half the skin already.  mdp_*_compute_host / mdp_aeam_force_host accept
+ * next step; *dangerous = one was beyond half the skin already.  rebomos: the style's own checks (device-built lists,
+ * pruned rows) ride in the same integrate kernel and are read by the NEXT compute, as in resident runs, so no call of a
+ * step waits for the stream.  mdp_*_compute_host / mdp_aeam_force_host accept
  * f == NULL while the integrator is on (per-atom tallies then need f).  mdp_hnve_off: back to plain host mode. */
 int mdp_hnve_setup(mdp_ctx *ctx, double dt, double ftm2v, const double *mass_per_type /* [ntypes+1], 1-based */, int ntypes);
 int mdp_hnve_off(mdp_ctx *ctx);
