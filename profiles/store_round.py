@@ -19,6 +19,8 @@ for tag, main in ((RND + "_rebomos4m", True), (RND + "_aeam1m", True), (RND + "_
         if not tag.endswith("16m"):
             print("missing", d)
         continue
+    # (bench.json of the collection is the line BEFORE the PMC pass: the lines re-collected afterwards -- collect_rNN.sh lines --
+    #  are copied over it by hand so that the stored JSON carries `traffic`)
     for src, dst in (("bench.json", "bench.json"), ("kernel_summary.txt", "kernel_summary.txt"),
                      ("rocprofv3_kernel_stats.csv", "rocprofv3_kernel_stats.csv"), ("pmc_entry.json", "pmc_fetch_write.json")):
         if os.path.exists(os.path.join(d, src)):
