@@ -704,3 +704,20 @@ def test_device_order_is_element_sorted_inside_every_run_of_32_atoms():
     mixed = sum(1 for k in range(d.nlocal // 2) if t[2 * k] != t[2 * k + 1])
     assert mixed <= nrun                                      # at most one mixed two-atom row per run
     ctx.close()
+
+
+def test_whole_step_calls_without_a_communicator_are_refused():
+    """mdp_dd_comm_step_begin / _end need mdp_dd_comm_init (a one-GPU domain has no communicator): an error with its
+    reason, nothing queued"""
+    s = S.rebomos_bulk_cell()
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP)
+    d.compute(0, 0)
+    with pytest.raises(capi.MdpError, match="mdp_dd_comm_init not called"):
+        ctx.dd_comm_step_begin(False, -1, 0, 0)
+    with pytest.raises(capi.MdpError, match="mdp_dd_comm_init not called"):
+        ctx.dd_comm_step_end(0, 0, False)
+    d.step(0, 0)                                   # ... and the domain goes on as before
+    assert np.isfinite(d.thermo()["pe"])
+    ctx.close()
+

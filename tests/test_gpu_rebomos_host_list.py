@@ -175,3 +175,13 @@ def test_plugin_with_neigh_modify_exclude(oracle, P):
         assert got[3] == pytest.approx(want["pe"], abs=6e-5)
         assert got[4] == pytest.approx(want["ke"], abs=6e-6)
     assert "Neighbor list builds = 0" in out
+
+
+def test_fix_nve_mdp_is_refused_with_the_host_list():
+    """the integrator on the device keeps atoms and images there; lists from the host's rows need the host's atoms"""
+    text = open(os.path.join(PKG, "examples", "in.rebomos-bulk.nve-mdp.mi355x")).read()
+    env = dict(os.environ, MDP_REBOMOS_HOST_LIST="1")
+    p = subprocess.run([os.path.join(PKG, "minilmp")], input=text, capture_output=True, text=True, cwd=PKG, env=env, timeout=300)
+    assert p.returncode != 0
+    assert "cannot be combined with MDP_REBOMOS_HOST_LIST=1" in p.stderr
+
