@@ -44,5 +44,6 @@ for r in range(rounds):
             km += np.array(ctx.get_timing())
         print(json.dumps({"mode": mode, "images_on_device": ctx.host_ghosts_derived(), "upload_ms": round(float(np.median(tu)) * 1e3, 3),
                           "compute_host_ms": round(float(np.median(tc)) * 1e3, 3),
-                          "kernel_phases_ms": [round(v, 3) for v in (km / N).tolist()[:3]]}), flush=True)
+                          # mdp_get_timing, rebomos: [0] centre kernels, [1] general kernel, [2] row pruning, [3] LJ tile + cubic
+                          "kernel_phases_ms": [round(v, 3) for v in (km / N).tolist()[:4]]}), flush=True)
         ctx.close()
