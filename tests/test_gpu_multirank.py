@@ -206,7 +206,8 @@ def test_two_ranks_on_one_gpu_match_single_domain(style):
 
 
 def _worker_rccl_self(port, style, q):
-    """the DEFAULT transport of bench.py -- resident.Transport on the "nccl" backend (RCCL), device buffers straight into
+    """the torch transport of bench.py (MDP_BENCH_TRANSPORT=torch; the default since round 5 is the library's own,
+    tests/test_gpu_domain.py) -- resident.Transport on the "nccl" backend (RCCL), device buffers straight into
     all_to_all_single, the exchange asynchronous behind the interior centres -- with a one-rank process group:
     `self_remote` makes every periodic self-image a remote ghost that travels through the all-to-all to the rank itself"""
     import sys
