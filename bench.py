@@ -49,22 +49,18 @@ def log(*a):
 
 
 # ------------------------------------------------------------------------------------------------ rank launcher
-def launch_ranks(n: int) -> int:
-    """start n fresh rank processes of this script and relay rank 0's JSON line.  The parent makes no GPU call."""
+def _rank_tree(n: int, env: dict, deadline: float):
+    """start n fresh rank processes of this script (own process group) and wait for them: (exit code, result line or
+    None, what went wrong or None).  Whatever ends the parent -- a signal, the deadline, an exception -- ends the ranks
+    too (first SIGTERM, then SIGKILL), so no rank is left holding a GPU."""
+    import signal
+    import threading
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} ...")
-    # the rank tree gets its own process group: whatever ends the parent -- a signal, the deadline below, an
-    # exception -- ends the ranks too (first SIGTERM, then SIGKILL), so no rank is left holding a GPU
-    import signal
-    import threading
-    deadline = float(os.environ.get("MDP_BENCH_DEADLINE_S", "3000"))
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
 
     def stop_ranks(sig=signal.SIGTERM):
@@ -83,7 +79,7 @@ def launch_ranks(n: int) -> int:
 
     def on_deadline():
         timed_out.append(True)
-        log(f"[bench] the ranks did not finish within {deadline:.0f} s (MDP_BENCH_DEADLINE_S): stopping them")
+        log(f"[bench] the ranks did not finish within {deadline:.0f} s: stopping them")
         stop_ranks()
         time.sleep(10)
         stop_ranks(signal.SIGKILL)
@@ -112,21 +108,43 @@ def launch_ranks(n: int) -> int:
         for sg, h in old.items():
             signal.signal(sg, h)
     if timed_out:
-        return 1
+        return 1, None, f"the ranks did not finish within {deadline:.0f} s"
     if rc != 0:
-        log(f"[bench] the rank processes failed (exit code {rc}); no result")
-        return rc if rc > 0 else 1
+        return (rc if rc > 0 else 1), None, f"the rank processes failed (exit code {rc})"
     if line is None:
-        log("[bench] the ranks exited without a result line")
-        return 1
+        return 1, None, "the ranks exited without a result line"
     try:
         got = json.loads(line)
     except ValueError:
-        log("[bench] rank 0 printed a damaged result line")
-        return 1
+        return 1, None, "rank 0 printed a damaged result line"
     if got.get("n_gpus") != n or got.get("config", {}).get("rccl_ranks", n) != n:
-        log(f"[bench] the result is for {got.get('n_gpus')} ranks, {n} were asked for; refusing it")
-        return 1
+        return 1, None, f"the result is for {got.get('n_gpus')} ranks, {n} were asked for"
+    return 0, line, None
+
+
+def launch_ranks(n: int) -> int:
+    """start n fresh rank processes of this script and relay rank 0's JSON line.  The parent makes no GPU call.
+    The default transport is the library's own (csrc/comm_rccl.hip).  If those ranks fail or pass their deadline
+    (MDP_BENCH_NATIVE_DEADLINE_S, 420 s), ONE fallback: fresh rank processes with MDP_BENCH_TRANSPORT=torch (all-to-all
+    through torch.distributed), and the line says so in `transport_fallback` -- never silently.  Both failing: non-zero."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    total = float(os.environ.get("MDP_BENCH_DEADLINE_S", "3000"))
+    native_first = env.get("MDP_BENCH_TRANSPORT", "native") == "native"
+    t0 = time.time()
+    first_deadline = min(total, float(os.environ.get("MDP_BENCH_NATIVE_DEADLINE_S", "420"))) if native_first else total
+    rc, line, why = _rank_tree(n, env, first_deadline)
+    if rc != 0 and native_first and os.environ.get("MDP_BENCH_NO_FALLBACK", "0") in ("", "0"):
+        left = total - (time.time() - t0)
+        log(f"[bench] library transport: {why}; starting fresh ranks on the torch.distributed transport ({left:.0f} s left)")
+        if left > 30:
+            env2 = dict(env, MDP_BENCH_TRANSPORT="torch", MDP_BENCH_FALLBACK_REASON="library transport (csrc/comm_rccl.hip): " + why)
+            env2.pop("MDP_BENCH_TEST_FAIL_NATIVE", None)
+            rc, line, why = _rank_tree(n, env2, left)
+    if rc != 0:
+        log(f"[bench] {why}; no result")
+        return rc
     print(line, flush=True)
     return 0
 
@@ -483,9 +501,15 @@ def run_job(E, job, par):
         "data": "synthetic",
         "ns_per_day": round(job["steps"] / elapsed * 0.001 * 86.4, 4),
         "config": {"workload": wname, "atoms": s.n, "style": wl, "parallelism": f"spatial-dd{world}",
-                   "transport": (("rccl (library, ncclSend/ncclRecv)" if native else "rccl (torch.distributed all_to_all)")
-                                 if not stage_host else par["backend"] + "-staged (rehearsal)") + (" to the rank itself (one-rank rehearsal)" if par.get("self_remote") else "")
+                   "transport": (("library (csrc/comm_rccl.hip, ncclSend/ncclRecv) on the TEST DOUBLE of tests/native: "
+                                  f"{world} ranks share one GPU, host-staged -- a rehearsal of the schedule, not a measurement"
+                                  if par.get("double") else
+                                  ("rccl (library, ncclSend/ncclRecv)" if native else "rccl (torch.distributed all_to_all)")
+                                  if not stage_host else par["backend"] + "-staged (rehearsal)")
+                                 + (" to the rank itself (one-rank rehearsal)" if par.get("self_remote") else ""))
                    if dist is not None else "none (one GPU)",
+                   "rccl_library": par.get("rccl_lib") if native else None,
+                   "rccl_library_is_test_double": bool(par.get("double")),
                    "initial_temp_K": job["temp"], "skin": skin, "thermo_every": thermo_every,
                    "displacement_check": "every step, deferred on-device flag" if dist is None
                    else ("every step, every rank's flag gathered behind the position exchange (no blocking collective)"
@@ -608,7 +632,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # MDP_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks: every rank uses
     # GPU (local_rank mod #GPUs) and the halo is staged through the host.  The judged runs use RCCL.
-    backend = os.environ.get("MDP_BENCH_BACKEND", "nccl")
+    # MDP_RCCL_LIBRARY pointing at the TEST DOUBLE of tests/native (several ranks on one GPU through the library's own
+    # transport, host-staged): the process group is gloo then -- it only hands the communicator id round and reduces
+    # the clock -- and the line is marked as a rehearsal.
+    rccl_lib, double = (capi.comm_library() if os.environ.get("MDP_RCCL_LIBRARY") else ("librccl.so.1", False))
+    backend = os.environ.get("MDP_BENCH_BACKEND", "gloo" if double else "nccl")
     stage_host = backend != "nccl"
     ngpu = torch.cuda.device_count()
     if stage_host:
@@ -639,9 +667,11 @@ def main():
     # (csrc/comm_rccl.hip: whole steps in two library calls, the `check yes` decision riding with the halo; the process
     # group then only distributes the communicator id); MDP_BENCH_TRANSPORT=torch = all-to-all through torch.distributed
     # (RCCL) with a collective displacement check every --check-every steps
-    native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "native") == "native" and not stage_host
+    native = dist is not None and os.environ.get("MDP_BENCH_TRANSPORT", "native") == "native" and (not stage_host or double)
+    if native and os.environ.get("MDP_BENCH_TEST_FAIL_NATIVE", "0") not in ("", "0"):
+        raise SystemExit("bench.py: MDP_BENCH_TEST_FAIL_NATIVE set -- the library-transport ranks give up (test of the fallback)")
     par = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, dev=dev, stage_host=stage_host, native=native,
-               backend=backend, self_remote=self_remote)
+               backend=backend, self_remote=self_remote, double=double and native, rccl_lib=rccl_lib)
 
     job = dict(workload=args.workload, replicate=list(args.replicate), temp=args.temp, steps=args.steps, warmup=args.warmup,
                thermo_every=THERMO_EVERY[args.workload] if args.thermo is None else args.thermo, check_every=args.check_every)
@@ -651,6 +681,8 @@ def main():
         job["disorder"] = dict(frac2=args.frac2)
     out, pieces = run_job(E, job, par)
     out["config"]["rccl_ranks"] = rccl_ranks
+    if os.environ.get("MDP_BENCH_FALLBACK_REASON"):
+        out["transport_fallback"] = os.environ["MDP_BENCH_FALLBACK_REASON"]
     if rank == 0 and world == 1 and dist is None and not args.no_host_mode:
         try:
             hm, img = host_mode_rate(E, pieces["s"], args.workload, pieces["pot"], pieces["skin"], pieces["cutghost"])

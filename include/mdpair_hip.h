@@ -374,6 +374,11 @@ int mdp_dd_reverse_unpack(mdp_ctx *ctx, const double *d_buf);  /* += onto the se
  * calls below are collective over the ranks and run on the context's stream; the per-step position exchange uses
  * a stream of its own between _begin and _end, so that work launched in between (mdp_md_compute_begin) overlaps it. */
 int mdp_dd_comm_unique_id(void *id128);
+/* Which RCCL object is bound: the name goes to buf (may be NULL).  Returns 0 for a RCCL library, 1 when MDP_RCCL_LIBRARY
+ * points at the repository's TEST DOUBLE (tests/native/fake_rccl.cpp: several ranks sharing one GPU, host-staged -- a
+ * rehearsal of the exchange schedule whose timings mean nothing; every report has to say so), MDP_ENOTIMPL when nothing
+ * loads.  MDP_RCCL_LIBRARY=<path> binds that one object instead of librccl.so.1; nothing else is tried then. */
+int mdp_dd_comm_library(char *buf, int cap);
 int mdp_dd_comm_init(mdp_ctx *ctx, const void *id128);
 int mdp_dd_comm_destroy(mdp_ctx *ctx);
 int mdp_dd_comm_reneighbor(mdp_ctx *ctx);       /* Comm::exchange + Comm::borders + Neighbor::build */

@@ -32,6 +32,8 @@ struct RcclApi {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   bool ok = false;
+  bool test_double = false; // bound to tests/native/libfake_rccl.so (MDP_RCCL_LIBRARY): a rehearsal, reported as one
+  char path[256] = {0};
 };
 
 RcclApi *rccl()
@@ -40,11 +42,24 @@ RcclApi *rccl()
   static std::once_flag once; // several contexts may come up on several host threads at the same time
   std::call_once(once, [] {
     void *h = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (h) break;
+    // MDP_RCCL_LIBRARY: the one object to bind instead of the system's RCCL (a differently named build, or the test
+    // double of tests/native/fake_rccl.cpp that lets several ranks share one GPU); nothing else is tried then
+    const char *forced = getenv("MDP_RCCL_LIBRARY");
+    if (forced && *forced) {
+      h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+      if (!h) fprintf(stderr, "mdpair_hip: MDP_RCCL_LIBRARY=%s could not be loaded: %s\n", forced, dlerror());
+      else snprintf(api.path, sizeof api.path, "%s", forced);
+    } else {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+          snprintf(api.path, sizeof api.path, "%s", name);
+          break;
+        }
+      }
     }
     if (!h) return;
+    api.test_double = dlsym(h, "mdp_fake_rccl_marker") != nullptr;
 #define MDP_SYM(field, sym)                                        \
   api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym)); \
   if (!api.field) return
@@ -162,6 +177,16 @@ int mdp_dd_comm_unique_id(void *id128)
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   memcpy(id128, &id, sizeof id);
   return MDP_OK;
+}
+
+// which RCCL object the library is bound to; returns 1 when it is the test double of tests/native (several ranks on one
+// GPU, host-staged: a rehearsal of the exchange schedule, never a measurement), 0 for a real RCCL, < 0 when none loads
+int mdp_dd_comm_library(char *buf, int cap)
+{
+  RcclApi *R = rccl();
+  if (buf && cap > 0) snprintf(buf, (size_t) cap, "%s", R ? R->path : "");
+  if (!R) return MDP_ENOTIMPL;
+  return R->test_double ? 1 : 0;
 }
 
 int mdp_dd_comm_init(mdp_ctx *c, const void *id128)

@@ -63,7 +63,7 @@ EXPORTS = [
     "mdp_dd_borders_begin", "mdp_dd_borders_pack", "mdp_dd_borders_end", "mdp_dd_info", "mdp_dd_forward_pack",
     "mdp_dd_forward_unpack", "mdp_dd_forward_scalar_pack", "mdp_dd_forward_scalar_unpack", "mdp_dd_reverse_pack",
     "mdp_dd_reverse_unpack", "mdp_md_moved_async", "mdp_md_integrate_check", "mdp_md_download_int", "mdp_md_download_x_all",
-    "mdp_dd_comm_unique_id", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
+    "mdp_dd_comm_unique_id", "mdp_dd_comm_library", "mdp_dd_comm_init", "mdp_dd_comm_destroy", "mdp_dd_comm_reneighbor",
     "mdp_dd_comm_forward_begin", "mdp_dd_comm_forward_end", "mdp_dd_comm_forward_scalar", "mdp_dd_comm_reverse",
     "mdp_dd_comm_allreduce", "mdp_dd_comm_step_begin", "mdp_dd_comm_step_end", "mdp_dd_comm_step_info", "mdp_aeam_device_lists", "mdp_rebomos_host_list", "mdp_aeam_check_host_list",
     "mdp_md_defer_final", "mdp_md_list_state", "mdp_md_aeam_force_begin", "mdp_md_aeam_state", "mdp_dd_comm_aeam_exchange_begin", "mdp_dd_comm_aeam_exchange_end",
@@ -105,6 +105,19 @@ def _dp(a):
 
 def _ip(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def comm_library():
+    """(name of the RCCL object the library binds, True when it is the test double of tests/native)"""
+    buf = C.create_string_buffer(256)
+    rc = lib().mdp_dd_comm_library(buf, C.c_int(256))
+    if rc < 0:
+        raise MdpError(rc, "no RCCL library could be loaded (MDP_RCCL_LIBRARY / librccl.so.1)")
+    return buf.value.decode(), rc == 1
+
+
+FAKE_RCCL = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "native",
+                                          "libfake_rccl.so"))
 
 
 def read_rebomos_file(path: str) -> RebomosParams:

@@ -150,6 +150,7 @@ class DeviceDomain:
         ctx.md_setup(cfg, x, v, s.type[mine], s.tag[mine], s.mass, map_, e1, e3, e1, e1)
         ctx.dd_setup(s.box, self.grid, self.rank, cutghost, self_remote=self_remote, nonperiodic=nonperiodic)
         self.native = bool(getattr(transport, "native", False))
+        self.native_two_call = True    # (False: the library's transport through the piecewise calls below -- tests)
         if self.native:
             transport.attach(ctx)
         self.send3 = self.recv3 = self.send1 = self.recv1 = None
@@ -333,7 +334,7 @@ class DeviceDomain:
         half-kicks in one pass (mdp_md_final_initial_integrate; same arithmetic) -- for steps after which nothing
         reads the velocities; thermo() / compute() / reneighbor() / flush() complete it otherwise."""
         ctx = self.ctx
-        if self.native and self.tr is not None:
+        if self.native and self.tr is not None and self.native_two_call:
             # The library's own transport drives the whole step in two calls (mdp_dd_comm_step_begin / _end): integrate,
             # decide, reneighbor or exchange, compute, final kick.  rebuild="halo" (or "auto"): the collective `check yes`
             # decision comes from the word that travelled with the previous step's halo -- no blocking call here.
@@ -468,8 +469,10 @@ class ThreadTransport:
         return np.sum(np.array(self._all(np.asarray(list(values), dtype=np.float64))), axis=0)
 
 
-def run_ranks(world: int, fn, device=0):
-    """run fn(rank, make_transport) on `world` threads; make_transport(ctx) gives the rank's ThreadTransport.
+def run_ranks(world: int, fn, device=0, native=False):
+    """run fn(rank, make_transport) on `world` threads; make_transport(ctx) gives the rank's ThreadTransport, or --
+    native=True -- a NativeTransport: the library's own RCCL transport with `world` ranks.  On one GPU that needs
+    MDP_RCCL_LIBRARY to name the test double of tests/native (RCCL itself refuses two ranks on one device).
     Returns the list of results; the first exception of any rank is re-raised."""
     import threading
     import torch
@@ -477,10 +480,22 @@ def run_ranks(world: int, fn, device=0):
     out, err = [None] * world, [None] * world
     dev = torch.device("cuda", device)
 
+    def bcast_from(r):
+        def bcast(b):                        # rank 0's communicator id to every rank thread
+            shared.barrier.wait()
+            if r == 0:
+                shared.slots[0] = b
+            shared.barrier.wait()
+            return shared.slots[0]
+        return bcast
+
     def body(r):
         try:
             torch.cuda.set_device(device)
-            out[r] = fn(r, lambda ctx: ThreadTransport(shared, r, ctx, dev))
+            if native:
+                out[r] = fn(r, lambda ctx: NativeTransport(world, r, bcast_from(r)))
+            else:
+                out[r] = fn(r, lambda ctx: ThreadTransport(shared, r, ctx, dev))
         except BaseException as e:   # noqa: BLE001 -- re-raised below
             err[r] = e
             shared.barrier.abort()

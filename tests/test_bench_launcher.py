@@ -30,6 +30,9 @@ def test_ranks_that_cannot_come_up_give_no_result():
     assert r.returncode != 0                       # never falls back to one rank
     assert '"metric"' not in r.stdout
     assert "starting 2 ranks" in r.stderr
+    # the one fallback (fresh ranks on the torch.distributed transport) was tried and failed as well: still no result
+    assert "starting fresh ranks on the torch.distributed transport" in r.stderr
+    assert r.stderr.count("starting 2 ranks") == 2
 
 
 import pytest
