@@ -914,9 +914,18 @@ int mdp_md_download_int(mdp_ctx *c, const char *name, int *out)
     if (2 * c->ntile > c->nlocal) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: tile_nu needs 2 * %d ints", c->ntile);
     src = c->tile_nu.p;
   }
+  // diagnostics: length / first-segment length of every cluster's row of 16-bit entries, as the Lennard-Jones (rebomos)
+  // or pair (aeam) tile kernels walk them now -- the pruned rows while a pruning is valid; nclus <= nlocal ints
+  const bool rows = !strcmp(name, "lj_len") || !strcmp(name, "lj_split");
+  if (rows) {
+    if (!c->lj_tiled || !c->nclus) return mdp_fail(c, MDP_ESTATE, "mdp_md_download_int: no tile rows");
+    const bool pr = c->prune_valid;
+    src = !strcmp(name, "lj_len") ? (pr ? c->lj_len_in.p : nullptr) : (pr ? c->lj_split_in.p : c->lj_split.p);
+    if (!src) return mdp_fail(c, MDP_ESTATE, "mdp_md_download_int: lj_len needs pruned rows (the rows as built: mdp_rebomos_list_info)");
+  }
   if (!src) return mdp_fail(c, MDP_EINVAL, "mdp_md_download_int: unknown array '%s'", name);
   // through the context's pinned buffer, complete on return (no asynchronous copy into the caller's pageable memory)
-  const size_t n = !strcmp(name, "tile_nu") ? (size_t) 2 * c->ntile : (size_t) c->nlocal;
+  const size_t n = !strcmp(name, "tile_nu") ? (size_t) 2 * c->ntile : (rows ? (size_t) c->nclus : (size_t) c->nlocal);
   if (n) {
     MDP_TRY(mdp_host_pinned_reserve(c, (n * sizeof(int) + 7) / 8 + 1));
     MDP_HIP(c, hipMemcpyAsync(c->h_down, src, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
