@@ -367,6 +367,11 @@ def run_job(E, job, par):
     dom.compute(1, 1)
     th = dom.thermo()
     pe0 = th["pe"]
+    overlap = None
+    if native:
+        # part of the setup, before the W warm-up steps: the library tries its orders of compute against exchanges on
+        # THIS machine and keeps the cheapest (mdp_dd_comm_step_info); a fixed policy (MDP_OVERLAP_POLICY) skips this
+        overlap = dom.tune_overlap()
     stats = ctx.md_neighbor_stats()
     if rank == 0:
         log(f"[bench] {wname}: {s.n} atoms, {world} GPU(s), T0 {job['temp']} K; rank0 nlocal={dom.nlocal} "
@@ -508,6 +513,8 @@ def run_job(E, job, par):
                                   if not stage_host else par["backend"] + "-staged (rehearsal)")
                                  + (" to the rank itself (one-rank rehearsal)" if par.get("self_remote") else ""))
                    if dist is not None else "none (one GPU)",
+                   "overlap_policy": ({k: overlap[k] for k in ("overlap_policy", "overlap_policy_fixed_by_env",
+                                                               "overlap_policy_trial_ms", "trial_steps")} if overlap else None),
                    "rccl_library": par.get("rccl_lib") if native else None,
                    "rccl_library_is_test_double": bool(par.get("double")),
                    "initial_temp_K": job["temp"], "skin": skin, "thermo_every": thermo_every,

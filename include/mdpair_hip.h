@@ -406,7 +406,14 @@ int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 
  *           pair forces when possible, the same exchanges in the blocking order otherwise), final half-kick now
  *           (defer_final = 0) or fused into the next _begin (1).
  * mdp_dd_comm_step_info: out[0] = aeam steps on the phased order, [1] = 1 if ghost forces travel, [2] = 1 if the last
- * _begin reneighbored, [3] = reneighborings so far, [4] = checks that saw an owned atom beyond half the skin. */
+ * _begin reneighbored, [3] = reneighborings so far, [4] = checks that saw an owned atom beyond half the skin,
+ * [5] = overlap policy, [6] = 1 if MDP_OVERLAP_POLICY fixed it, [7] = its mean device time per step in the trial (ns).
+ * Overlap policy: how a step orders its compute against its exchanges -- 0 "split" (what needs no remote ghost of this
+ * step is launched behind the start of the exchange), 1 "lead" (as 0, and the compute stream waits until the RCCL kernel
+ * has started), 2 "blocking" (exchange, then the whole compute), 3 "first" (rebomos: only the first interior kernel
+ * behind the exchange).  The sends and receives are the same in all of them.  The first steps of a run are a trial
+ * (blocks of 4 steps per policy, two rounds; -1 in out[5] while it runs): device time per step between two events, MAX
+ * over the ranks, cheapest policy kept.  MDP_OVERLAP_POLICY = split | lead | blocking | first skips the trial. */
 int mdp_dd_comm_step_begin(mdp_ctx *ctx, int with_final, int force_rebuild, int eflag, int vflag, int *reneighbored);
 int mdp_dd_comm_step_end(mdp_ctx *ctx, int eflag, int vflag, int defer_final);
 int mdp_dd_comm_step_info(mdp_ctx *ctx, long long out[8]);

@@ -1798,6 +1798,7 @@ int mdp_aeam_run_begin(mdp_ctx *c, int eflag, int vflag)
   if (!c->aeam_tiled || c->aeam_split <= 0 || (vflag & MDP_VFLAG_ATOM) || !c->nlocal) return MDP_OK;
   if (const char *e = getenv("MDP_AEAM_OVERLAP"))
     if (atoi(e) == 0) return MDP_OK;
+  if (c->overlap_mode == 2) return MDP_OK; // blocking order chosen for this step (MdpDomain::ov_policy)
   double cut[4];
   aeam_prune_cuts(c, cut);
   bool due = false;

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <mutex>
+#include <string>
 #include <rccl/rccl.h>
 
 namespace {
@@ -155,11 +156,124 @@ int comm_lead(mdp_ctx *c)
     const char *e = getenv("MDP_COMM_LEAD");
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
   }();
-  if (lead == 0 || (lead < 0 && c->cfg.style != 2)) return MDP_OK;
   MdpDomain &D = c->dd;
+  // whole steps in the library (step mode): the overlap policy of the step decides; piecewise callers keep the
+  // measured default (aeam yes, rebomos no)
+  const bool want = D.step_mode ? D.lead : c->cfg.style == 2;
+  if (lead == 0 || (lead < 0 && !want)) return MDP_OK;
   if (!D.ev_lead) MDP_HIP(c, hipEventCreateWithFlags(&D.ev_lead, hipEventDisableTiming));
   MDP_HIP(c, hipEventRecord(D.ev_lead, D.comm_stream));
   MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_lead, 0));
+  return MDP_OK;
+}
+
+// ---- overlap policy -------------------------------------------------------------------------------------------------
+// Whether an exchange really travels behind the interior work depends on the machine: on one MI355X a RCCL kernel
+// queued behind a compute kernel that fills the device ends when that kernel's grid has drained, and
+// what real xGMI links do is not known before the first run on them.  So the first steps of a run are a trial: blocks
+// of kOvBlock steps take the policies in turn (every rank the same one in the same step: the schedule depends on the
+// step count only), the device time of each step is taken between two events on the context's stream -- it contains
+// every wait for an exchange --, the ranks' means are reduced with MAX, and the cheapest policy stays.  The exchanges
+// themselves are the same in every policy (same sends and receives, issued at the same point of the step), so ranks
+// could even differ without harm; they do not, because they reduce before they choose.
+// MDP_OVERLAP_POLICY = split | lead | blocking | first fixes the policy (no trial); auto (default) runs the trial.
+constexpr int kOvBlock = 4, kOvRounds = 2; // steps per block (the first is the transition and is not measured), rounds
+
+int ov_npol(const mdp_ctx *c) { return c->cfg.style == 1 ? 4 : 3; }
+
+const char *ov_name(int p)
+{
+  static const char *n[4] = {"split", "lead", "blocking", "first"};
+  return p >= 0 && p < 4 ? n[p] : "undecided";
+}
+
+void ov_read_env(mdp_ctx *c)
+{
+  MdpDomain &D = c->dd;
+  if (D.ov_forced != -2) return;
+  D.ov_forced = -1;
+  if (const char *e = getenv("MDP_OVERLAP_POLICY")) {
+    for (int p = 0; p < ov_npol(c); p++)
+      if (!strcmp(e, ov_name(p))) D.ov_forced = p;
+    if (D.ov_forced < 0 && strcmp(e, "auto"))
+      fprintf(stderr, "mdpair_hip: MDP_OVERLAP_POLICY=%s is not one of split, lead, blocking%s, auto: running the trial\n", e,
+              c->cfg.style == 1 ? ", first" : "");
+  }
+  if (D.ov_forced >= 0) D.ov_policy = D.ov_forced;
+}
+
+// completed event pairs -> sums (never waits unless `drain`)
+int ov_harvest(mdp_ctx *c, bool drain)
+{
+  MdpDomain &D = c->dd;
+  for (int k = 0; k < 4; k++) {
+    if (D.ov_slot_pol[k] < 0 || k == D.ov_slot) continue;
+    if (drain) MDP_HIP(c, hipEventSynchronize(D.ov_ev[k][1]));
+    else if (hipEventQuery(D.ov_ev[k][1]) != hipSuccess) continue;
+    float ms = 0.0f;
+    MDP_HIP(c, hipEventElapsedTime(&ms, D.ov_ev[k][0], D.ov_ev[k][1]));
+    D.ov_sum[D.ov_slot_pol[k]] += ms;
+    D.ov_cnt[D.ov_slot_pol[k]]++;
+    D.ov_slot_pol[k] = -1;
+  }
+  return MDP_OK;
+}
+
+// at the head of a step: the policy this step runs under; opens the measurement of a trial step
+int ov_step_begin(mdp_ctx *c, bool plain_step /* no reneighboring, no tally: comparable with its neighbours */)
+{
+  MdpDomain &D = c->dd;
+  ov_read_env(c);
+  D.ov_slot = -1;
+  if (D.ov_policy < 0) {
+    const int np = ov_npol(c);
+    const long long total = (long long) kOvBlock * np * kOvRounds;
+    MDP_TRY(ov_harvest(c, false));
+    if (D.ov_step >= total) { // the trial is over: every rank reduces the same vector at the same step
+      MDP_TRY(ov_harvest(c, true));
+      double mean[4];
+      for (int p = 0; p < 4; p++) mean[p] = p < np && D.ov_cnt[p] > 0 ? D.ov_sum[p] / D.ov_cnt[p] : (p < np ? 1.0e30 : 0.0);
+      MDP_TRY(mdp_dd_comm_allreduce(c, mean, 4, /*max*/ 1));
+      int best = 0;
+      for (int p = 1; p < np; p++)
+        if (mean[p] < mean[best] * 0.995) best = p; // (a later policy has to win by half a percent)
+      for (int p = 0; p < 4; p++) D.ov_mean[p] = mean[p];
+      D.ov_policy = best;
+      if (D.G.rank == 0)
+        fprintf(stderr, "mdpair_hip: overlap policy %s (device ms per step, max over %d ranks: split %.4f lead %.4f blocking %.4f%s)\n",
+                ov_name(best), D.G.nranks, mean[0], mean[1], mean[2],
+                np > 3 ? (std::string(" first ") + std::to_string(mean[3])).c_str() : "");
+    }
+  }
+  if (D.ov_policy >= 0) {
+    D.ov_cur = D.ov_policy;
+  } else {
+    D.ov_cur = (int) ((D.ov_step / kOvBlock) % ov_npol(c));
+    const bool measured = plain_step && D.ov_step % kOvBlock != 0;
+    D.ov_step++;
+    if (measured)
+      for (int k = 0; k < 4 && D.ov_slot < 0; k++)
+        if (D.ov_slot_pol[k] < 0) D.ov_slot = k;
+    if (D.ov_slot >= 0) {
+      for (int e = 0; e < 2; e++)
+        if (!D.ov_ev[D.ov_slot][e]) MDP_HIP(c, hipEventCreate(&D.ov_ev[D.ov_slot][e]));
+      MDP_HIP(c, hipEventRecord(D.ov_ev[D.ov_slot][0], c->stream));
+    }
+  }
+  D.lead = D.ov_cur == 1;
+  c->overlap_mode = D.ov_cur == 2 ? 2 : (D.ov_cur == 3 ? 3 : 0);
+  return MDP_OK;
+}
+
+int ov_step_end(mdp_ctx *c)
+{
+  MdpDomain &D = c->dd;
+  if (D.ov_slot >= 0) {
+    MDP_HIP(c, hipEventRecord(D.ov_ev[D.ov_slot][1], c->stream));
+    D.ov_slot_pol[D.ov_slot] = D.ov_cur;
+    D.ov_slot = -1;
+  }
+  c->overlap_mode = 0; // (piecewise callers of mdp_md_compute_begin / _end keep the split order)
   return MDP_OK;
 }
 
@@ -229,6 +343,11 @@ int mdp_dd_comm_destroy(mdp_ctx *c)
   if (D.ev_arrived) (void) hipEventDestroy(D.ev_arrived);
   if (D.ev_lead) (void) hipEventDestroy(D.ev_lead);
   D.ev_packed = D.ev_arrived = D.ev_lead = nullptr;
+  for (int k = 0; k < 4; k++)
+    for (int e = 0; e < 2; e++) {
+      if (D.ov_ev[k][e]) (void) hipEventDestroy(D.ov_ev[k][e]);
+      D.ov_ev[k][e] = nullptr;
+    }
   D.sbuf.release();
   D.rbuf.release();
   D.cnt_dev.release();
@@ -453,6 +572,7 @@ int mdp_dd_comm_step_begin(mdp_ctx *c, int with_final, int force_rebuild, int ef
   }
   int moved = 0, dangerous = 0;
   const bool rebuild = force_rebuild > 0 || (force_rebuild < 0 && glob);
+  MDP_TRY(ov_step_begin(c, !rebuild && !eflag && !vflag));
   if (rebuild) {
     // (no check of the new positions: they are about to become the reference)
     MDP_TRY(mdp_md_advance(c, with_final != 0, nullptr, 0.0, 0.0));
@@ -500,12 +620,14 @@ int mdp_dd_comm_step_end(mdp_ctx *c, int eflag, int vflag, int defer_final)
       else MDP_TRY(mdp_md_fold_self_ghost_f(c));
     }
   }
-  if (defer_final) return mdp_md_defer_final(c);
-  return mdp_md_final_integrate(c);
+  if (defer_final) MDP_TRY(mdp_md_defer_final(c));
+  else MDP_TRY(mdp_md_final_integrate(c));
+  return ov_step_end(c);
 }
 
 // [0] = aeam steps on the phased order so far, [1] = ghost forces travel (aeam), [2] = the last _begin reneighbored,
-// [3] = reneighborings, [4] = checks that saw an owned atom beyond half the skin ("dangerous builds")
+// [3] = reneighborings, [4] = checks that saw an owned atom beyond half the skin ("dangerous builds"),
+// [5] = overlap policy (-1 while its trial runs), [6] = 1 if MDP_OVERLAP_POLICY fixed it, [7] = its trial mean in ns
 int mdp_dd_comm_step_info(mdp_ctx *c, long long out[8])
 {
   if (!c || !out) return MDP_EINVAL;
@@ -515,6 +637,9 @@ int mdp_dd_comm_step_info(mdp_ctx *c, long long out[8])
   out[2] = c->dd.fresh_ghosts ? 1 : 0;
   out[3] = c->dd.reneighbors;
   out[4] = c->dd.dangerous;
+  out[5] = c->dd.ov_policy;                  // 0 split, 1 lead, 2 blocking, 3 first; -1 while the trial runs
+  out[6] = c->dd.ov_forced >= 0 ? 1 : 0;     // fixed by MDP_OVERLAP_POLICY
+  out[7] = (long long) (c->dd.ov_mean[c->dd.ov_policy >= 0 ? c->dd.ov_policy : 0] * 1.0e6 + 0.5); // its trial mean, ns
   return MDP_OK;
 }
 

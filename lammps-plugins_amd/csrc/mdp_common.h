@@ -227,6 +227,23 @@ struct MdpDomain {
   bool ghost_forces = true;        // aeam: some rank has an angular centre next to a remote ghost (decided per reneighboring)
   long long dangerous = 0;         // step mode: checks that saw an owned atom beyond half the skin
   long long steps_phased = 0;      // aeam steps whose exchanges travelled behind the interior tiles
+  // How a step orders its compute against its exchanges (mdp_dd_comm_step_begin / _end), chosen from measurements on
+  // the machine the run is on (comm_rccl.hip, "overlap policy"):
+  //   0 split     the work that needs no remote ghost of this step is launched behind the start of the exchange
+  //   1 lead      as 0, and the compute stream waits until the RCCL kernel of the exchange has started (comm_lead)
+  //   2 blocking  exchange first, then the whole compute in its one-GPU order
+  //   3 first     rebomos only: of the interior work only the first kernel (lane-per-centre) runs behind the exchange
+  int ov_policy = -1;              // the choice; -1 while the trial runs
+  int ov_forced = -2;              // MDP_OVERLAP_POLICY: -2 not read yet, -1 auto, >= 0 fixed
+  int ov_cur = 0;                  // policy of the step in flight
+  bool lead = false;               // (policy 1 of the step in flight)
+  long long ov_step = 0;           // steps the trial has seen
+  double ov_sum[4] = {0, 0, 0, 0}; // device time of the measured steps per policy, ms
+  int ov_cnt[4] = {0, 0, 0, 0};
+  double ov_mean[4] = {0, 0, 0, 0};
+  hipEvent_t ov_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  int ov_slot_pol[4] = {-1, -1, -1, -1}; // policy of the step a slot's event pair brackets (-1: free)
+  int ov_slot = -1;                // slot of the step in flight (-1: not measured)
 };
 
 constexpr int MDP_UP_RING = 2;      // host-mode upload: pinned staging chunks in flight
@@ -312,6 +329,9 @@ struct mdp_ctx {
   // halo overlap (multi-GPU): clusters whose lists reach no remote ghost come first in cl_order
   int remote_start = 1 << 30;
   bool centre_split = false;      // REBO centres split interior / boundary (default with remote ghosts)
+  int centres_early = 0;          // rebomos: which interior centre kernels mdp_rebomos_run_begin launched (launch_centres `which`)
+  int overlap_mode = 0;           // this step: 0 interior work in compute_begin, 2 nothing early (blocking order), 3 rebomos:
+                                  // only the lane-per-centre kernel early (MdpDomain::ov_policy; set per step by the step calls)
   DevBuf<int> cl_flag, cl_pos, cl_order;
   DevBuf<int> lj_split;           // [nclus] number of Mo entries at the head of each row
   // Lennard-Jones tile lists (default): the MDP_TILE consecutive clusters one workgroup handles share

@@ -3819,17 +3819,22 @@ static int launch_lj_cubic(mdp_ctx *c, int eflag, int vflag)
 }
 
 // parts: bit 0 = interior centres, bit 1 = boundary centres (+ the overflow pass, which must follow both)
-static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts)
+// which (interior part only): bit 0 = the lane-per-centre kernel, bit 1 = the lane-group kernels; `first` = this is the
+// first centre launch of the compute
+static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts, int which = 3, bool first = true)
 {
-  if (parts & 1) c->ovf_par ^= 1; // (a new compute: the set of pinned overflow counts it reads first and writes last)
+  if ((parts & 1) && first) c->ovf_par ^= 1; // (a new compute: the set of pinned overflow counts it reads first and writes last)
   hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
   for (int part = 0; part < 2; part++) {
     if (!((parts >> part) & 1)) continue;
-    launch_centre3(c, eflag, vflag, part);
-    launch_centre<8>(c, 1, eflag, vflag, part);
-    launch_centre<12>(c, 2, eflag, vflag, part);
-    launch_centre<16>(c, 3, eflag, vflag, part);
-    launch_centre<32>(c, 4, eflag, vflag, part);
+    const int w = part == 0 ? which : 3;
+    if (w & 1) launch_centre3(c, eflag, vflag, part);
+    if (w & 2) {
+      launch_centre<8>(c, 1, eflag, vflag, part);
+      launch_centre<12>(c, 2, eflag, vflag, part);
+      launch_centre<16>(c, 3, eflag, vflag, part);
+      launch_centre<32>(c, 4, eflag, vflag, part);
+    }
   }
   MDP_HIP(c, hipGetLastError());
   if (!(parts & 2)) return MDP_OK;
@@ -3888,7 +3893,12 @@ int mdp_rebomos_run_begin(mdp_ctx *c, int eflag, int vflag)
     MDP_HIP(c, c->vslot.reserve((size_t) 6 * c->cand_total + 6));
     MDP_HIP(c, hipMemsetAsync(c->vatom.p, 0, sizeof(double) * 6 * c->nall, c->stream));
   }
-  if (c->centre_split && !(vflag & MDP_VFLAG_ATOM)) MDP_TRY(launch_centres(c, eflag, vflag, /*interior*/ 1));
+  // (overlap_mode: what of the interior work runs here, behind the start of the halo exchange -- MdpDomain::ov_policy)
+  c->centres_early = 0;
+  if (c->centre_split && !(vflag & MDP_VFLAG_ATOM) && c->overlap_mode != 2) {
+    c->centres_early = c->overlap_mode == 3 ? 1 : 3;
+    MDP_TRY(launch_centres(c, eflag, vflag, /*interior*/ 1, c->centres_early));
+  }
   MDP_HIP(c, hipGetLastError());
   return MDP_OK;
 }
@@ -3900,8 +3910,12 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
   const bool va = (vflag & MDP_VFLAG_ATOM) != 0;
   if (va)
     MDP_TRY(launch_centres_vatom(c, eflag, vflag));
-  else
-    MDP_TRY(launch_centres(c, eflag, vflag, c->centre_split ? /*boundary*/ 2 : 3));
+  else if (!c->centre_split)
+    MDP_TRY(launch_centres(c, eflag, vflag, 3));
+  else if (c->centres_early == 3)
+    MDP_TRY(launch_centres(c, eflag, vflag, /*boundary*/ 2));
+  else // the interior kernels that did not run behind the exchange, then the boundary centres
+    MDP_TRY(launch_centres(c, eflag, vflag, 3, 3 & ~c->centres_early, /*first=*/c->centres_early == 0));
   if (va) mdp_time_mark(c, 1);
   mdp_time_mark(c, 2);
   if (va) {

@@ -350,6 +350,7 @@ class DeviceDomain:
             self._final_pending = bool(defer_final)
             si = ctx.dd_comm_step_info()
             self.aeam_overlapped, self.ghost_forces, self.dangerous = si["aeam_phased"], si["ghost_forces"], si["dangerous"]
+            self.overlap_policy = si["overlap_policy"]
             return
         if isinstance(rebuild, str):        # "auto": one GPU, deferred on-device flag read every step
             if self.tr is not None:
@@ -385,6 +386,19 @@ class DeviceDomain:
             ctx.md_defer_final()        # (the library completes the kick itself if velocities are read before the next step)
         else:
             ctx.md_final_integrate()
+
+    def tune_overlap(self, max_steps=80):
+        """library transport: force-only steps until the library's overlap-policy trial has chosen (comm_rccl.hip); returns
+        the step info.  Collective: every rank runs the same steps."""
+        si = self.ctx.dd_comm_step_info()
+        n = 0
+        while si["overlap_policy"].startswith("undecided") and n < max_steps:
+            self.step(0, 0, rebuild="halo", defer_final=True)
+            si = self.ctx.dd_comm_step_info()
+            n += 1
+        self.flush()
+        si["trial_steps"] = n
+        return si
 
     def thermo(self, reduce=True):
         """KE, PE, virial (summed over ranks), T and P of the whole system"""

@@ -103,6 +103,9 @@ def _compare(s, one, many):
         nlocal=[r["nlocal"] for r in many["ranks"]], nrecv=[r["nrecv"] for r in many["ranks"]],
         prunings=[r["prunings"] for r in many["ranks"]], overlapped=[r["overlapped"] for r in many["ranks"]],
         ghost_forces=[bool(r["info"]["ghost_forces"]) for r in many["ranks"]],
+        policy=[r["info"]["overlap_policy"] for r in many["ranks"]],
+        policy_fixed=[r["info"]["overlap_policy_fixed_by_env"] for r in many["ranks"]],
+        policy_trial_ms=[r["info"]["overlap_policy_trial_ms"] for r in many["ranks"]],
         interior_tiles=[r["aeam"]["interior_tiles"] if r["aeam"] else None for r in many["ranks"]],
         tiles=[r["aeam"]["tiles"] if r["aeam"] else None for r in many["ranks"]])
 
@@ -125,6 +128,19 @@ def case_steps(style, world, pure=False):
     s, v0, one = _one_rank(style, pure, steps, thermo_at)
     many = _trajectory(world, style, s, v0, steps, True, thermo_at)
     return _compare(s, one, many)
+
+
+def case_fixed_policies():
+    """every order of compute against exchanges by itself (MDP_OVERLAP_POLICY): same trajectory"""
+    out = {}
+    for style, pols in (("rebomos", ("split", "lead", "blocking", "first")), ("aeam", ("split", "lead", "blocking"))):
+        for pol in pols:
+            os.environ["MDP_OVERLAP_POLICY"] = pol
+            try:
+                out[f"{style}_{pol}"] = case_steps(style, 2)
+            finally:
+                del os.environ["MDP_OVERLAP_POLICY"]
+    return out
 
 
 def case_library():
@@ -200,6 +216,7 @@ CASES = {
     "aeam_2": lambda: case_steps("aeam", 2), "aeam_4": lambda: case_steps("aeam", 4), "aeam_8": lambda: case_steps("aeam", 8),
     "aeam_pure_2": lambda: case_steps("aeam", 2, pure=True), "aeam_pure_4": lambda: case_steps("aeam", 4, pure=True),
     "piecewise_2": case_forced_and_blocking_calls,
+    "fixed_policies": case_fixed_policies,
     "mismatch": case_mismatched_schedule,
 }
 

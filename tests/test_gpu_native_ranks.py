@@ -63,6 +63,9 @@ def test_whole_steps_on_n_ranks_follow_the_one_rank_trajectory(results, style, w
     assert r["reneighbors"] == r["builds"]                              # (the library's count includes the setup's)
     assert r["late"] == [0] * world and r["late_one"] == 0
     assert min(r["nrecv"]) > 0                                          # every rank has REMOTE ghosts
+    # the first steps were the library's overlap-policy trial (every order in turn); all ranks kept the same one
+    assert len(set(r["policy"])) == 1 and r["policy"][0] in ("split", "lead", "blocking", "first")
+    assert not any(r["policy_fixed"]) and min(r["policy_trial_ms"]) > 0.0
     if style == "aeam":
         assert all(r["ghost_forces"])                                   # 3 % angular atoms: some sit in a shell
         assert all(0 < o for o in r["overlapped"])                      # steps on the phased order ...
@@ -77,6 +80,20 @@ def test_pure_metal_bricks_skip_the_reverse_exchange_on_every_rank(results, worl
     assert not any(r["ghost_forces"])
     assert max(r["pe_rel"]) < 1e-10
     assert all(0 < o < 48 for o in r["overlapped"])                     # blocking steps among phased ones
+
+
+def test_every_overlap_policy_by_itself_gives_the_trajectory(results):
+    """MDP_OVERLAP_POLICY fixes the order of compute against exchanges (no trial): split / lead / blocking / first"""
+    r = _case(results, "fixed_policies")
+    assert len(r) == 7
+    for name, c in r.items():
+        assert c["owned_once"] and c["dx"] < 1e-8 and c["df"] < 1e-7, name
+        assert max(c["pe_rel"]) < 1e-10, name
+        assert set(c["policy"]) == {name.split("_")[1]} and all(c["policy_fixed"]), name
+        if name == "aeam_blocking":
+            assert c["overlapped"] == [0, 0]                            # no step on the phased order
+        elif name.startswith("aeam"):
+            assert min(c["overlapped"]) > 0
 
 
 def test_piecewise_transport_calls_between_two_ranks(results):
