@@ -315,6 +315,115 @@ def pmc_entry(workload, replicate, world):
         ent.get("note", "FETCH_SIZE x2 + WRITE_SIZE, path kernels of one step")
 
 
+
+# ------------------------------------------------------------------------------------------------ binding resource
+N_CU, N_XCD, N_SIMD = 256, 8, 1024
+L1_LOOKUP_CEILING = 0.9    # profiles/ubench/tcp_gather: vector-L1 lookups per clock and CU, every lane another row, all hits
+
+
+def binding_block(workload, rep, world, dominant_short):
+    """What binds the dominant kernel when it is not HBM (it is not: traffic is below the algorithmic bytes for rebomos and the
+    rate is a tenth of the roof for aeam): from the STORED counter file of the same configuration (profiles/pmc_binding.json,
+    separate rocprofv3 --pmc passes, reported only while the hash of csrc/* matches the sources it was measured on).
+      rebomos kernels: FP64 vector issue -- SQ_INSTS_VALU wave instructions x 4 cycles / (SIMDs x kernel cycles)
+      aeam pair force: vector-L1 lookups per clock and CU -- TCP_TOTAL_CACHE_ACCESSES / (kernel cycles x CUs), against the
+                       0.9 a CU sustains when every lane reads another row and everything hits (profiles/ubench/tcp_gather)
+    kernel cycles = GRBM_GUI_ACTIVE / XCDs of the same launch, so the figure does not depend on this run's clock."""
+    f = os.path.join(ROOT, "profiles", "pmc_binding.json")
+    if not os.path.exists(f):
+        return None
+    try:
+        ent = json.load(open(f)).get(f"{workload}:{'x'.join(map(str, rep))}:{world}")
+    except ValueError:
+        return None
+    if not isinstance(ent, dict) or ent.get("kernel_source_sha") != kernel_source_sha():
+        return {"resource": None, "note": "no counter entry for these kernel sources (profiles/pmc_binding.json is stale or has no such configuration)"}
+    per = {}
+    for name, c in ent.get("kernels", {}).items():
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
+        if cyc <= 0:
+            continue
+        per[name] = {"fp64_valu_issue_frac": round(c.get("SQ_INSTS_VALU", 0.0) * 4.0 / (N_SIMD * cyc), 4),
+                     "l1_lookups_per_clk_cu": round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (cyc * N_CU), 4),
+                     "lds_conflict_share_of_lds_cycles": (round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"], 3)
+                                                          if c.get("SQ_ACTIVE_INST_LDS") else None),
+                     "waves_waiting_share": (round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") else None),
+                     "kernel_cycles": int(cyc)}
+    k = per.get(dominant_short)
+    if not k:
+        return {"resource": None, "note": f"no counters for {dominant_short}", "per_kernel": per}
+    if workload == "aeam":
+        out = {"resource": "vector-L1 lookups per clock and CU (per-lane gathers of spline rows: one lookup moves at most 16 B of a lane)",
+               "achieved": k["l1_lookups_per_clk_cu"], "ceiling": L1_LOOKUP_CEILING, "unit": "lookups/clk/CU",
+               "frac": round(k["l1_lookups_per_clk_cu"] / L1_LOOKUP_CEILING, 4)}
+    else:
+        out = {"resource": "FP64 vector issue (one wave instruction per SIMD every 4 cycles)",
+               "achieved": k["fp64_valu_issue_frac"], "ceiling": 1.0, "unit": "share of issue slots",
+               "frac": k["fp64_valu_issue_frac"]}
+    out.update(kernel=dominant_short, per_kernel=per,
+               source="stored counters (profiles/pmc_binding.json, rocprofv3 --pmc passes on these kernel sources; not re-measured "
+                      "in this run): " + ent.get("note", ""))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the drop-in path
+def plugin_load_run(example, subs, timeout=900):
+    """`minilmp -in <example>` as a FRESH child process (this process holds no context any more): the reference's plugin
+    surface -- plugin load, pair_style, fix nve/mdp, run -- on the mini-host.  Returns ms per step from the host's own
+    `Loop time` line, the fix's download count and the thermo rows."""
+    pkg = os.path.join(ROOT, "lammps-plugins_amd")
+    text = open(os.path.join(pkg, "examples", example)).read()
+    for old, new in subs.items():
+        if old not in text:
+            raise RuntimeError(f"{example}: '{old}' not found")
+        text = text.replace(old, new)
+    p = subprocess.run([os.path.join(pkg, "minilmp")], input=text, capture_output=True, text=True, cwd=pkg, timeout=timeout,
+                       env=dict(os.environ, MDP_FIX_STATS="1"))
+    if p.returncode != 0:
+        raise RuntimeError(f"minilmp failed ({p.returncode}): {p.stderr[-400:]}")
+    import re
+    m = re.search(r"Loop time of ([0-9.eE+-]+) on 1 procs for (\d+) steps with (\d+) atoms", p.stdout)
+    d = re.search(r"fix nve/mdp: (\d+) downloads", p.stdout)
+    rows, on = [], False
+    for line in p.stdout.splitlines():
+        w = line.split()
+        if w[:1] == ["Step"]:
+            on = True
+        elif on and w and w[0].lstrip("-").isdigit():
+            rows.append([float(x) for x in w])
+        elif on and line.startswith("Loop time"):
+            on = False
+    nb = re.search(r"update: every = (\d+) steps, delay = (\d+) steps, check = (\w+)", p.stdout)
+    builds = re.search(r"Neighbor list builds = (\d+)", p.stdout)
+    return dict(ms_per_step=round(float(m.group(1)) / int(m.group(2)) * 1e3, 4), steps=int(m.group(2)), atoms=int(m.group(3)),
+                Matom_steps_per_s=round(int(m.group(3)) * int(m.group(2)) / float(m.group(1)) / 1e6, 2),
+                downloads=int(d.group(1)) if d else None, thermo_rows=rows,
+                neighbor_settings_in_effect=(f"every {nb.group(1)} delay {nb.group(2)} check {nb.group(3)}" if nb else None),
+                host_neighbor_list_builds=int(builds.group(1)) if builds else None,
+                check_yes_decided_on_device="check yes decided on the device" in p.stdout, input="examples/" + example)
+
+
+def resident_thermo_rows(E, steps):
+    """thermo rows (step, temp, press, pe, ke) of the headline system in a device-resident run, at the given steps"""
+    capi, resident, S = E["capi"], E["resident"], E["S"]
+    s = S.replicate(S.rebomos_bulk_cell(), tuple(DEFAULT_REPLICATE["rebomos"]))
+    ctx = capi.Context(0)
+    pot = capi.read_rebomos_file(POT_REBOMOS)
+    ctx.rebomos_set_params(pot)
+    dom = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, 3.0 * pot.rcmax[0][0] + 2.0, 2.0, [0, 0, 1])
+    dom.compute(1, 1)
+    rows, n = [], 0
+    for target in steps:
+        while n < target:
+            n += 1
+            ev = 1 if n == target else 0
+            dom.step(ev, ev, rebuild="auto", defer_final=not ev)
+        t = dom.thermo()
+        rows.append([float(n), t["temp"], t["press"], t["pe"], t["ke"]])
+    ctx.close()
+    return rows
+
+
 # ------------------------------------------------------------------------------------------------ one measured job
 def run_job(E, job, par):
     """job: workload, replicate, temp, steps, warmup, thermo_every, check_every, inner_skin
@@ -542,6 +651,10 @@ def run_job(E, job, par):
                      "algorithmic_bytes_per_pass": alg_bytes, "path_ms": round(kall, 4),
                      "phase_ms": {n: round(float(m), 4) for n, m in phases.items()},
                      "dominant_kernel": dom_k,
+                     "binding": binding_block(wl + ("_" + "_".join(sorted(dis)) if dis else ""), rep, world,
+                                              {"rebo_lj_tile_kernel": "lj_tile", "rebo_lj_gather_kernel": "lj_gather",
+                                               "aeam_tile_force_kernel": "aeam_tile_force", "aeam_ptile_kernel": "aeam_ptile",
+                                               "aeam_tile_density_kernel": "aeam_tile_density"}.get(dname.split(" ")[0], dname)),
                      "whole_step": {"achieved": round(step_achieved, 2), "frac": round(step_achieved / HBM_PEAK_GBPS, 5)},
                      "fp64": {"bound": "fp64-valu", "flop_per_atom_step": FLOP_ALG[wl],
                               "achieved": round(flops_path, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -754,6 +867,36 @@ def main():
                                            "(80 000 angular centres with their O(n^2) triplet loops), 863 K")
         except Exception as e:  # noqa: BLE001
             log(f"[bench] secondary AEAM 8 % Si run failed: {e}")
+        # ---- the drop-in path itself, in the driver's record: `plugin load` + `fix nve/mdp` on the mini-host (a fresh
+        # child process; every context of this process is closed), inputs with the REFERENCE's neighbor settings
+        # (in.rebomos-bulk:27-34: no neigh_modify line; sample.in:17-18)
+        if not args.no_host_mode:
+            try:
+                pl = plugin_load_run("in.rebomos-4m.nve-mdp.mi355x", {"thermo 50": "thermo 100", "run 100": "run 300"})
+                ref = resident_thermo_rows(E, (0, 100))
+                got = {int(r[0]): r[1:5] for r in pl["thermo_rows"]}
+                worst = 0.0
+                for r in ref:
+                    g = got.get(int(r[0]))
+                    if g is None:
+                        worst = float("inf")
+                        continue
+                    for a, b in zip(g, r[1:5]):
+                        worst = max(worst, abs(a - b) / max(abs(b), 1.0))
+                pl["thermo_rows_vs_resident_run"] = {"steps": [int(r[0]) for r in ref], "columns": "temp press pe ke",
+                                                     "max_rel_diff": worst, "equal_to_printed_digits": worst < 5e-8}
+                pl["note"] = ("BASELINE.json configs[3] on one GPU through the reference's plugin surface: minilmp, plugin load "
+                              "rebomosplugin.so, pair_style rebomos, fix nve/mdp, the reference's neighbor settings unchanged")
+                sec["plugin_load_nve_mdp"] = pl
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] plugin-load REBO-MoS run failed: {e}")
+            try:
+                pl = plugin_load_run("in.aeam-alsi.nve-mdp.mi355x", {})
+                pl["note"] = ("USER-AEAM/sample.in's system (32 000 atoms, 0.75 % Si by the mini-host's own RNG, NVE from 863 K) through "
+                              "plugin load aeamplugin.so + fix nve/mdp, neigh_modify every 1 delay 1 check yes as sample.in:18")
+                sec["plugin_load_nve_mdp_aeam"] = pl
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] plugin-load AEAM run failed: {e}")
         out["secondary"] = sec
     # the CPU baseline runs on rank 0 AFTER every timed region (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu_baseline:

@@ -282,6 +282,7 @@ class Fix : protected Pointers {
   virtual void setup(int) {}
   virtual void initial_integrate(int) {}
   virtual void final_integrate() {}
+  virtual void post_run() {}    // Modify::post_run(): behind the last step of every run
   virtual void reset_dt() {}
 };
 

@@ -616,7 +616,8 @@ struct Host {
     build_neighbor_lists();
     set_vviews();
     if (fix) fix->init(); // (LAMMPS::init: force->init() before modify->init())
-    printf("Neighbor list info ...\n  update: every = 1 steps, delay = 0 steps, check = yes\n");
+    printf("Neighbor list info ...\n  update: every = %d steps, delay = %d steps, check = %s\n", neighbor.every, neighbor.delay,
+           neighbor.dist_check ? "yes" : "no");
     printf("  max neighbors/atom: %d, page size: %d\n  master list distance cutoff = %g\n  ghost atom cutoff = %g\n",
            neighbor.oneatom, neighbor.pgsize, pair->cutforce + skin, comm_cutoff());
     printf("  pair %s, perpetual\n      attributes: full, newton on%s\n", "style", (neighbor.request_flags & NeighConst::REQ_GHOST) ? ", ghost" : "");
@@ -704,6 +705,7 @@ struct Host {
       if (out || last) print_thermo();
     }
     const double loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (fix) fix->post_run(); // (Modify::post_run, behind Verlet::run in Run::command)
     printf("Loop time of %g on 1 procs for %ld steps with %d atoms\n\n", loop, nsteps, atom.nlocal);
     if (nsteps > 0 && loop > 0) {
       const double sps = nsteps / loop;

@@ -6,6 +6,8 @@
    style's context (Pair::extract("mdp_ctx")), so that between two reneighborings nothing per atom crosses the link.
    A plugin registering a fix style is what the reference repository itself does (USER-BFIELD/bfieldplugin.cpp:15-29,
    creator.v2; virtuals USER-BFIELD/fix_bfield.h:33-38).
+
+   fix ID all nve/mdp [hostcheck yes|no]      (default no: see fix_nve_mdp.cpp)
 -------------------------------------------------------------------------------------------------- */
 #ifdef FIX_CLASS
 // clang-format off
@@ -30,12 +32,17 @@ class FixNVEMDP : public Fix {
   void init() override;
   void initial_integrate(int) override;
   void final_integrate() override;
+  void post_run() override;
   void reset_dt() override;
 
  protected:
   mdp_ctx **ctxp;      // the pair style's device context (created in its init_style)
   int *pair_linked;    // the pair style's "positions and forces stay on the device" switch
   long downloads;      // steps on which the host's x / v were brought up to date (statistics)
+  int hostcheck;       // `hostcheck yes`: Neighbor::decide() keeps looking at atom->x, which is downloaded for it
+  int took_delay;      // init() raised neighbor->delay (`check yes`: the device's check decides) ...
+  int saved_delay;     // ... from this value, which the destructor restores
+  static constexpr int kDelayTaken = 1 << 30;
 
   mdp_ctx *ctx() const { return ctxp ? *ctxp : nullptr; }
   void to_host(bool forces);

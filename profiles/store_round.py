@@ -62,3 +62,17 @@ for src, dst in ((RND + "_rebomos4m_pmc_sq_tcp_counters.json",) * 2, (RND + "_ae
     if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 10:
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 json.dump(tab, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+# SQ / TCP / GRBM counters of the path kernels -> profiles/pmc_binding.json (bench.py: roofline.binding), stamped with the
+# hash of the kernel sources of THIS tree (the collection ran on them: collect_rNN.sh counters, then this script, no edit between)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+bf = os.path.join(P, "pmc_binding.json")
+btab = json.load(open(bf)) if os.path.exists(bf) else {}
+for src, key in ((RND + "_rebomos4m_pmc_sq_tcp_counters.json", "rebomos:24x24x24:1"), (RND + "_aeam1m_pmc_sq_tcp_counters.json", "aeam:63x63x63:1")):
+    f = os.path.join(P, src)
+    if os.path.exists(f) and os.path.getsize(f) > 10:
+        btab[key] = {"kernel_source_sha": bench.kernel_source_sha(), "kernels": json.load(open(f)),
+                     "note": "median dispatch per kernel and counter over the force-only steps of `bench.py --steps 4 --warmup 1`, "
+                             "one counter group per rocprofv3 --pmc run (profiles/pmc_passes.sh, profiles/summarize_pmc.py); stored as profiles/" + src}
+        print("binding entry", key, btab[key]["kernel_source_sha"], sorted(btab[key]["kernels"]))
+json.dump(btab, open(bf, "w"), indent=1)

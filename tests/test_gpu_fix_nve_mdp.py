@@ -47,17 +47,27 @@ REBO_HOT = dict([("create_atoms 2 box basis 1 1 basis 2 1 basis 3 2 basis 4 2 ba
                  ("thermo 10", "velocity all create 1500.0 4928459\nneighbor 0.4 bin\nthermo 50"), ("run 20", "run 300")])
 
 
-@pytest.mark.parametrize("neigh", ["delay 1000000 every 1 check no", "every 1 delay 0 check yes", "every 5 delay 10 check yes"])
-def test_rebomos_hot_run_equals_the_hosts_fix_nve(neigh):
-    """2 304 atoms from 1 500 K, 300 steps, 0.4 A of skin: the host reneighbors many times.  With the decision left to the device
-    (`delay <large>`: the fix asks through force_reneighbor) and with the host looking at atom->x itself on the steps
-    neigh_modify names, the thermo rows are those of the host's own `fix nve` run to the printed digits."""
+@pytest.mark.parametrize("neigh,fixargs", [("delay 1000000 every 1 check no", ""), ("every 1 delay 0 check yes", ""),
+                                           ("every 5 delay 10 check yes", ""), ("every 1 delay 0 check yes", " hostcheck yes"),
+                                           ("every 7 delay 0 check no", "")])
+def test_rebomos_hot_run_equals_the_hosts_fix_nve(neigh, fixargs):
+    """2 304 atoms from 1 500 K, 300 steps, 0.4 A of skin: the host reneighbors many times.  Under `check yes` the device's
+    displacement check decides (the fix takes the host's own look at atom->x out of the steps and asks through
+    force_reneighbor); `hostcheck yes` keeps the host looking, with x and v downloaded for it; `check no` rebuilds by the
+    calendar and gets x and v for those steps.  The thermo rows are those of the host's own `fix nve` run to the printed digits."""
     base = _script("in.rebomos-bulk.mi355x", **REBO_HOT)
     rc0, out0, err0 = _run(base)
     assert rc0 == 0, err0
-    dev = base.replace("fix integrate all nve", f"neigh_modify {neigh}\nfix integrate all nve/mdp")
-    rc1, out1, err1 = _run(dev)
+    dev = base.replace("fix integrate all nve", f"neigh_modify {neigh}\nfix integrate all nve/mdp{fixargs}")
+    rc1, out1, err1 = _run(dev, env={"MDP_FIX_STATS": "1"})
     assert rc1 == 0, err1
+    downloads = int(re.search(r"fix nve/mdp: (\d+) downloads", out1).group(1))
+    took = "check yes decided on the device" in out1
+    assert took == ("check yes" in neigh and not fixargs)
+    if fixargs:
+        assert downloads >= 300                               # the host looked at atom->x on every step
+    elif "check yes" in neigh:
+        assert 7 <= downloads < 60                            # output steps + the reneighborings the device asked for
     r0, r1 = _thermo_rows(out0), _thermo_rows(out1)
     assert [int(r[0]) for r in r1] == [0, 50, 100, 150, 200, 250, 300]
     builds = int(re.search(r"Neighbor list builds = (\d+)", out1).group(1))
