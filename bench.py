@@ -44,6 +44,15 @@ POT_REBOMOS = os.path.join(ROOT, "tests", "golden", "potentials", "MoS.REBO.set5
 POT_AEAM = os.path.join(ROOT, "tests", "golden", "potentials", "AlSi.aeam")
 
 
+def _jsonable(o):
+    """numpy scalars / arrays that found their way into the result (a line that cannot be printed is a lost run)"""
+    if hasattr(o, "tolist"):
+        return o.tolist()
+    if hasattr(o, "item"):
+        return o.item()
+    return str(o)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -419,7 +428,7 @@ def resident_thermo_rows(E, steps):
             ev = 1 if n == target else 0
             dom.step(ev, ev, rebuild="auto", defer_final=not ev)
         t = dom.thermo()
-        rows.append([float(n), t["temp"], t["press"], t["pe"], t["ke"]])
+        rows.append([float(n), float(t["temp"]), float(t["press"]), float(t["pe"]), float(t["ke"])])
     ctx.close()
     return rows
 
@@ -884,7 +893,7 @@ def main():
                     for a, b in zip(g, r[1:5]):
                         worst = max(worst, abs(a - b) / max(abs(b), 1.0))
                 pl["thermo_rows_vs_resident_run"] = {"steps": [int(r[0]) for r in ref], "columns": "temp press pe ke",
-                                                     "max_rel_diff": worst, "equal_to_printed_digits": worst < 5e-8}
+                                                     "max_rel_diff": float(worst), "equal_to_printed_digits": bool(worst < 5e-8)}
                 pl["note"] = ("BASELINE.json configs[3] on one GPU through the reference's plugin surface: minilmp, plugin load "
                               "rebomosplugin.so, pair_style rebomos, fix nve/mdp, the reference's neighbor settings unchanged")
                 sec["plugin_load_nve_mdp"] = pl
@@ -904,7 +913,7 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.dup2(fd_out, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, default=_jsonable), flush=True)
         os.dup2(2, 1)
     if dist is not None:
         dist.barrier()

@@ -2011,6 +2011,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   __shared__ double4 s_xa[NA];
   __shared__ double s_cut[NA][2];
   __shared__ int s_lo[3], s_hi[3], s_n0[4], s_n1[4], s_over, s_rowsum;
+  __shared__ double s_bb[6], s_cmax; // bounding box of the tile's atoms (lo x y z | hi x y z), their largest list cutoff
   const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid < 3) {
     s_lo[tid] = 1 << 30;
@@ -2028,6 +2029,30 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
     s_xa[tid] = xa;
     s_cut[tid][0] = valid ? P.ljlist_cutsq[ta * 2 + 0] : -1.0;
     s_cut[tid][1] = valid ? P.ljlist_cutsq[ta * 2 + 1] : -1.0;
+    {
+      // (the NA <= 64 atom threads are the first lanes of wave 0: min / max by shuffles; absent atoms do not count)
+      static_assert(NA <= 64, "the tile's atoms are held by one wave");
+      double lo3[3] = {valid ? xa.x : 1.0e300, valid ? xa.y : 1.0e300, valid ? xa.z : 1.0e300};
+      double hi3[3] = {valid ? xa.x : -1.0e300, valid ? xa.y : -1.0e300, valid ? xa.z : -1.0e300};
+      double cm = valid ? fmax(s_cut[tid][0], s_cut[tid][1]) : -1.0;
+#pragma unroll
+      for (int o = 1; o < NA; o <<= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          lo3[d] = fmin(lo3[d], __shfl_xor(lo3[d], o, 64));
+          hi3[d] = fmax(hi3[d], __shfl_xor(hi3[d], o, 64));
+        }
+        cm = fmax(cm, __shfl_xor(cm, o, 64));
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          s_bb[d] = lo3[d];
+          s_bb[3 + d] = hi3[d];
+        }
+        s_cmax = cm;
+      }
+    }
     if (valid) {
       int cc[3];
       cc[0] = (int) ((xa.x - g.lo[0]) * g.inv[0]);
@@ -2066,8 +2091,26 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
     if (tid < nr) {
       const int r = rbase + tid;
       const int y = ylo + r % ny, z = zlo + r / ny;
-      pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
-      len = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1] - pb;
+      // The stencil is a box of cells, what can hold a neighbour is the tile's bounding box grown by the largest list
+      // cutoff -- about half of that box: a row of cells farther than the cutoff from the bounding box (in the y-z plane)
+      // is left out, and of the others only the cells along x that the remaining distance reaches.  Conservative by
+      // construction (cell and box faces, a 1e-9 A margin), so the union is what the full sweep finds.
+      const double cy0 = g.lo[1] + y / g.inv[1], cy1 = g.lo[1] + (y + 1) / g.inv[1];
+      const double cz0 = g.lo[2] + z / g.inv[2], cz1 = g.lo[2] + (z + 1) / g.inv[2];
+      // (the first and the last cell of a dimension also hold what lies beyond the grid: that face is at infinity)
+      const double dy = y < g.n[1] - 1 && s_bb[1] > cy1 ? s_bb[1] - cy1 : (y > 0 && cy0 > s_bb[4] ? cy0 - s_bb[4] : 0.0);
+      const double dz = z < g.n[2] - 1 && s_bb[2] > cz1 ? s_bb[2] - cz1 : (z > 0 && cz0 > s_bb[5] ? cz0 - s_bb[5] : 0.0);
+      const double left = s_cmax - dy * dy - dz * dz; // squared reach along x
+      if (left >= -1.0e-9) {
+        const double rx = sqrt(left > 0.0 ? left : 0.0) + 1.0e-9;
+        int x0 = (int) floor((s_bb[0] - rx - g.lo[0]) * g.inv[0]), x1 = (int) floor((s_bb[3] + rx - g.lo[0]) * g.inv[0]);
+        x0 = x0 < xlo ? xlo : x0;
+        x1 = x1 > xhi ? xhi : x1;
+        if (x0 <= x1) {
+          pb = cell_start[x0 + g.n[0] * (y + g.n[1] * z)];
+          len = cell_start[x1 + g.n[0] * (y + g.n[1] * z) + 1] - pb;
+        }
+      }
     }
     int incl = len;
 #pragma unroll
@@ -2220,8 +2263,13 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const MdpGrid g, const R
   if (tid == 0) {
     tile_nu[2 * t] = nU;
     tile_nu[2 * t + 1] = N0;
-    atomicMax(&tile_flag[1], nU);
-    atomicMax(&tile_flag[2], s_rowsum); // row entries of the whole tile (kernels that stage a tile's rows in LDS)
+    // running maxima over all tiles, two words for the whole grid: an atomic per tile on ONE address is served one after
+    // the other (about 10 ns each: a quarter of a million of them are milliseconds).  A plain look first -- the word only
+    // grows, so a stale smaller value costs at most a redundant atomic -- leaves a handful of atomics per launch.
+    // (the look goes to the L2, where the atomics land: a CU's L1 would keep the first value it saw)
+    if (nU > __hip_atomic_load(&tile_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tile_flag[1], nU);
+    if (s_rowsum > __hip_atomic_load(&tile_flag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(&tile_flag[2], s_rowsum); // row entries of the whole tile (kernels that stage a tile's rows in LDS)
   }
 }
 
@@ -2247,14 +2295,13 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const int cap, const int
     __syncthreads();
     for (int k = 2; k <= np; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < np; i += 256) {
-          const int p = i ^ j;
-          if (p > i) {
-            const unsigned long long x = s_key[i], y = s_key[p];
-            if ((x > y) == ((i & k) == 0)) {
-              s_key[i] = y;
-              s_key[p] = x;
-            }
+        // every thread takes whole compare-exchange pairs (i, i + j): q-th pair, i = q with a zero inserted at bit log2 j
+        for (int q = tid; q < (np >> 1); q += 256) {
+          const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), p = i | j;
+          const unsigned long long x = s_key[i], y = s_key[p];
+          if ((x > y) == ((i & k) == 0)) {
+            s_key[i] = y;
+            s_key[p] = x;
           }
         }
         __syncthreads();
@@ -2519,13 +2566,34 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
   int *row = (MODE == 2 && have) ? cand + off[i] : nullptr;
   int *stage = (MODE != 2 && have && cand) ? cand + (size_t) i * kCandStride : nullptr;
   const unsigned long long below = (1ull << s) - 1ull;
+  // the stencil is a box of cells around the atom's cell, what can hold a candidate is a sphere: a row of cells out of
+  // the atom's reach in the y-z plane is skipped, of the others only the cells along x that the remaining distance
+  // reaches are read (conservative: cell faces, 1e-9 A of margin; the first / last cell of a dimension also holds what
+  // lies beyond the grid, so that face is at infinity) -- a little under half of the box
+  const double reach2 = have ? fmax(P.cand_cutsq[ti * 2], P.cand_cutsq[ti * 2 + 1]) : 0.0;
+  const double wy = 1.0 / g.inv[1], wz = 1.0 / g.inv[2]; // cell widths (once: the loop below has no division)
   for (int z = wzlo; z <= wzhi; z++)
     for (int y = wylo; y <= wyhi; y++) {
-      const bool rowin = have && z >= zlo && z <= zhi && y >= ylo && y <= yhi;
+      bool rowin = have && z >= zlo && z <= zhi && y >= ylo && y <= yhi;
       int pb = 0, pe = 0;
       if (rowin) {
-        pb = cell_start[xlo + g.n[0] * (y + g.n[1] * z)];
-        pe = cell_start[xhi + g.n[0] * (y + g.n[1] * z) + 1];
+        const double cy0 = g.lo[1] + y * wy, cy1 = cy0 + wy;
+        const double cz0 = g.lo[2] + z * wz, cz1 = cz0 + wz;
+        const double dy = y < g.n[1] - 1 && xi.y > cy1 ? xi.y - cy1 : (y > 0 && cy0 > xi.y ? cy0 - xi.y : 0.0);
+        const double dz = z < g.n[2] - 1 && xi.z > cz1 ? xi.z - cz1 : (z > 0 && cz0 > xi.z ? cz0 - xi.z : 0.0);
+        const double left = reach2 - dy * dy - dz * dz;
+        rowin = left >= -1.0e-6;
+        if (rowin) {
+          // (single precision is plenty for a reach that is rounded outward: 1e-5 relative, 1e-4 A absolute)
+          const double rx = (double) (sqrtf(left > 0.0 ? (float) left : 0.0f) * 1.00001f + 1.0e-4f);
+          int x0 = (int) floor((xi.x - rx - g.lo[0]) * g.inv[0]), x1 = (int) floor((xi.x + rx - g.lo[0]) * g.inv[0]);
+          x0 = x0 < xlo ? xlo : x0;
+          x1 = x1 > xhi ? xhi : x1;
+          if (x0 <= x1) {
+            pb = cell_start[x0 + g.n[0] * (y + g.n[1] * z)];
+            pe = cell_start[x1 + g.n[0] * (y + g.n[1] * z) + 1];
+          }
+        }
       }
       const int lenw = wave_max_int(pe - pb);
       for (int base = 0; base < lenw; base += RP_L) {
@@ -2771,8 +2839,8 @@ __global__ __launch_bounds__(256) void tile_scan_csr_kernel(const RebomosDev P, 
   if (tid == 0) {
     tile_nu[2 * t] = nU;
     tile_nu[2 * t + 1] = N0;
-    atomicMax(&tile_flag[1], nU);
-    atomicMax(&tile_flag[2], s_rowsum);
+    if (nU > __hip_atomic_load(&tile_flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tile_flag[1], nU);
+    if (s_rowsum > __hip_atomic_load(&tile_flag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tile_flag[2], s_rowsum);
   }
 }
 
@@ -2916,14 +2984,29 @@ __global__ __launch_bounds__(256) void classify_kernel(const RebomosDev P, const
     k = 2 * k + (ti != 0); // classes are per (lane-group size, element): the element is then uniform per launch
     if (bnd) k += MDP_NCLASS_HALF;
   }
+  // one atomic per class and BLOCK (a wave's share found by a prefix over the block's waves in LDS): the class counters
+  // are twenty addresses, and an atomic per wave on the two or three busy ones was 75 000 atomics per address at
+  // 4.6 M atoms, served one after the other
+  __shared__ int s_cnt[4][MDP_NCLASS], s_base[MDP_NCLASS];
+  const int wave = threadIdx.x >> 6;
+  unsigned long long mine = 0ull;
 #pragma unroll
   for (int kk = 0; kk < MDP_NCLASS; kk++) {
     const unsigned long long m = __ballot(k == kk);
-    if (m == 0ull) continue;
-    int base = 0;
-    if (lane == __ffsll((long long) m) - 1) base = atomicAdd(&class_count[kk], __popcll(m));
-    base = __shfl(base, __ffsll((long long) m) - 1, 64);
-    if (k == kk) class_list[(size_t) kk * nall + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    if (lane == 0) s_cnt[wave][kk] = __popcll(m);
+    if (k == kk) mine = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < MDP_NCLASS) {
+    const int kk = threadIdx.x;
+    const int total = s_cnt[0][kk] + s_cnt[1][kk] + s_cnt[2][kk] + s_cnt[3][kk];
+    s_base[kk] = total ? atomicAdd(&class_count[kk], total) : 0;
+  }
+  __syncthreads();
+  if (k >= 0) {
+    int base = s_base[k];
+    for (int w = 0; w < wave; w++) base += s_cnt[w][k];
+    class_list[(size_t) k * nall + base + __popcll(mine & ((1ull << lane) - 1ull))] = i;
   }
 }
 
