@@ -2568,25 +2568,29 @@ __global__ __launch_bounds__(256) void cand_build_kernel(const MdpGrid g, const 
   const unsigned long long below = (1ull << s) - 1ull;
   // the stencil is a box of cells around the atom's cell, what can hold a candidate is a sphere: a row of cells out of
   // the atom's reach in the y-z plane is skipped, of the others only the cells along x that the remaining distance
-  // reaches are read (conservative: cell faces, 1e-9 A of margin; the first / last cell of a dimension also holds what
-  // lies beyond the grid, so that face is at infinity) -- a little under half of the box
-  const double reach2 = have ? fmax(P.cand_cutsq[ti * 2], P.cand_cutsq[ti * 2 + 1]) : 0.0;
-  const double wy = 1.0 / g.inv[1], wz = 1.0 / g.inv[2]; // cell widths (once: the loop below has no division)
+  // reaches are read (conservative: the first / last cell of a dimension also holds what lies beyond the grid, so that
+  // face is at infinity) -- a little under half of the box.  All of it in single precision, in units of cells, rounded
+  // outward by 1e-3 of a cell (float resolves 6e-5 cells at the 1024 cells a dimension has at most): a few instructions per row.
+  const float reach = have ? (float) sqrt(fmax(P.cand_cutsq[ti * 2], P.cand_cutsq[ti * 2 + 1])) * 1.00001f : 0.0f;
+  const float ivx = (float) g.inv[0], ivy = (float) g.inv[1], ivz = (float) g.inv[2];
+  const float fx = (float) ((xi.x - g.lo[0]) * g.inv[0]), fy = (float) ((xi.y - g.lo[1]) * g.inv[1]),
+              fz = (float) ((xi.z - g.lo[2]) * g.inv[2]); // the atom in cell coordinates
+  const float iry = 1.0f / (reach * ivy + 1.0e-3f), irz = 1.0f / (reach * ivz + 1.0e-3f); // 1 / reach in cells
   for (int z = wzlo; z <= wzhi; z++)
     for (int y = wylo; y <= wyhi; y++) {
       bool rowin = have && z >= zlo && z <= zhi && y >= ylo && y <= yhi;
       int pb = 0, pe = 0;
       if (rowin) {
-        const double cy0 = g.lo[1] + y * wy, cy1 = cy0 + wy;
-        const double cz0 = g.lo[2] + z * wz, cz1 = cz0 + wz;
-        const double dy = y < g.n[1] - 1 && xi.y > cy1 ? xi.y - cy1 : (y > 0 && cy0 > xi.y ? cy0 - xi.y : 0.0);
-        const double dz = z < g.n[2] - 1 && xi.z > cz1 ? xi.z - cz1 : (z > 0 && cz0 > xi.z ? cz0 - xi.z : 0.0);
-        const double left = reach2 - dy * dy - dz * dz;
-        rowin = left >= -1.0e-6;
+        // distance of the atom from the row's cells in y and z, in cells (0 inside the row; the first / last cell of a
+        // dimension reaches to infinity on its outer side), as fractions of the reach
+        const float dy = y < g.n[1] - 1 && fy > (float) (y + 1) ? fy - (float) (y + 1) : (y > 0 && fy < (float) y ? (float) y - fy : 0.0f);
+        const float dz = z < g.n[2] - 1 && fz > (float) (z + 1) ? fz - (float) (z + 1) : (z > 0 && fz < (float) z ? (float) z - fz : 0.0f);
+        const float qy = dy * iry, qz = dz * irz;
+        const float left = 1.0f - qy * qy - qz * qz;
+        rowin = left >= -1.0e-5f;
         if (rowin) {
-          // (single precision is plenty for a reach that is rounded outward: 1e-5 relative, 1e-4 A absolute)
-          const double rx = (double) (sqrtf(left > 0.0 ? (float) left : 0.0f) * 1.00001f + 1.0e-4f);
-          int x0 = (int) floor((xi.x - rx - g.lo[0]) * g.inv[0]), x1 = (int) floor((xi.x + rx - g.lo[0]) * g.inv[0]);
+          const float rxc = (reach * ivx) * sqrtf(left > 0.0f ? left : 0.0f) + 2.0e-3f; // reach along x in cells
+          int x0 = (int) floorf(fx - rxc), x1 = (int) floorf(fx + rxc);
           x0 = x0 < xlo ? xlo : x0;
           x1 = x1 > xhi ? xhi : x1;
           if (x0 <= x1) {
