@@ -240,7 +240,7 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
       if (f0) SC.flags[4] |= f0;
       SC.flags[0] = 0;
       if (SC.ovf)
-        for (int k = 0; k < 6; k++) SC.ovf[(size_t) k * SC.ovf_stride] = 0;
+        for (int k = 0; k < MDP_NOVF_LISTS; k++) SC.ovf[(size_t) k * SC.ovf_stride] = 0;
     } else if (i < 4)
       SC.flags[i] = 0;
   }

@@ -312,7 +312,7 @@ __global__ void acc_zero_kernel(double *__restrict__ acc, const int n, int *__re
     if (f0) flags[4] |= f0;
     flags[0] = 0;
     if (ovf)
-      for (int k = 0; k < 6; k++) ovf[(size_t) k * ovf_stride] = 0;
+      for (int k = 0; k < MDP_NOVF_LISTS; k++) ovf[(size_t) k * ovf_stride] = 0;
   } else if (i < 4)
     flags[i] = 0;
 }

@@ -22,6 +22,9 @@
 #define MDP_ACC_STRIDE 16
 // REBO centre classes: lane-group size (4, 8, 12, 16, 32) x element, x {interior, boundary}: classes 10..19 hold the
 // centres whose candidate set reaches a REMOTE ghost (multi-GPU runs); the interior ones run while the halo is in flight
+#define MDP_NOVF_LISTS 7 // {count, ids ...} lists in mdp_ctx::ovf, counts zeroed with the accumulators of every compute: [0] centres for the
+                         // general kernel, [1..4] the lane-per-centre kernel's overflow per (part, element), [5] tiles with a pair on
+                         // the cubic Lennard-Jones spline, [6] those of them whose pair queues overflowed (rows walked after all)
 #define MDP_NCLASS 20
 #define MDP_NCLASS_HALF 10
 
@@ -374,6 +377,11 @@ struct mdp_ctx {
   bool aeam_img_fp = false;       // the embedding kernel of this compute filled fp of the periodic self-images too
   DevBuf<int> lj_fix_stamp;       // [ntile] stamp of the compute that last listed the tile for rebo_lj_cubic_kernel
   int lj_stamp = 0;
+  // hot systems: the flagged pairs of the Lennard-Jones tile kernel in per-group queues (rebo_lj_tile_kernel<.., QUEUE>)
+  DevBuf<unsigned short> lj_cq;   // [ntile][16 groups][2 atoms][lj_cq_cap] items
+  DevBuf<int> lj_cq_cnt;          // [ntile][16][2] entries (zero between computes)
+  int lj_cq_cap = 0, lj_cq_tiles = 0;
+  bool lj_queue_now = false;      // this compute's tile launches took the QUEUE variant
   DevBuf<double> lj_fixtab;       // [4][12] lo hi sw lj1 lj2 lj3 lj4 rcLJmin c2 c3 - - per pair type (cubic inner spline, rare path)
   DevBuf<int> cand_stage;         // [nall][64] candidate rows at a fixed stride, written by the counting sweep of a list build
   DevBuf<int> class_list;         // [MDP_NCLASS][nall]   class = 2 * (lane-group size index) + element

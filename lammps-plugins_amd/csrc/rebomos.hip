@@ -1170,16 +1170,17 @@ __device__ __forceinline__ void lj_store(const bool have, const int kc, const in
 // 12-6 branch only, straight-line: pairs inside the cubic inner spline (rcLJmin <= r < 0.95 sigma; none in
 // an equilibrium crystal) are evaluated as 12-6 here and flagged; rebo_lj_cubic_kernel then replaces them.
 template <bool EV>
-__device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, const double4 &xj, double &fx,
-                                             double &fy, double &fz, double &e, const int vflag, double &v0,
-                                             double &v1, double &v2, double &v3, double &v4, double &v5,
-                                             unsigned long long &cub)
+__device__ __forceinline__ unsigned long long lj_pair_fast(const LJPar &q, const double4 &xa, const double4 &xj, double &fx,
+                                                           double &fy, double &fz, double &e, const int vflag, double &v0,
+                                                           double &v1, double &v2, double &v3, double &v4, double &v5,
+                                                           unsigned long long &cub)
 {
   const double dx = xa.x - xj.x, dy = xa.y - xj.y, dz = xa.z - xj.z;
   const double rsq = dx * dx + dy * dy + dz * dz;
   const bool inwin = rsq >= q.lo && rsq <= q.hi;
   // wave-uniform flag kept in scalar registers: the compare masks are ANDed/ORed by the scalar unit
-  cub |= __builtin_amdgcn_fcmp(rsq, q.lo, 3 /*oge*/) & __builtin_amdgcn_fcmp(rsq, q.sw, 4 /*olt*/);
+  const unsigned long long mcub = __builtin_amdgcn_fcmp(rsq, q.lo, 3 /*oge*/) & __builtin_amdgcn_fcmp(rsq, q.sw, 4 /*olt*/);
+  cub |= mcub;
   // 1/rsq: hardware seed (24 bits, measured) + ONE Newton step = 2e-15 relative.  Evaluated for every
   // entry: rsq = 0 (the atom itself) gives inf/NaN, rsq = 1e60 (dummy entry) gives 0 -- both are discarded
   // by the select below, which never propagates its unselected operand.
@@ -1204,6 +1205,7 @@ __device__ __forceinline__ void lj_pair_fast(const LJPar &q, const double4 &xa, 
       v5 += dy * dz * h;
     }
   }
+  return mcub; // the lanes of THIS call whose pair sits on the cubic inner spline (a wave-level value)
 }
 
 // tail of both Lennard-Jones kernels: REBO slot-force gather, group reductions, stores, global tallies
@@ -1530,7 +1532,111 @@ __global__ __launch_bounds__(256) void rebo_lj_cubic_kernel(
   }
 }
 
-template <bool EV, bool GATHER, int WAVES, int CL>
+// The follow-up of the QUEUE variant of rebo_lj_tile_kernel: per listed tile every 16-lane group works off the two
+// queues it wrote -- items (index into the union | segment << 12) of the (entry, atom) pairs on the cubic inner spline --
+// with all its lanes: position of the neighbour through the union's member list, (cubic - 12-6) exactly as
+// rebo_lj_cubic_kernel's flush computes it, group reduction, read-modify-write of f.  No union is staged and no row is
+// walked.  The counts are zeroed again here (they are written only when non-zero); a tile one of whose queues overflowed
+// goes to `walk_list` and is taken by rebo_lj_cubic_kernel behind this launch.
+template <int CL, bool EV>
+__global__ __launch_bounds__(256) void rebo_lj_cubicq_kernel(
+    const double *__restrict__ fixtab, const int *__restrict__ fix_list, int *__restrict__ walk_list, const int nlocal,
+    const int nclus, const double4 *__restrict__ xq, const int cap, const int *__restrict__ tu,
+    const unsigned short *__restrict__ cq, int *__restrict__ cq_cnt, const int cq_cap, double *__restrict__ f,
+    double *__restrict__ eatom, double *__restrict__ acc, const int eflag, const int vflag,
+    int *__restrict__ h_count /* pinned: the host sizes later grids and picks the variant from it */)
+{
+  constexpr int L = 16;
+  const int tid = threadIdx.x, lane = tid & 63, s = lane % L;
+  const int nfix = fix_list[0];
+  if (blockIdx.x == 0 && tid == 0) *h_count = nfix;
+  for (int e = blockIdx.x; e < nfix; e += gridDim.x) {
+    const int t = fix_list[1 + e];
+    const int kc = t * MDP_TILE + tid / L;
+    const bool have = kc < nclus;
+    const int *__restrict__ mem = tu + (size_t) t * cap;
+    int *__restrict__ cnt = cq_cnt + ((size_t) t * MDP_TILE + tid / L) * CL;
+    int nq[CL];
+    bool over = false;
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      nq[c] = cnt[c];
+      over = over || nq[c] > cq_cap;
+    }
+    over = __syncthreads_or(over) != 0;
+    if (s == 0) {
+#pragma unroll
+      for (int c = 0; c < CL; c++)
+        if (nq[c]) cnt[c] = 0;
+    }
+    if (over) { // (block-uniform)
+      if (tid == 0) walk_list[1 + atomicAdd(&walk_list[0], 1)] = t;
+      continue;
+    }
+    double4 xa[CL];
+    int ta[CL];
+    double fx[CL], fy[CL], fz[CL], ee[CL];
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      xa[c] = xq[have && kc * CL + c < nlocal ? kc * CL + c : 0];
+      ta[c] = (int) xa[c].w;
+      ta[c] = ta[c] < 0 ? 0 : ta[c];
+      fx[c] = fy[c] = fz[c] = ee[c] = 0.0;
+    }
+    const unsigned short *__restrict__ q0 = cq + ((size_t) t * MDP_TILE + tid / L) * CL * cq_cap;
+#pragma unroll
+    for (int c = 0; c < CL; c++) {
+      for (int i = s; i < nq[c]; i += L) {
+        const int it = (int) q0[c * cq_cap + i];
+        const int li = it & 0xFFF, seg = (it >> 12) & 1;
+        const double4 xj = xq[mem[li]];
+        const double *__restrict__ q = fixtab + 12 * (ta[c] * 2 + seg);
+        const double dx = xa[c].x - xj.x, dy = xa[c].y - xj.y, dz = xa[c].z - xj.z;
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        // (1/rsq exactly as lj_pair_fast computed it, so that the 12-6 value subtracted here is the one added there)
+        double r2inv = __builtin_amdgcn_rcp(rsq);
+        r2inv = fma(r2inv, fma(-rsq, r2inv, 1.0), r2inv);
+        const double r6inv = r2inv * r2inv * r2inv;
+        const double f12 = r6inv * (q[3] * r6inv - q[4]) * r2inv;
+        const double rij = sqrt(rsq);
+        const double drp = rij - q[7];
+        const double fc = -drp * (3.0 * drp * q[9] + 2.0 * q[8]) / rij;
+        const double df = fc - f12;
+        fx[c] += dx * df;
+        fy[c] += dy * df;
+        fz[c] += dz * df;
+        if (EV) {
+          const double v12 = r6inv * (q[5] * r6inv - q[6]);
+          const double V = drp * drp * (drp * q[9] + q[8]);
+          ee[c] += 0.5 * (V - v12);
+          if (vflag) {
+            const double h = 0.5 * df;
+            v0 += dx * dx * h;
+            v1 += dy * dy * h;
+            v2 += dz * dz * h;
+            v3 += dx * dy * h;
+            v4 += dx * dz * h;
+            v5 += dy * dz * h;
+          }
+        }
+      }
+    }
+    double e_fix = 0.0;
+#pragma unroll
+    for (int c = 0; c < CL; c++) e_fix += ee[c];
+    lj_store<CL, L>(have, kc, s, lane, nlocal, e_fix, fx, fy, fz, ee, v0, v1, v2, v3, v4, v5, f, eatom, acc, eflag, vflag,
+                    /*accumulate=*/1);
+  }
+}
+
+// QUEUE (a hot system: most tiles were listed in the compute before): the flagged (entry, atom) pairs are not left for
+// a second walk of the rows -- every 16-lane group appends them, as 16-bit items (index into the union | segment << 12),
+// to its own two queues in device memory (one per atom of the cluster: cq[((tile * 16 + group) * 2 + atom) * cq_cap ...],
+// counts in cq_cnt, written only when non-zero and zeroed again by their reader), and rebo_lj_cubicq_kernel adds the
+// corrections from the queues alone.  The appends sit behind a wave-uniform branch on the compare mask.  The variant
+// without QUEUE is the kernel as it was: a crystal never runs this one (launch_lj decides from the last list's length).
+template <bool EV, bool GATHER, int WAVES, int CL, bool QUEUE = false>
 __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const RebomosDev P, const int nlocal, const int *__restrict__ order, const int first, const int nclus,
     const double4 *__restrict__ xq, const int cap, const int capL, const int skip_above,
@@ -1541,7 +1647,7 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
     const double *__restrict__ fnbr, const double *__restrict__ fown, double *__restrict__ f,
     double *__restrict__ eatom, double *__restrict__ acc,
     const int eflag, const int vflag, const int accumulate, int *__restrict__ fix_list, int *__restrict__ fix_stamp,
-    const int stamp)
+    const int stamp, unsigned short *__restrict__ cq = nullptr, int *__restrict__ cq_cnt = nullptr, const int cq_cap = 0)
 {
   constexpr int L = 16; // lanes per row; CL atoms per row (1: every atom walks its own neighbourhood, nothing of a partner's)
   constexpr int U = 1; // row entries per lane and iteration (segments are padded to L entries, so U * L must be L)
@@ -1682,6 +1788,18 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   // are unconditional (address clamped, validity re-derived at use), so the only wait inside the loop is
   // for the load issued a full trip earlier.
   unsigned long long cub = 0;
+  // QUEUE: this group's two queues (entries so far: the same number in its 16 lanes)
+  int qn[CL];
+#pragma unroll
+  for (int c = 0; c < CL; c++) qn[c] = 0;
+  const int glane0 = lane - s;
+  unsigned short *__restrict__ cqg = QUEUE ? cq + ((size_t) t * MDP_TILE + tid / L) * CL * cq_cap : nullptr;
+  auto push = [&](const int c, const unsigned long long m, const int li, const int seg) {
+    const unsigned mg = (unsigned) (m >> glane0) & 0xFFFFu; // the group's 16 bits of the wave's compare mask
+    const int at = qn[c] + __popc(mg & ((1u << s) - 1u));
+    if (((mg >> s) & 1u) && at < cq_cap) cqg[c * cq_cap + at] = (unsigned short) (li | (seg << 12));
+    qn[c] += __popc(mg);
+  };
   auto segment = [&](auto segc) {
     constexpr int SEG = decltype(segc)::value;
     const int kb = SEG ? split : 0, ke = SEG ? cnt : split;
@@ -1689,12 +1807,15 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
 #pragma unroll
     for (int c = 0; c < CL; c++) q[c] = lj_select(P, ta[c], SEG);
     int je[U], jo[U];
+    int ie[U], io[U]; // QUEUE: the entries xe / xo were read for (their index registers are re-requested at once)
     double4 xe[U], xo[U];
     const unsigned short *__restrict__ rp = row + kb + s; // this lane's column of the segment
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const double *p = s_pos + 3 * jh[SEG][u]; // iteration 0
       xe[u] = make_double4(p[0], p[1], p[2], 0.0);
+      ie[u] = jh[SEG][u];
+      io[u] = 0;
       jo[u] = jh[SEG][U + u];     // iteration 1
       je[u] = jh[SEG][2 * U + u]; // iteration 2
     }
@@ -1704,19 +1825,24 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
       for (int u = 0; u < U; u++) {
         const double *p = s_pos + 3 * jo[u];
         xo[u] = make_double4(p[0], p[1], p[2], 0.0);
+        if (QUEUE) io[u] = jo[u];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) jo[u] = (int) rp[3 * U * L + u * L];
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int c = 0; c < CL; c++)
-          lj_pair_fast<EV>(q[c], xa[c], xe[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+        for (int c = 0; c < CL; c++) {
+          const unsigned long long m =
+              lj_pair_fast<EV>(q[c], xa[c], xe[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+          if (QUEUE && m) push(c, m, ie[u], SEG);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const double *p = s_pos + 3 * je[u];
         xe[u] = make_double4(p[0], p[1], p[2], 0.0);
+        if (QUEUE) ie[u] = je[u];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) je[u] = (int) rp[4 * U * L + u * L];
@@ -1725,8 +1851,11 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
 #pragma unroll
         for (int u = 0; u < U; u++) {
 #pragma unroll
-          for (int c = 0; c < CL; c++)
-            lj_pair_fast<EV>(q[c], xa[c], xo[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+          for (int c = 0; c < CL; c++) {
+            const unsigned long long m =
+                lj_pair_fast<EV>(q[c], xa[c], xo[u], fx[c], fy[c], fz[c], ee[c], vflag, v0, v1, v2, v3, v4, v5, cub);
+            if (QUEUE && m) push(c, m, io[u], SEG);
+          }
         }
       }
     }
@@ -1738,6 +1867,11 @@ __global__ __launch_bounds__(256, WAVES) void rebo_lj_tile_kernel(
   // follows this launch and adds the corrections (the first flagged wave of a tile appends it; `stamp` changes with
   // every compute, so the per-tile words need no reset).  Nothing of that path costs this kernel a register.
   if (cub && lane == 0 && atomicExch(&fix_stamp[t], stamp) != stamp) fix_list[1 + atomicAdd(&fix_list[0], 1)] = t;
+  if (QUEUE && s == 0) { // (a count beyond the capacity tells the reader that this tile needs the walk of the rows)
+#pragma unroll
+    for (int c = 0; c < CL; c++)
+      if (qn[c]) cq_cnt[((size_t) t * MDP_TILE + tid / L) * CL + c] = qn[c];
+  }
 
   double e_lj = 0.0;
 #pragma unroll
@@ -3223,7 +3357,7 @@ int mdp_rebomos_repack(mdp_ctx *c)
   MDP_HIP(c, c->is_center.reserve(nall + 1));
   MDP_HIP(c, c->amask.reserve(nall + 1));
   // overflow lists: [0] the general kernel's, [1..4] the lane-per-centre kernel's per (part, element); each {count, ids...}
-  MDP_HIP(c, c->ovf.reserve((size_t) 6 * (nall + 2))); // (five overflow lists of centres + the list of tiles with a pair on the cubic LJ spline)
+  MDP_HIP(c, c->ovf.reserve((size_t) MDP_NOVF_LISTS * (nall + 2))); // (mdp_common.h: five lists of centres, two of tiles)
   c->ovf_stride = nall + 2;
   c->acc_prezeroed = false; // (the counters sit at new places: the next mdp_acc_begin zeroes them itself)
   // multi-GPU runs hide the halo exchange behind the REBO centres that reach no remote ghost.  (Round 1 split the
@@ -3801,6 +3935,39 @@ int mdp_prune_upkeep(mdp_ctx *c, const double cut[4], const double skin, const b
 
 // force_clear (optional) + compute on the device; results stay on the device (f, eatom, acc)
 // one launch class of the Lennard-Jones units (see unit_class_kernel): 0 small unions, 1 large unions (2, 3: unused)
+// Which variant of the tile kernel this compute takes (once per compute: the first class launch decides, the follow-up
+// kernels read lj_queue_now).  Hot means: the compute before listed more than an eighth of the tiles for the cubic
+// follow-up (its count, published to a pinned word by that follow-up, read without a wait) -- then walking every listed
+// tile's rows a second time costs more than the tile kernel itself (a 3 300 K melt: 1.97 against 1.55 ms) and the pairs
+// are queued where they are found instead.  A crystal lists nothing and keeps the kernel without the queue code.
+// MDP_LJ_QUEUE = 0 / 1 forces the variant (tests, A/B).
+static bool lj_queue_mode(mdp_ctx *c)
+{
+  const char *fe = getenv("MDP_LJ_QUEUE"); // (read per compute: the tests switch it within one process)
+  const int forced = fe ? (atoi(fe) != 0 ? 1 : 0) : -1;
+  bool on = false;
+  if (c->lj_tiled && c->cluster == 2 && c->ntile > 0 && forced != 0) {
+    const int listed = *(const int *) (c->h_pinned + 45);
+    on = forced == 1 || (long long) listed * 8 > c->ntile;
+  }
+  const char *ce0 = getenv("MDP_LJ_QUEUE_CAP");
+  const bool recap = ce0 && c->lj_cq_cap && atoi(ce0) >= 1 && atoi(ce0) <= 4096 && atoi(ce0) != c->lj_cq_cap;
+  if (on && (c->lj_cq_tiles != c->ntile || !c->lj_cq.p || recap)) { // (first hot compute after a list build with another tile count)
+    int kCap = 64; // items per queue: ten times what a 3 300 K melt of MoS2 puts into one (6.8 on average)
+    if (const char *ce = getenv("MDP_LJ_QUEUE_CAP")) kCap = atoi(ce) >= 1 && atoi(ce) <= 4096 ? atoi(ce) : kCap; // (tests: overflow)
+    if (c->lj_cq.reserve((size_t) c->ntile * MDP_TILE * 2 * kCap + 8) != hipSuccess ||
+        c->lj_cq_cnt.reserve((size_t) c->ntile * MDP_TILE * 2 + 8) != hipSuccess ||
+        hipMemsetAsync(c->lj_cq_cnt.p, 0, sizeof(int) * ((size_t) c->ntile * MDP_TILE * 2 + 8), c->stream) != hipSuccess)
+      on = false; // (no memory for the queues: the walk serves)
+    else {
+      c->lj_cq_cap = kCap;
+      c->lj_cq_tiles = c->ntile;
+    }
+  }
+  c->lj_queue_now = on;
+  return on;
+}
+
 static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, bool accumulate)
 {
   int first = c->lj_class_base[klass], count = c->lj_class_base[klass + 1] - first;
@@ -3817,26 +3984,29 @@ static int launch_lj(mdp_ctx *c, int klass, bool gather, int eflag, int vflag, b
   const bool ev = eflag || vflag; // force-only steps take the variant without energy/virial arithmetic
   if (c->lj_tiled) {
     const bool pruned = c->prune_valid; // rows pruned to the pairs that can be inside a window right now
+    const bool queue = c->lj_queue_now; // (decided once per compute: mdp_rebomos_run_end)
     const bool small = !(klass & 1);
     const int capL = ((small ? c->tile_small : c->tile_maxu) + 1 + 7) & ~7;
     const size_t lds = (size_t) capL * 3 * sizeof(double);
-#define MDP_LJT_(EVV, GV, WV, CLV)                                                                                  \
+#define MDP_LJT_(EVV, GV, WV, CLV, QV)                                                                              \
   do {                                                                                                              \
     if (lds > 48 * 1024)                                                                                            \
-      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile_kernel<EVV, GV, WV, CLV>,                          \
+      MDP_HIP(c, hipFuncSetAttribute((const void *) rebo_lj_tile_kernel<EVV, GV, WV, CLV, QV>,                      \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));                       \
-    rebo_lj_tile_kernel<EVV, GV, WV, CLV><<<count, 256, lds, st>>>(                                                 \
+    rebo_lj_tile_kernel<EVV, GV, WV, CLV, QV><<<count, 256, lds, st>>>(                                             \
         c->rebomos, c->nlocal, order, first, c->nclus, c->xq.p, c->tile_cap, capL, skip_above, c->tu.p,            \
         c->tile_nu.p, c->lj_off.p, pruned ? c->lj_len_in.p : nullptr, pruned ? c->lj_split_in.p : c->lj_split.p,    \
         pruned ? c->lj16_in.p : c->lj16.p, c->cand_off.p, c->amask.p, c->rev.p, c->rev16.p,                         \
         c->fnbr.p,                                                                                                  \
         c->fown.p, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, accumulate ? 1 : 0,                                 \
-        c->ovf.p + (size_t) 5 * c->ovf_stride, c->lj_fix_stamp.p, c->lj_stamp);                                     \
+        c->ovf.p + (size_t) 5 * c->ovf_stride, c->lj_fix_stamp.p, c->lj_stamp, c->lj_cq.p, c->lj_cq_cnt.p,          \
+        c->lj_cq_cap);                                                                                              \
   } while (0)
 #define MDP_LJT(EVV, GV, WV)                                                                                        \
   do {                                                                                                              \
-    if (c->cluster == 1) MDP_LJT_(EVV, GV, WV, 1);                                                                  \
-    else MDP_LJT_(EVV, GV, WV, 2);                                                                                  \
+    if (c->cluster == 1) MDP_LJT_(EVV, GV, WV, 1, false);                                                           \
+    else if (queue) MDP_LJT_(EVV, GV, WV, 2, true);                                                                 \
+    else MDP_LJT_(EVV, GV, WV, 2, false);                                                                           \
   } while (0)
     // the force-only variants fit 5 waves per SIMD (<= 102 VGPRs); with small unions LDS allows 5 workgroups too
     if (ev && gather) MDP_LJT(true, true, 4);
@@ -3874,14 +4044,33 @@ static int launch_lj_cubic(mdp_ctx *c, int eflag, int vflag)
 {
   if (!c->lj_tiled || c->ntile <= 0) return MDP_OK;
   const bool pruned = c->prune_valid;
+  const bool queue = c->lj_queue_now;
+  if (queue) { // the queues the tile launches of this compute filled; tiles whose queues overflowed go on to the walk below
+    int *h_count = (int *) (c->h_pinned + 45);
+    long long want = (long long) *h_count + *h_count / 4 + 256;
+    const int grid = (int) (want < c->ntile ? want : c->ntile);
+    const bool ev = eflag || vflag;
+    const int *fix_list = c->ovf.p + (size_t) 5 * c->ovf_stride;
+    int *walk_list = c->ovf.p + (size_t) 6 * c->ovf_stride;
+    if (ev)
+      rebo_lj_cubicq_kernel<2, true><<<grid, 256, 0, c->stream>>>(c->lj_fixtab.p, fix_list, walk_list, c->nlocal, c->nclus,
+                                                                  c->xq.p, c->tile_cap, c->tu.p, c->lj_cq.p, c->lj_cq_cnt.p,
+                                                                  c->lj_cq_cap, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, h_count);
+    else
+      rebo_lj_cubicq_kernel<2, false><<<grid, 256, 0, c->stream>>>(c->lj_fixtab.p, fix_list, walk_list, c->nlocal, c->nclus,
+                                                                   c->xq.p, c->tile_cap, c->tu.p, c->lj_cq.p, c->lj_cq_cnt.p,
+                                                                   c->lj_cq_cap, c->f.p, c->eatom.p, c->acc.p, eflag, vflag, h_count);
+    MDP_HIP(c, hipGetLastError());
+  }
   const int capL = (c->tile_maxu + 1 + 7) & ~7;
   const size_t lds = (size_t) capL * 3 * sizeof(double);
   // a workgroup per listed tile, from the count an earlier compute published (any grid covers the list: the kernel
   // strides over it; a crystal lists nothing and gets 256 workgroups that leave at once)
-  int *h_count = (int *) (c->h_pinned + 45);
+  // (queue mode: this walk only serves the tiles the queue kernel passed on -- normally none; its count has its own word)
+  int *h_count = (int *) (c->h_pinned + (queue ? 47 : 45));
   long long want = (long long) *h_count + *h_count / 4 + 256;
   const int grid = (int) (want < c->ntile ? want : c->ntile);
-  const int *fix_list = c->ovf.p + (size_t) 5 * c->ovf_stride;
+  const int *fix_list = c->ovf.p + (size_t) (queue ? 6 : 5) * c->ovf_stride;
 #define MDP_LJC(CLV, EVV)                                                                                            \
   do {                                                                                                                \
     if (lds > 48 * 1024)                                                                                              \
@@ -4005,6 +4194,7 @@ int mdp_rebomos_run_end(mdp_ctx *c, int eflag, int vflag)
     MDP_TRY(launch_centres(c, eflag, vflag, 3, 3 & ~c->centres_early, /*first=*/c->centres_early == 0));
   if (va) mdp_time_mark(c, 1);
   mdp_time_mark(c, 2);
+  (void) lj_queue_mode(c); // which variant the tile launches of this compute take (and their follow-up reads)
   if (va) {
     mdp_time_mark(c, 3);
     c->prune_valid = false; // (these paths walk the rows as built)

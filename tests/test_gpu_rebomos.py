@@ -71,6 +71,32 @@ def test_all_branches_match_oracle(ctx, oracle, P, fac, amp, seed):
     _compare(_gpu_compute(ctx, eng, s.x), eng.compute(s.x))
 
 
+@pytest.mark.parametrize("cap", [None, "2", "auto"])
+@pytest.mark.parametrize("ev", [0, 1])
+def test_cubic_pairs_through_the_queues_of_the_tile_kernel(ctx, oracle, P, monkeypatch, cap, ev):
+    """hot systems: the tile kernel appends its flagged pairs to per-group queues and a follow-up works them off without
+    walking the rows again (rebo_lj_tile_kernel<.., QUEUE>, rebo_lj_cubicq_kernel; chosen by itself when the compute
+    before listed more than an eighth of the tiles, forced here).  With two items per queue nearly every tile overflows
+    and is handed to the walk (rebo_lj_cubic_kernel) instead -- same forces and energies either way."""
+    if cap == "auto":           # no switch: the first compute walks, the later ones queue (every tile of this cell is listed)
+        monkeypatch.delenv("MDP_LJ_QUEUE", raising=False)
+    else:
+        monkeypatch.setenv("MDP_LJ_QUEUE", "1")
+        if cap:
+            monkeypatch.setenv("MDP_LJ_QUEUE_CAP", cap)
+    s = S.jitter(S.scale(S.replicate(S.rebomos_bulk_cell(), (2, 1, 1)), 1.12), 0.15, seed=1234)
+    eng = mdref.RebomosCPU(oracle, P, s)
+    ref = eng.compute(s.x)
+    for k in range(3):          # (the counts must be back at zero after every compute)
+        g = _gpu_compute(ctx, eng, s.x, first=k == 0, eflag=3 if ev else 0, vflag=ev)
+        assert np.abs(g["f"] - ref["f_owned"]).max() < F_TOL
+        if ev:
+            _compare(g, ref)
+    monkeypatch.setenv("MDP_LJ_QUEUE", "0")
+    g0 = _gpu_compute(ctx, eng, s.x, first=False, eflag=3 if ev else 0, vflag=ev)
+    assert np.abs(g0["f"] - g["f"]).max() < 1e-11            # the walk of the rows gives the same corrections
+
+
 def test_paged_list_entry_point_and_position_update(ctx, oracle, P):
     """the LAMMPS int** path (with high bits set, masked by NEIGHMASK) and per-step position updates
     with a list that stays valid inside the skin"""
