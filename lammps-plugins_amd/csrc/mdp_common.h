@@ -103,7 +103,7 @@ struct MdpStyleCheck {
   double *acc = nullptr;
   int nacc = 0;
   int *flags = nullptr, *ovf = nullptr;
-  int ovf_stride = 0; // the six list counters (five overflow lists, cubic-spline tiles) sit at ovf[k * ovf_stride]
+  int ovf_stride = 0; // the MDP_NOVF_LISTS list counters (five overflow lists, two lists of cubic-spline tiles) sit at ovf[k * ovf_stride]
 };
 struct MdpStyleCheckMeta {
   bool has_style = false, has_prune = false;
