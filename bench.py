@@ -134,7 +134,7 @@ def _rank_tree(n: int, env: dict, deadline: float):
 def launch_ranks(n: int) -> int:
     """start n fresh rank processes of this script and relay rank 0's JSON line.  The parent makes no GPU call.
     The default transport is the library's own (csrc/comm_rccl.hip).  If those ranks fail or pass their deadline
-    (MDP_BENCH_NATIVE_DEADLINE_S, 420 s), ONE fallback: fresh rank processes with MDP_BENCH_TRANSPORT=torch (all-to-all
+    (MDP_BENCH_NATIVE_DEADLINE_S, 300 s), ONE fallback: fresh rank processes with MDP_BENCH_TRANSPORT=torch (all-to-all
     through torch.distributed), and the line says so in `transport_fallback` -- never silently.  Both failing: non-zero."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
@@ -142,7 +142,7 @@ def launch_ranks(n: int) -> int:
     total = float(os.environ.get("MDP_BENCH_DEADLINE_S", "3000"))
     native_first = env.get("MDP_BENCH_TRANSPORT", "native") == "native"
     t0 = time.time()
-    first_deadline = min(total, float(os.environ.get("MDP_BENCH_NATIVE_DEADLINE_S", "420"))) if native_first else total
+    first_deadline = min(total, float(os.environ.get("MDP_BENCH_NATIVE_DEADLINE_S", "300"))) if native_first else total
     rc, line, why = _rank_tree(n, env, first_deadline)
     if rc != 0 and native_first and os.environ.get("MDP_BENCH_NO_FALLBACK", "0") in ("", "0"):
         left = total - (time.time() - t0)
