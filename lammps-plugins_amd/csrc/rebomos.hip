@@ -2450,12 +2450,92 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const int cap, const int
   }
 }
 
-static int tile_sort_launch(mdp_ctx *c, int ntile)
+// tile_sort_kernel and tile_fill_kernel (below) in one launch: the sorted masks stay in LDS and the rows are filled from
+// there -- the masks of a tile are needed by nothing else, so their way back to global memory and a launch with its
+// dependent loads (tile -> union size -> masks) are saved.
+__global__ __launch_bounds__(256) void tile_sort_fill_kernel(const int cap, const int np_max, const int *__restrict__ tile_nu,
+                                                             int *__restrict__ tu, const unsigned short *__restrict__ tmask,
+                                                             const int nclus, const long long *__restrict__ off,
+                                                             const int *__restrict__ split, unsigned short *__restrict__ lj16)
 {
+  extern __shared__ unsigned long long s_key[];                                   // [np_max] keys of the segment being sorted
+  unsigned short *s_fm = reinterpret_cast<unsigned short *>(s_key + np_max);      // [cap] masks in final order
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int nU = tile_nu[2 * t], N0 = tile_nu[2 * t + 1];
+  int *mem = tu + (size_t) t * cap;
+  const unsigned short *mm = tmask + (size_t) t * cap;
+  // (everything the fill needs from global memory is requested before the sort)
+  const int gq = tid / 16, sq = tid % 16, glane0 = lane - sq;
+  const int kc = t * MDP_TILE + gq;
+  const bool have = kc < nclus;
+  const long long b0 = off[kc];
+  const int len[2] = {split[kc], (int) (off[kc + 1] - b0) - split[kc]}; // padded segment lengths (tile_scan_kernel)
+  for (int seg = 0; seg < 2; seg++) {
+    const int b = seg ? N0 : 0, n = (seg ? nU : N0) - b;
+    if (n <= 1) { // (block-uniform)
+      if (n == 1 && tid == 0) s_fm[b] = mm[b];
+      continue;
+    }
+    int np = 2;
+    while (np < n) np <<= 1;
+    for (int i = tid; i < np; i += 256)
+      s_key[i] = i < n ? (((unsigned long long) (unsigned) mem[b + i]) << 16) | mm[b + i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int q = tid; q < (np >> 1); q += 256) {
+          const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), p = i | j;
+          const unsigned long long x = s_key[i], y = s_key[p];
+          if ((x > y) == ((i & k) == 0)) {
+            s_key[i] = y;
+            s_key[p] = x;
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < n; i += 256) {
+      const unsigned long long v = s_key[i];
+      mem[b + i] = (int) (v >> 16);
+      s_fm[b + i] = (unsigned short) (v & 0xFFFFull);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  unsigned short *row = lj16 + b0;
+  const unsigned long long below = (1ull << sq) - 1ull;
+  for (int seg = 0; seg < 2; seg++) {
+    const int ub = seg ? N0 : 0, ue = seg ? nU : N0;
+    int n = 0;
+    for (int base = ub; base < ue; base += 16) {
+      const int u = base + sq;
+      const bool k = have && u < ue && ((s_fm[u < ue ? u : ub] >> gq) & 1);
+      const unsigned long long bal = (__ballot(k) >> glane0) & 0xFFFFull;
+      if (k) row[n + __popcll(bal & below)] = (unsigned short) u;
+      n += __popcll(bal);
+    }
+    for (int q = n + sq; q < len[seg]; q += 16) row[q] = (unsigned short) nU; // padding: the dummy slot
+    row += len[seg];
+  }
+}
+
+// sorts the unions; with `fill` also writes the rows (then tile_fill_kernel must not follow).  *filled tells the caller.
+static int tile_sort_launch(mdp_ctx *c, int ntile, int nclus = 0, bool fill = false, bool *filled = nullptr)
+{
+  if (filled) *filled = false;
   if (const char *e = getenv("MDP_TILE_SORT"))
     if (atoi(e) == 0) return MDP_OK;
   int np = 2;
   while (np < c->tile_maxu) np <<= 1;
+  if (fill) {
+    const size_t lds = (size_t) np * sizeof(unsigned long long) + (size_t) c->tile_cap * sizeof(unsigned short);
+    if (lds > 48 * 1024)
+      MDP_HIP(c, hipFuncSetAttribute((const void *) tile_sort_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    tile_sort_fill_kernel<<<ntile, 256, lds, c->stream>>>(c->tile_cap, np, c->tile_nu.p, c->tu.p, c->tmask.p, nclus,
+                                                          c->lj_off.p, c->lj_split.p, c->lj16.p);
+    MDP_HIP(c, hipGetLastError());
+    if (filled) *filled = true;
+    return MDP_OK;
+  }
   const size_t lds = (size_t) np * sizeof(unsigned long long);
   if (lds > 48 * 1024)
     MDP_HIP(c, hipFuncSetAttribute((const void *) tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -3531,8 +3611,9 @@ int mdp_rebomos_repack(mdp_ctx *c)
     cand_build_kernel<2><<<(nall + per_block - 1) / per_block, 256, 0, st>>>(
         c->grid, Rc, c->rebomos, nall, nlocal, c->xq.p, c->cell_perm.p, c->cell_start.p, nullptr, c->cand_off.p,
         c->cand.p, c->is_center.p, self_end, c->xq_cell.p);
-  if (tiled) MDP_TRY(tile_sort_launch(c, ntile));
-  if (tiled)
+  bool rows_filled = false;
+  if (tiled) MDP_TRY(tile_sort_launch(c, ntile, nclus, /*fill=*/true, &rows_filled));
+  if (tiled && !rows_filled) // (MDP_TILE_SORT=0: the unions stay as found)
     tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
                                             c->lj16.p);
   c->prune_valid = false; // (new rows: the pruned copy is made at the next compute that wants it)
@@ -3696,9 +3777,11 @@ int mdp_tile_lists_build(mdp_ctx *c, const double cutsq[4], int cl, bool *ok)
   long long total = 0;
   MDP_TRY(mdp_read_one(c, c->lj_off.p + nrow, sizeof(long long), &total));
   MDP_HIP(c, c->lj16.reserve((size_t) total + 256));
-  MDP_TRY(tile_sort_launch(c, ntile));
-  tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
-                                          c->lj16.p);
+  bool rows_filled = false;
+  MDP_TRY(tile_sort_launch(c, ntile, nclus, /*fill=*/true, &rows_filled));
+  if (!rows_filled)
+    tile_fill_kernel<<<ntile, 256, 0, st>>>(nclus, c->tile_cap, c->tile_nu.p, c->tmask.p, c->lj_off.p, c->lj_split.p,
+                                            c->lj16.p);
   MDP_HIP(c, hipGetLastError());
   c->nclus = nclus;
   c->ntile = ntile;
