@@ -190,6 +190,28 @@ def test_bricks_with_migration_follow_the_one_rank_trajectory(world):
     assert many["th"]["pe"] == pytest.approx(rest["th"]["pe"], rel=1e-9)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_strained_hot_bricks_queue_their_cubic_pairs(world, oracle):
+    """the x 1.12 cell with jitter (pairs on the cubic inner Lennard-Jones spline in every tile) on bricks: after the first
+    compute every rank takes the tile kernel that queues those pairs, with remote ghosts among the queued neighbours;
+    forces equal the oracle's, the trajectory the one-brick run's"""
+    P = oracle.rebomos_params(POT_REBOMOS)
+    s = S.jitter(S.scale(S.replicate(S.rebomos_bulk_cell(), (3, 3, 2)), 1.12), 0.15, seed=1234)
+    v0 = S.gaussian_velocities(s, 300.0, seed=21) + np.array([40.0, -30.0, 20.0])
+    xw = S.wrap(s.box, s.x)
+    o = mdref.RebomosCPU(oracle, P, S.System(s.box, xw, s.type, s.tag, s.mass)).compute(xw)
+    st = _run(world, s, v0, 0, 0)
+    assert np.abs(st["f"] - o["f_owned"]).max() < 1e-9
+    one = _run(1, s, v0, 20, 5)
+    many = _run(world, s, v0, 20, 5)
+    dx = many["x"] - one["x"]
+    dx -= np.round(s.box.x2lamda(dx + s.box.lo)) @ s.box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert np.abs(many["f"] - one["f"]).max() < 1e-7
+    assert many["th"]["pe"] == pytest.approx(one["th"]["pe"], rel=1e-10)
+    assert np.allclose(many["th"]["virial"], one["th"]["virial"], rtol=1e-8, atol=1e-5)
+
+
 def test_aeam_bricks_with_halo_of_fp_and_ghost_forces(oracle):
     """AEAM on 2 and 4 bricks: scalar forward exchange of fp and reverse exchange of the angular ghost forces
     through the library's send list; forces equal the oracle's, trajectory equals the one-rank run"""
