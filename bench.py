@@ -906,6 +906,25 @@ def main():
                 sec["plugin_load_nve_mdp_aeam"] = pl
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] plugin-load AEAM run failed: {e}")
+            try:   # the same system driven by the C++ host of minihost/ddhost.cpp: resident mode through the C-ABI, no Python in the loop
+                pkg = os.path.join(ROOT, "lammps-plugins_amd")
+                p = subprocess.run([os.path.join(pkg, "ddhost"), "-ranks", "1", "-replicate", *map(str, DEFAULT_REPLICATE["rebomos"]),
+                                    "-steps", "200", "-thermo", str(THERMO_EVERY["rebomos"])], cwd=pkg, capture_output=True, text=True, timeout=600)
+                import re
+                m = re.search(r"Loop time of ([0-9.eE+-]+) on 1 procs for (\d+) steps with (\d+) atoms", p.stdout)
+                if p.returncode != 0 or not m:
+                    raise RuntimeError(f"ddhost failed ({p.returncode}): {p.stderr[-300:]}")
+                rows = [[float(w) for w in l.split()] for l in p.stdout.splitlines() if re.match(r"^\s*\d+\s+[-0-9.e+]+\s+[-0-9.e+]+", l)]
+                sec["cpp_host_resident"] = dict(
+                    ms_per_step=round(float(m.group(1)) / int(m.group(2)) * 1e3, 4), steps=int(m.group(2)), atoms=int(m.group(3)),
+                    Matom_steps_per_s=round(int(m.group(3)) * int(m.group(2)) / float(m.group(1)) / 1e6, 2),
+                    thermo_every=THERMO_EVERY["rebomos"], pe_step0=rows[0][3] if rows else None,
+                    pe_step0_over_13824_cells=(rows[0][3] / 13824.0 if rows else None),
+                    note="minihost/ddhost.cpp: the headline system, device-resident NVE with thermo every 10 steps as in.rebomos-bulk:31, "
+                         "driven by a C++ program through include/mdpair_hip.h alone (mdp_md_integrate_check / mdp_md_compute per step); "
+                         "PE of step 0 / 13 824 cells = log.rebomos-bulk.1:54")
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] ddhost run failed: {e}")
         out["secondary"] = sec
     # the CPU baseline runs on rank 0 AFTER every timed region (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu_baseline:
