@@ -1,4 +1,4 @@
-// ddhost.cpp -- a C++ host for device-resident multi-GPU runs of the rebomos style: one brick of the box per GPU, one host
+// ddhost.cpp -- a C++ host for device-resident multi-GPU runs of both styles (rebomos, aeam): one brick of the box per GPU, one host
 // thread per GPU, everything through the C-ABI of include/mdpair_hip.h (no Python, no torch, no MPI).
 //
 // What the reference gets from LAMMPS on several MPI ranks (USER-REBOMOS/log.rebomos-bulk.4: processor grid :22, thermo
@@ -13,8 +13,11 @@
 // ranks RCCL refuses to connect two ranks on one device: MDP_RCCL_LIBRARY=<tests/native/libfake_rccl.so> (the
 // repository's test double) lets them share it -- a rehearsal, and the program says so.
 //
-// usage: ddhost [-ranks N] [-replicate a b c] [-steps K] [-thermo T] [-temp K] [-seed S] [-drift vx vy vz]
-//               [-pot MoS.REBO.set5b] [-dump prefix]
+// usage: ddhost [-style rebomos|aeam] [-ranks N] [-replicate a b c] [-steps K] [-thermo T] [-temp K] [-seed S]
+//               [-drift vx vy vz] [-pot file] [-frac2 f] [-dump prefix]
+//   -style aeam    USER-AEAM/sample.in's system: fcc Al, a = 4.045, `replicate` = conventional cells per dimension, a fraction
+//                  -frac2 (0.0075, sample.in:19) of the atoms switched to type 2 (Si) by this program's own hash of the atom
+//                  id (LAMMPS' `set type/fraction` generator is out of scope), skin 1.0 (sample.in:17), AlSi.aeam
 //   -dump prefix   every rank writes prefix.<rank>: int nlocal, then nlocal records {int tag; double x[3], v[3]} (tests)
 #include "mdpair_hip.h"
 
@@ -51,7 +54,7 @@ struct System {
   Box box;
   std::vector<double> x, v; // [n][3]
   std::vector<int> type, tag;
-  double mass[3] = {0.0, 95.95, 32.065};
+  double mass[3] = {0.0, 95.95, 32.065}; // per type, 1-based (aeam: from the potential file)
   int n() const { return (int) type.size(); }
 };
 
@@ -106,6 +109,33 @@ System build_system(const int rep[3])
         }
   s.tag.resize(s.type.size());
   for (size_t a = 0; a < s.tag.size(); a++) s.tag[a] = (int) a + 1;
+  s.v.assign(s.x.size(), 0.0);
+  return s;
+}
+
+// USER-AEAM/sample.in:8-11,19: fcc lattice of rep conventional cells, a fraction of the atoms of type 2
+System build_fcc(const int rep[3], double a, double frac2, uint64_t seed)
+{
+  System s;
+  s.box = Box{{0, 0, 0}, {rep[0] * a, rep[1] * a, rep[2] * a}, 0.0, 0.0, 0.0};
+  const double basis[4][3] = {{0, 0, 0}, {0.5, 0.5, 0}, {0.5, 0, 0.5}, {0, 0.5, 0.5}};
+  for (int k = 0; k < rep[2]; k++)
+    for (int j = 0; j < rep[1]; j++)
+      for (int i = 0; i < rep[0]; i++)
+        for (int b = 0; b < 4; b++) {
+          s.x.push_back((i + basis[b][0]) * a);
+          s.x.push_back((j + basis[b][1]) * a);
+          s.x.push_back((k + basis[b][2]) * a);
+          uint64_t h = (seed ^ (0x9E3779B97F4A7C15ull * (uint64_t) (s.type.size() + 1)));
+          h ^= h >> 33;
+          h *= 0xFF51AFD7ED558CCDull;
+          h ^= h >> 33;
+          h *= 0xC4CEB9FE1A85EC53ull;
+          h ^= h >> 33;
+          s.type.push_back((h >> 11) * (1.0 / 9007199254740992.0) < frac2 ? 2 : 1);
+        }
+  s.tag.resize(s.type.size());
+  for (size_t q = 0; q < s.tag.size(); q++) s.tag[q] = (int) q + 1;
   s.v.assign(s.x.size(), 0.0);
   return s;
 }
@@ -193,7 +223,9 @@ struct Args {
   int ranks = 1, rep[3] = {2, 2, 1}, steps = 20, thermo = 10;
   double temp = 0.0, drift[3] = {0, 0, 0};
   uint64_t seed = 4928459;
-  std::string pot = "../tests/golden/potentials/MoS.REBO.set5b", dump;
+  int style = 1; // 1 rebomos, 2 aeam
+  double frac2 = 0.0075;
+  std::string pot, dump;
 };
 
 struct Shared {
@@ -247,15 +279,37 @@ void rank_main(Shared &S, int rank)
     return;
   }
   CK(mdp_create(&ctx, rank % ndev));
-  mdp_rebomos_params P;
-  char err[512] = {0};
-  if (mdp_rebomos_read_file(A.pot.c_str(), &P, err, 512) != MDP_OK) {
-    fprintf(stderr, "ERROR: %s\n", err);
-    S.failed = 1;
-    return;
+  double skin, cutghost;
+  mdp_aeam_file *af = nullptr; // (the tables point into it: it lives as long as the context)
+  if (A.style == 1) {
+    mdp_rebomos_params P;
+    char err[512] = {0};
+    if (mdp_rebomos_read_file(A.pot.c_str(), &P, err, 512) != MDP_OK) {
+      fprintf(stderr, "ERROR: %s\n", err);
+      S.failed = 1;
+      S.bar.fail();
+      return;
+    }
+    CK(mdp_rebomos_set_params(ctx, &P));
+    skin = 2.0;
+    cutghost = 3.0 * P.rcmax[0][0] + skin; // cut3rebo + skin (pair_rebomos.cpp:257, log.rebomos-bulk.1:43)
+  } else {
+    char err[512] = {0};
+    if (mdp_aeam_file_read(A.pot.c_str(), &af, err, 512) != MDP_OK) {
+      fprintf(stderr, "ERROR: %s\n", err);
+      S.failed = 1;
+      S.bar.fail();
+      return;
+    }
+    mdp_aeam_tables T;
+    const int amap[3] = {0, 0, 1}; // pair_coeff * * AlSi.aeam Al Si: type 1 -> element 0, type 2 -> element 1
+    CK(mdp_aeam_file_build(af, 2, amap, &T));
+    CK(mdp_aeam_set_tables(ctx, &T));
+    skin = 1.0; // sample.in:17
+    double cmax = 0.0;
+    for (int q = 0; q < T.nelements * T.nelements; q++) cmax = std::fmax(cmax, T.cut[q]);
+    cutghost = cmax + skin;
   }
-  CK(mdp_rebomos_set_params(ctx, &P));
-  const double skin = 2.0, cutghost = 3.0 * P.rcmax[0][0] + skin; // cut3rebo + skin (pair_rebomos.cpp:257, log.rebomos-bulk.1:43)
   // this rank's brick of the box (lamda space, as LAMMPS' Comm brick does for triclinic boxes)
   const System &G = S.s;
   std::vector<double> x, v;
@@ -277,7 +331,7 @@ void rank_main(Shared &S, int rank)
   }
   mdp_md_config cfg;
   memset(&cfg, 0, sizeof cfg);
-  cfg.style = 1;
+  cfg.style = A.style;
   cfg.nlocal = (int) type.size();
   cfg.ntypes = 2;
   cfg.skin = skin;
@@ -296,7 +350,8 @@ void rank_main(Shared &S, int rank)
   const int map[3] = {0, 0, 1}; // type 1 -> Mo, type 2 -> S (pair_coeff * * MoS.REBO.set5b M S)
   const int idummy = 0;
   const double ddummy[3] = {0, 0, 0};
-  CK(mdp_md_setup(ctx, &cfg, x.data(), v.data(), type.data(), tag.data(), G.mass, map, &idummy, ddummy, &idummy, &idummy));
+  CK(mdp_md_setup(ctx, &cfg, x.data(), v.data(), type.data(), tag.data(), G.mass, A.style == 1 ? map : nullptr, &idummy, ddummy, &idummy,
+                  &idummy));
   mdp_dd_config dd;
   memset(&dd, 0, sizeof dd);
   for (int d = 0; d < 3; d++) {
@@ -330,7 +385,13 @@ void rank_main(Shared &S, int rank)
     CK(mdp_dd_comm_reneighbor(ctx));
   } else
     CK(mdp_dd_reneighbor(ctx));
-  CK(mdp_md_compute(ctx, 1, 1));
+  if (multi && A.style == 2) { // PairAEAM::compute with its own exchanges, blocking order (pair_aeam.cpp:257,307 + reverse_comm of f)
+    CK(mdp_md_aeam_density(ctx, 1));
+    CK(mdp_dd_comm_forward_scalar(ctx));
+    CK(mdp_md_aeam_force(ctx, 1, 1));
+    CK(mdp_dd_comm_reverse(ctx));
+  } else
+    CK(mdp_md_compute(ctx, 1, 1));
   long long di[8];
   CK(mdp_dd_info(ctx, di, nullptr, nullptr));
   S.nlocal[rank] = di[0];
@@ -398,6 +459,7 @@ void rank_main(Shared &S, int rank)
   }
   if (multi) CK(mdp_dd_comm_destroy(ctx));
   mdp_destroy(ctx);
+  if (af) mdp_aeam_file_free(af);
 }
 
 } // namespace
@@ -421,6 +483,16 @@ int main(int argc, char **argv)
     else if (k == "-seed") need(1), a.seed = strtoull(argv[++i], nullptr, 10);
     else if (k == "-drift") need(3), a.drift[0] = atof(argv[i + 1]), a.drift[1] = atof(argv[i + 2]), a.drift[2] = atof(argv[i + 3]), i += 3;
     else if (k == "-pot") need(1), a.pot = argv[++i];
+    else if (k == "-frac2") need(1), a.frac2 = atof(argv[++i]);
+    else if (k == "-style") {
+      need(1);
+      const std::string v = argv[++i];
+      if (v != "rebomos" && v != "aeam") {
+        fprintf(stderr, "ddhost: -style rebomos|aeam\n");
+        return 2;
+      }
+      a.style = v == "aeam" ? 2 : 1;
+    }
     else if (k == "-dump") need(1), a.dump = argv[++i];
     else {
       fprintf(stderr, "ddhost: unknown option %s\n", k.c_str());
@@ -431,13 +503,39 @@ int main(int argc, char **argv)
     fprintf(stderr, "ddhost: bad arguments\n");
     return 2;
   }
+  if (a.pot.empty()) a.pot = a.style == 1 ? "../tests/golden/potentials/MoS.REBO.set5b" : "../tests/golden/potentials/AlSi.aeam";
   Shared S(a.ranks);
   S.a = a;
-  S.s = build_system(a.rep);
+  if (a.style == 1)
+    S.s = build_system(a.rep);
+  else {
+    S.s = build_fcc(a.rep, 4.045, a.frac2, 7683797);
+    // masses of the file's elements (one read on the main thread: the rank threads read the file again for their tables)
+    mdp_aeam_file *f = nullptr;
+    char err[512] = {0};
+    int ne = 0, nn = 0, na = 0;
+    double m[64] = {0};
+    if (mdp_aeam_file_read(a.pot.c_str(), &f, err, 512) != MDP_OK) {
+      fprintf(stderr, "ERROR: %s\n", err);
+      return 1;
+    }
+    mdp_aeam_file_info(f, &ne, &nn, &na, m, 64, nullptr, 0);
+    mdp_aeam_file_free(f);
+    if (ne < 2) {
+      fprintf(stderr, "ERROR: %s defines %d element(s); -style aeam maps two atom types\n", a.pot.c_str(), ne);
+      return 1;
+    }
+    S.s.mass[1] = m[0];
+    S.s.mass[2] = m[1];
+  }
   create_velocities(S.s, a.temp, a.seed, a.drift);
   proc_grid(a.ranks, S.grid);
-  printf("ddhost: REBO-MoS bulk, in.rebomos-bulk cell replicated %d x %d x %d = %d atoms, %d rank(s), %d steps\n", a.rep[0], a.rep[1],
-         a.rep[2], S.s.n(), a.ranks, a.steps);
+  if (a.style == 1)
+    printf("ddhost: REBO-MoS bulk, in.rebomos-bulk cell replicated %d x %d x %d = %d atoms, %d rank(s), %d steps\n", a.rep[0], a.rep[1],
+           a.rep[2], S.s.n(), a.ranks, a.steps);
+  else
+    printf("ddhost: AEAM AlSi, fcc a = 4.045, %d x %d x %d cells = %d atoms (%.2f %% type 2), %d rank(s), %d steps\n", a.rep[0], a.rep[1],
+           a.rep[2], S.s.n(), 100.0 * a.frac2, a.ranks, a.steps);
   fflush(stdout);
   std::vector<std::thread> th;
   for (int r = 0; r < a.ranks; r++) th.emplace_back(rank_main, std::ref(S), r);

@@ -89,3 +89,24 @@ def test_ddhost_hot_run_on_n_ranks_follows_its_one_rank_run(ranks, tmp_path):
     dx = xn - x1
     dx -= np.round(box.x2lamda(dx + box.lo)) @ box.h.T                  # same atom, possibly another periodic image
     assert np.abs(dx).max() < 1e-8
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ddhost_aeam_on_n_ranks_follows_its_one_rank_run(ranks, tmp_path):
+    """the aeam style in the same C++ host: 16^3 fcc cells (16 384 atoms, 3 % Si) at 863 K with a drift -- fp forward and
+    ghost-force reverse exchanges behind the interior tiles, reneighborings by the flag in the halo"""
+    common = ["-style", "aeam", "-replicate", 16, 16, 16, "-frac2", 0.03, "-steps", 48, "-thermo", 16, "-temp", 863,
+              "-drift", 40, 25, -30]
+    o1, r1 = _ddhost(["-ranks", 1, "-dump", tmp_path / "one"] + common)
+    on, rn = _ddhost(["-ranks", ranks, "-dump", tmp_path / "many"] + common, double=True)
+    x1, v1 = _dump(tmp_path / "one", 1)
+    xn, vn = _dump(tmp_path / "many", ranks)
+    assert np.abs(vn - v1).max() < 1e-7
+    assert len(rn) == len(r1) == 4
+    for a, b in zip(rn, r1):
+        assert a[3] == pytest.approx(b[3], rel=1e-10) and a[4] == pytest.approx(b[4], rel=1e-9)
+    box = S.fcc_cell(4.045, 16).box
+    dx = xn - x1
+    dx -= np.round(box.x2lamda(dx + box.lo)) @ box.h.T
+    assert np.abs(dx).max() < 1e-8
+    assert int(re.search(r"Neighbor list builds = (\d+)", on).group(1)) >= 3
