@@ -410,10 +410,12 @@ int mdp_dd_comm_allreduce(mdp_ctx *ctx, double *vals, int n, int op /* 0 sum, 1 
  * [5] = overlap policy, [6] = 1 if MDP_OVERLAP_POLICY fixed it, [7] = its mean device time per step in the trial (ns).
  * Overlap policy: how a step orders its compute against its exchanges -- 0 "split" (what needs no remote ghost of this
  * step is launched behind the start of the exchange), 1 "lead" (as 0, and the compute stream waits until the RCCL kernel
- * has started), 2 "blocking" (exchange, then the whole compute), 3 "first" (rebomos: only the first interior kernel
- * behind the exchange).  The sends and receives are the same in all of them.  The first steps of a run are a trial
- * (blocks of 4 steps per policy, two rounds; -1 in out[5] while it runs): device time per step between two events, MAX
- * over the ranks, cheapest policy kept.  MDP_OVERLAP_POLICY = split | lead | blocking | first skips the trial. */
+ * has started), 2 "blocking" (exchange, then the whole compute: rebomos with one launch per centre class over its
+ * interior and boundary halves), 3 "first" (rebomos: only the first interior kernel behind the exchange), 4 "inline"
+ * (as blocking, the position exchange queued on the context's own stream: no second stream, no events).  The sends and
+ * receives are the same in all of them.  The first steps of a run are a trial (blocks of 4 steps per policy, two
+ * rounds; -1 in out[5] while it runs): device time per step between two events, MAX over the ranks, cheapest policy
+ * kept.  MDP_OVERLAP_POLICY = split | lead | blocking | first | inline skips the trial. */
 int mdp_dd_comm_step_begin(mdp_ctx *ctx, int with_final, int force_rebuild, int eflag, int vflag, int *reneighbored);
 int mdp_dd_comm_step_end(mdp_ctx *ctx, int eflag, int vflag, int defer_final);
 int mdp_dd_comm_step_info(mdp_ctx *ctx, long long out[8]);

@@ -1466,8 +1466,9 @@ __global__ __launch_bounds__(256) void tile_first_remote_kernel(const int ntile,
   const int nU = tile_nu[2 * t];
   int hit = 0;
   for (int u = lane; u < nU; u += 64) hit |= mem[u] >= remote_start;
+  hit = __any(hit); // (all 64 lanes vote: a tile that straddles the end of the interior atoms holds few remote ghosts)
   if (lane != 0) return;
-  if (__any(hit)) {
+  if (hit) {
     atomicMin(&count[1], t);
   } else {
     // (thousands of atomics on one word serialise: only a tile that would raise the maximum sends one)

@@ -179,12 +179,14 @@ int comm_lead(mdp_ctx *c)
 // MDP_OVERLAP_POLICY = split | lead | blocking | first fixes the policy (no trial); auto (default) runs the trial.
 constexpr int kOvBlock = 4, kOvRounds = 2; // steps per block (the first is the transition and is not measured), rounds
 
-int ov_npol(const mdp_ctx *c) { return c->cfg.style == 1 ? 4 : 3; }
+// policies in trial order; "first" (3) exists for rebomos only
+int ov_npol(const mdp_ctx *c) { return c->cfg.style == 1 ? 5 : 4; }
+int ov_policy_of(const mdp_ctx *c, int idx) { return c->cfg.style == 1 ? idx : (idx < 3 ? idx : 4); }
 
 const char *ov_name(int p)
 {
-  static const char *n[4] = {"split", "lead", "blocking", "first"};
-  return p >= 0 && p < 4 ? n[p] : "undecided";
+  static const char *n[5] = {"split", "lead", "blocking", "first", "inline"};
+  return p >= 0 && p < 5 ? n[p] : "undecided";
 }
 
 void ov_read_env(mdp_ctx *c)
@@ -193,10 +195,10 @@ void ov_read_env(mdp_ctx *c)
   if (D.ov_forced != -2) return;
   D.ov_forced = -1;
   if (const char *e = getenv("MDP_OVERLAP_POLICY")) {
-    for (int p = 0; p < ov_npol(c); p++)
-      if (!strcmp(e, ov_name(p))) D.ov_forced = p;
+    for (int i = 0; i < ov_npol(c); i++)
+      if (!strcmp(e, ov_name(ov_policy_of(c, i)))) D.ov_forced = ov_policy_of(c, i);
     if (D.ov_forced < 0 && strcmp(e, "auto"))
-      fprintf(stderr, "mdpair_hip: MDP_OVERLAP_POLICY=%s is not one of split, lead, blocking%s, auto: running the trial\n", e,
+      fprintf(stderr, "mdpair_hip: MDP_OVERLAP_POLICY=%s is not one of split, lead, blocking, inline%s, auto: running the trial\n", e,
               c->cfg.style == 1 ? ", first" : "");
   }
   if (D.ov_forced >= 0) D.ov_policy = D.ov_forced;
@@ -206,7 +208,7 @@ void ov_read_env(mdp_ctx *c)
 int ov_harvest(mdp_ctx *c, bool drain)
 {
   MdpDomain &D = c->dd;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 4; k++) { // (event-pair slots)
     if (D.ov_slot_pol[k] < 0 || k == D.ov_slot) continue;
     if (drain) MDP_HIP(c, hipEventSynchronize(D.ov_ev[k][1]));
     else if (hipEventQuery(D.ov_ev[k][1]) != hipSuccess) continue;
@@ -231,24 +233,26 @@ int ov_step_begin(mdp_ctx *c, bool plain_step /* no reneighboring, no tally: com
     MDP_TRY(ov_harvest(c, false));
     if (D.ov_step >= total) { // the trial is over: every rank reduces the same vector at the same step
       MDP_TRY(ov_harvest(c, true));
-      double mean[4];
-      for (int p = 0; p < 4; p++) mean[p] = p < np && D.ov_cnt[p] > 0 ? D.ov_sum[p] / D.ov_cnt[p] : (p < np ? 1.0e30 : 0.0);
-      MDP_TRY(mdp_dd_comm_allreduce(c, mean, 4, /*max*/ 1));
+      double mean[5];
+      for (int p = 0; p < 5; p++) mean[p] = D.ov_cnt[p] > 0 ? D.ov_sum[p] / D.ov_cnt[p] : 1.0e30; // (never tried: never chosen)
+      MDP_TRY(mdp_dd_comm_allreduce(c, mean, 5, /*max*/ 1));
       int best = 0;
-      for (int p = 1; p < np; p++)
+      for (int i = 1; i < np; i++) {
+        const int p = ov_policy_of(c, i);
         if (mean[p] < mean[best] * 0.995) best = p; // (a later policy has to win by half a percent)
-      for (int p = 0; p < 4; p++) D.ov_mean[p] = mean[p];
+      }
+      for (int p = 0; p < 5; p++) D.ov_mean[p] = mean[p] < 1.0e29 ? mean[p] : 0.0;
       D.ov_policy = best;
       if (D.G.rank == 0)
-        fprintf(stderr, "mdpair_hip: overlap policy %s (device ms per step, max over %d ranks: split %.4f lead %.4f blocking %.4f%s)\n",
-                ov_name(best), D.G.nranks, mean[0], mean[1], mean[2],
-                np > 3 ? (std::string(" first ") + std::to_string(mean[3])).c_str() : "");
+        fprintf(stderr, "mdpair_hip: overlap policy %s (device ms per step, max over %d ranks: split %.4f lead %.4f blocking %.4f "
+                        "first %.4f inline %.4f)\n",
+                ov_name(best), D.G.nranks, D.ov_mean[0], D.ov_mean[1], D.ov_mean[2], D.ov_mean[3], D.ov_mean[4]);
     }
   }
   if (D.ov_policy >= 0) {
     D.ov_cur = D.ov_policy;
   } else {
-    D.ov_cur = (int) ((D.ov_step / kOvBlock) % ov_npol(c));
+    D.ov_cur = ov_policy_of(c, (int) ((D.ov_step / kOvBlock) % ov_npol(c)));
     const bool measured = plain_step && D.ov_step % kOvBlock != 0;
     D.ov_step++;
     if (measured)
@@ -261,7 +265,8 @@ int ov_step_begin(mdp_ctx *c, bool plain_step /* no reneighboring, no tally: com
     }
   }
   D.lead = D.ov_cur == 1;
-  c->overlap_mode = D.ov_cur == 2 ? 2 : (D.ov_cur == 3 ? 3 : 0);
+  D.inline_x = D.ov_cur == 4; // the position exchange on the context's own stream (no second stream, no events)
+  c->overlap_mode = (D.ov_cur == 2 || D.ov_cur == 4) ? 2 : (D.ov_cur == 3 ? 3 : 0);
   return MDP_OK;
 }
 
@@ -406,9 +411,16 @@ int mdp_dd_comm_forward_begin(mdp_ctx *c)
   MDP_HIP(c, D.sbuf.reserve((size_t) 3 * D.nsend + 8));
   MDP_HIP(c, D.rbuf.reserve((size_t) 3 * D.nrecv + 8));
   MDP_TRY(mdp_dd_forward_pack(c, D.sbuf.p));
-  MDP_HIP(c, hipEventRecord(D.ev_packed, c->stream));
-  MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
-  MDP_TRY(comm_lead(c));
+  // policy "inline" (whole steps only): nothing is to overlap the exchange, so it is queued on the context's stream
+  // itself -- pack, RCCL kernel, unpack in stream order, without the two hand-overs between streams
+  const bool inl = D.step_mode && D.inline_x;
+  hipStream_t xs = inl ? c->stream : D.comm_stream;
+  if (!inl) {
+    MDP_HIP(c, hipEventRecord(D.ev_packed, c->stream));
+    MDP_HIP(c, hipStreamWaitEvent(D.comm_stream, D.ev_packed, 0));
+    MDP_TRY(comm_lead(c));
+  }
+  D.fwd_inline = inl;
   // the ranks' "an atom of mine has moved beyond the trigger" words of this step travel WITH the positions (the
   // integrate kernel of this step wrote this rank's; mdp_dd_forward_unpack reduces them for the next step's decision):
   // one more double to and from every rank in the same group of ncclSend/ncclRecv -- one RCCL kernel per step -- up to
@@ -418,12 +430,12 @@ int mdp_dd_comm_forward_begin(mdp_ctx *c)
   if (flags && n <= kFlagP2PRanks) {
     RcclApi *R = rccl();
     MDP_NCCL(c, R->GroupStart());
-    const int rc = exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream);
+    const int rc = exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, xs);
     ncclResult_t first = ncclSuccess; // (the group is always closed: see exchange())
     for (int q = 0; q < n && first == ncclSuccess && rc == MDP_OK; q++) {
-      first = R->Send(D.flagbuf.p + D.flag_par, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+      first = R->Send(D.flagbuf.p + D.flag_par, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, xs);
       if (first == ncclSuccess)
-        first = R->Recv(D.flagbuf.p + 2 + q, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, D.comm_stream);
+        first = R->Recv(D.flagbuf.p + 2 + q, 1, ncclDouble, q, (ncclComm_t) D.nccl_comm, xs);
     }
     const ncclResult_t end = R->GroupEnd();
     if (rc != MDP_OK) return rc;
@@ -431,14 +443,14 @@ int mdp_dd_comm_forward_begin(mdp_ctx *c)
     if (end != ncclSuccess) return mdp_fail(c, MDP_EHIP, "ncclGroupEnd -> %s", R->GetErrorString(end));
     D.fwd_gathered = true;
   } else {
-    MDP_TRY(exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, D.comm_stream));
+    MDP_TRY(exchange(c, D.sbuf.p, D.bord_send.data(), D.rbuf.p, D.bord_recv.data(), 3, xs));
     if (flags) {
       MDP_NCCL(c, rccl()->AllGather(D.flagbuf.p + D.flag_par, D.flagbuf.p + 2, 1, ncclDouble, (ncclComm_t) D.nccl_comm,
-                                    D.comm_stream));
+                                    xs));
       D.fwd_gathered = true;
     }
   }
-  MDP_HIP(c, hipEventRecord(D.ev_arrived, D.comm_stream));
+  if (!inl) MDP_HIP(c, hipEventRecord(D.ev_arrived, xs));
   D.fwd_pending = true;
   return MDP_OK;
 }
@@ -448,7 +460,7 @@ int mdp_dd_comm_forward_end(mdp_ctx *c)
   MDP_TRY(comm_require(c));
   MdpDomain &D = c->dd;
   if (!D.nsend && !D.nrecv && !D.step_mode) return MDP_OK;
-  MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_arrived, 0));
+  if (!D.fwd_inline) MDP_HIP(c, hipStreamWaitEvent(c->stream, D.ev_arrived, 0));
   D.fwd_pending = false;
   return mdp_dd_forward_unpack(c, D.rbuf.p);
 }

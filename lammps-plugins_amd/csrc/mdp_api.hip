@@ -873,6 +873,7 @@ int mdp_destroy(mdp_ctx *c)
   c->lj16.release();
   c->is_center.release();
   c->class_list.release();
+  c->class_merged.release();
   c->class_count.release();
   c->pk_cand.release();
   c->amask.release();

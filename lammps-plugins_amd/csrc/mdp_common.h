@@ -236,14 +236,16 @@ struct MdpDomain {
   //   1 lead      as 0, and the compute stream waits until the RCCL kernel of the exchange has started (comm_lead)
   //   2 blocking  exchange first, then the whole compute in its one-GPU order
   //   3 first     rebomos only: of the interior work only the first kernel (lane-per-centre) runs behind the exchange
+  //   4 inline    as blocking, with the position exchange queued on the context's own stream (no second stream, no events)
   int ov_policy = -1;              // the choice; -1 while the trial runs
   int ov_forced = -2;              // MDP_OVERLAP_POLICY: -2 not read yet, -1 auto, >= 0 fixed
   int ov_cur = 0;                  // policy of the step in flight
   bool lead = false;               // (policy 1 of the step in flight)
   long long ov_step = 0;           // steps the trial has seen
-  double ov_sum[4] = {0, 0, 0, 0}; // device time of the measured steps per policy, ms
-  int ov_cnt[4] = {0, 0, 0, 0};
-  double ov_mean[4] = {0, 0, 0, 0};
+  double ov_sum[5] = {0, 0, 0, 0, 0}; // device time of the measured steps per policy, ms
+  int ov_cnt[5] = {0, 0, 0, 0, 0};
+  double ov_mean[5] = {0, 0, 0, 0, 0};
+  bool inline_x = false, fwd_inline = false; // (policy 4 of the step in flight; how the exchange in flight was queued)
   hipEvent_t ov_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   int ov_slot_pol[4] = {-1, -1, -1, -1}; // policy of the step a slot's event pair brackets (-1: free)
   int ov_slot = -1;                // slot of the step in flight (-1: not measured)
@@ -388,6 +390,8 @@ struct mdp_ctx {
   DevBuf<int> class_count;        // [MDP_NCLASS]
   DevBuf<int> pk_cand;            // per class, per centre: its first UA*G candidates, contiguous in class order
   size_t pk_base[MDP_NCLASS] = {};
+  DevBuf<int> class_merged;       // per class: interior centres then boundary centres, one list (launches over both halves)
+  size_t merged_base[MDP_NCLASS_HALF] = {};
   int h_class_count[MDP_NCLASS] = {};
   DevBuf<unsigned long long> amask; // [nall] bit t: candidate t currently inside rcmax
   DevBuf<int> rev;                // [cand_total] absolute reverse slot (owned rows)

@@ -3698,12 +3698,34 @@ int mdp_rebomos_repack(mdp_ctx *c)
   { // packed candidate heads of the lane-group classes (widths = UA*G of rebo_centre_kernel<G>), per element
     const int width[5] = {CentreCfg<4>::UA * 4, CentreCfg<8>::UA * 8, CentreCfg<12>::UA * 12, CentreCfg<16>::UA * 16,
                           CentreCfg<32>::UA * 32};
+    // (the boundary half of a class directly behind its interior half: a launch over both -- the blocking orders of a
+    //  multi-GPU step, which have no use for two launches per class -- then finds one contiguous block)
     size_t total = 0;
-    for (int k = 0; k < MDP_NCLASS; k++) {
-      c->pk_base[k] = total;
-      total += (size_t) c->h_class_count[k] * width[(k % MDP_NCLASS_HALF) / 2];
-    }
+    for (int g = 0; g < MDP_NCLASS_HALF; g++)
+      for (int half = 0; half < 2; half++) {
+        const int k = g + half * MDP_NCLASS_HALF;
+        c->pk_base[k] = total;
+        total += (size_t) c->h_class_count[k] * width[g / 2];
+      }
     MDP_HIP(c, c->pk_cand.reserve(total + 1));
+    if (centre_split) { // ... and the two halves' centre lists once more as one list per class
+      size_t mtot = 0;
+      for (int g = 0; g < MDP_NCLASS_HALF; g++) {
+        c->merged_base[g] = mtot;
+        mtot += (size_t) c->h_class_count[g] + c->h_class_count[g + MDP_NCLASS_HALF];
+      }
+      MDP_HIP(c, c->class_merged.reserve(mtot + 1));
+      for (int g = 0; g < MDP_NCLASS_HALF; g++) {
+        const int n0 = c->h_class_count[g], n1 = c->h_class_count[g + MDP_NCLASS_HALF];
+        if (n0)
+          MDP_HIP(c, hipMemcpyAsync(c->class_merged.p + c->merged_base[g], c->class_list.p + (size_t) g * nall, sizeof(int) * n0,
+                                    hipMemcpyDeviceToDevice, st));
+        if (n1)
+          MDP_HIP(c, hipMemcpyAsync(c->class_merged.p + c->merged_base[g] + n0,
+                                    c->class_list.p + (size_t) (g + MDP_NCLASS_HALF) * nall, sizeof(int) * n1,
+                                    hipMemcpyDeviceToDevice, st));
+      }
+    }
     for (int k = 0; k < MDP_NCLASS; k++) {
       const int w = width[(k % MDP_NCLASS_HALF) / 2];
       const long long n = (long long) c->h_class_count[k] * w;
@@ -3868,12 +3890,15 @@ template <int G>
 static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
 {
   for (int elem = 0; elem < 2; elem++) {
-    const int k = 2 * kg + elem + part * MDP_NCLASS_HALF; // part 0: interior centres, 1: boundary centres
-    const int n = c->h_class_count[k];
+    // part 0: interior centres, 1: boundary centres, 2: both halves of the class in one launch (class_merged; their
+    // packed candidates are contiguous: mdp_rebomos_repack)
+    const int k = 2 * kg + elem + (part == 1 ? MDP_NCLASS_HALF : 0);
+    const int n = c->h_class_count[k] + (part == 2 ? c->h_class_count[k + MDP_NCLASS_HALF] : 0);
     if (n <= 0) continue;
+    const int *list = part == 2 ? c->class_merged.p + c->merged_base[k] : c->class_list.p + (size_t) k * c->nall;
     constexpr int per_block = CentreCfg<G>::WPB * CentreCfg<G>::GPW;
     const int grid = (n + per_block - 1) / per_block;
-    rebo_centre_kernel<G><<<grid, 64 * CentreCfg<G>::WPB, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n, c->nlocal,
+    rebo_centre_kernel<G><<<grid, 64 * CentreCfg<G>::WPB, 0, c->stream>>>(c->rebomos, list, n, c->nlocal,
                                                        c->xq.p, c->cand_off.p, c->cand.p, c->pk_cand.p + c->pk_base[k],
                                                        c->amask.p, c->fnbr.p, c->fown.p, c->acc.p, c->ovf.p, eflag, vflag,
                                                        elem);
@@ -3884,22 +3909,23 @@ static void launch_centre(mdp_ctx *c, int kg, int eflag, int vflag, int part)
 static void launch_centre3(mdp_ctx *c, int eflag, int vflag, int part)
 {
   for (int elem = 0; elem < 2; elem++) {
-    const int k = elem + part * MDP_NCLASS_HALF;
-    const int n = c->h_class_count[k];
+    const int k = elem + (part == 1 ? MDP_NCLASS_HALF : 0); // (part 2: both halves in one launch, as launch_centre)
+    const int n = c->h_class_count[k] + (part == 2 ? c->h_class_count[k + MDP_NCLASS_HALF] : 0);
     if (n <= 0) continue;
+    const int *clist = part == 2 ? c->class_merged.p + c->merged_base[k] : c->class_list.p + (size_t) k * c->nall;
     // Its centres with a fourth neighbour (S-S pairs of MoS2 dip below rcmax at 300 K) are counted per (part, elem);
     // the count of a step is published to a pinned word by the last centre kernel of the step and read here TWO computes
     // later, without a wait of its own: two sets of words alternate (ovf_par), and the set read now was written by the
     // compute before the last, which the deferred displacement check of this compute has waited for (mdp_sflag_collect)
     // -- so the choice of path below is the same in every run of the same trajectory.  While it is zero -- a cold crystal -- such a centre goes straight to the general
     // kernel's list; once centres do overflow they are collected on a list of their own ...
-    const int q = part * 2 + elem;
+    const int q = (part == 1 ? 2 : 0) + elem; // (a launch over both halves collects on the interior half's list)
     int *list = c->ovf.p + (size_t) (q + 1) * c->ovf_stride + 1; // (count at list[-1]; zeroed with the accumulators)
     int *h_cnt = (int *) (c->h_pinned + 40) + 4 * c->ovf_par + q;
     if (*h_cnt > 0) c->ovf3_hot[q] = 64;      // (hysteresis: stay in list mode for 64 computes after the last overflow)
     else if (c->ovf3_hot[q] > 0) c->ovf3_hot[q]--;
     const bool list_mode = c->ovf3_hot[q] > 0;
-    rebo_centre3_kernel<<<(n + kC3Block - 1) / kC3Block, kC3Block, 0, c->stream>>>(c->rebomos, c->class_list.p + (size_t) k * c->nall, n,
+    rebo_centre3_kernel<<<(n + kC3Block - 1) / kC3Block, kC3Block, 0, c->stream>>>(c->rebomos, clist, n,
                                                                 c->nlocal, c->xq.p, c->cand_off.p, c->cand.p,
                                                                 c->pk_cand.p + c->pk_base[k], c->amask.p, c->fnbr.p,
                                                                 c->fown.p, c->acc.p, list, list_mode ? nullptr : c->ovf.p,
@@ -4185,17 +4211,26 @@ static int launch_centres(mdp_ctx *c, int eflag, int vflag, int parts, int which
 {
   if ((parts & 1) && first) c->ovf_par ^= 1; // (a new compute: the set of pinned overflow counts it reads first and writes last)
   hipStream_t st = c->stream; // (the overflow counter ovf[0] was zeroed by mdp_acc_begin of this compute)
-  for (int part = 0; part < 2; part++) {
-    if (!((parts >> part) & 1)) continue;
-    const int w = part == 0 ? which : 3;
-    if (w & 1) launch_centre3(c, eflag, vflag, part);
-    if (w & 2) {
-      launch_centre<8>(c, 1, eflag, vflag, part);
-      launch_centre<12>(c, 2, eflag, vflag, part);
-      launch_centre<16>(c, 3, eflag, vflag, part);
-      launch_centre<32>(c, 4, eflag, vflag, part);
+  if (c->centre_split && parts == 3 && which == 3) {
+    // nothing of this compute ran behind an exchange (a blocking order of the multi-GPU step): one launch per class over
+    // both of its halves instead of two -- the boundary halves are 6 % of the centres and a third of the launches
+    launch_centre3(c, eflag, vflag, 2);
+    launch_centre<8>(c, 1, eflag, vflag, 2);
+    launch_centre<12>(c, 2, eflag, vflag, 2);
+    launch_centre<16>(c, 3, eflag, vflag, 2);
+    launch_centre<32>(c, 4, eflag, vflag, 2);
+  } else
+    for (int part = 0; part < 2; part++) {
+      if (!((parts >> part) & 1)) continue;
+      const int w = part == 0 ? which : 3;
+      if (w & 1) launch_centre3(c, eflag, vflag, part);
+      if (w & 2) {
+        launch_centre<8>(c, 1, eflag, vflag, part);
+        launch_centre<12>(c, 2, eflag, vflag, part);
+        launch_centre<16>(c, 3, eflag, vflag, part);
+        launch_centre<32>(c, 4, eflag, vflag, part);
+      }
     }
-  }
   MDP_HIP(c, hipGetLastError());
   if (!(parts & 2)) return MDP_OK;
   // centres that outgrew their lane group since the last build (normally none: the kernel reads the

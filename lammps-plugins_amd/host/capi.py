@@ -592,7 +592,7 @@ class Context:
     def dd_comm_step_info(self):
         out = (C.c_longlong * 8)()
         self._ck(self.L.mdp_dd_comm_step_info(self.h, out))
-        names = {-1: "undecided (trial running)", 0: "split", 1: "lead", 2: "blocking", 3: "first"}
+        names = {-1: "undecided (trial running)", 0: "split", 1: "lead", 2: "blocking", 3: "first", 4: "inline"}
         return dict(aeam_phased=int(out[0]), ghost_forces=bool(out[1]), reneighbored=bool(out[2]), reneighbors=int(out[3]),
                     dangerous=int(out[4]), overlap_policy=names.get(int(out[5]), str(int(out[5]))),
                     overlap_policy_fixed_by_env=bool(out[6]), overlap_policy_trial_ms=int(out[7]) * 1.0e-6)

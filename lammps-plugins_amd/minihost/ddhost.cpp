@@ -546,8 +546,8 @@ int main(int argc, char **argv)
     printf("Performance: %.3f ns/day, %.3f timesteps/s, %.3f Matom-step/s\n\n", a.steps / S.loop_s * 0.001 * 86.4, a.steps / S.loop_s,
            (double) S.s.n() * a.steps / S.loop_s / 1e6);
   for (int r = 0; r < a.ranks; r++) printf("rank %d: Nlocal %lld  Nghost %lld\n", r, S.nlocal[r], S.nghost[r]);
-  static const char *pol[5] = {"split", "lead", "blocking", "first", "undecided"};
+  static const char *pol[6] = {"split", "lead", "blocking", "first", "inline", "undecided"};
   printf("Neighbor list builds = %lld\nDangerous builds = %lld\n", S.info[3], S.info[4]);
-  if (a.ranks > 1) printf("Overlap policy = %s\n", pol[S.info[5] >= 0 && S.info[5] < 4 ? S.info[5] : 4]);
+  if (a.ranks > 1) printf("Overlap policy = %s\n", pol[S.info[5] >= 0 && S.info[5] < 5 ? S.info[5] : 5]);
   return 0;
 }

@@ -133,7 +133,7 @@ def case_steps(style, world, pure=False):
 def case_fixed_policies():
     """every order of compute against exchanges by itself (MDP_OVERLAP_POLICY): same trajectory"""
     out = {}
-    for style, pols in (("rebomos", ("split", "lead", "blocking", "first")), ("aeam", ("split", "lead", "blocking"))):
+    for style, pols in (("rebomos", ("split", "lead", "blocking", "first", "inline")), ("aeam", ("split", "lead", "blocking", "inline"))):
         for pol in pols:
             os.environ["MDP_OVERLAP_POLICY"] = pol
             try:

@@ -84,7 +84,7 @@ def test_ddhost_hot_run_on_n_ranks_follows_its_one_rank_run(ranks, tmp_path):
         assert a[2] == pytest.approx(b[2], rel=1e-7, abs=1e-3)
     builds = int(re.search(r"Neighbor list builds = (\d+)", on).group(1))
     assert builds >= 3 and "Dangerous builds = 0" in on
-    assert re.search(r"Overlap policy = (split|lead|blocking|first)", on)
+    assert re.search(r"Overlap policy = (split|lead|blocking|first|inline)", on)
     box = S.replicate(S.rebomos_bulk_cell(), (3, 3, 2)).box
     dx = xn - x1
     dx -= np.round(box.x2lamda(dx + box.lo)) @ box.h.T                  # same atom, possibly another periodic image

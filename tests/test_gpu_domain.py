@@ -129,9 +129,17 @@ def _run(world, s, v0, steps, rebuild_every, style=capi.STYLE_REBOMOS, pot=None,
         tags, a = _by_tag(d, ("x", "v", "f"))
         aeam = ctx.md_aeam_state() if style == capi.STYLE_AEAM else None
         prunes = ctx.md_prune_stats()
+        near = None
+        if aeam and world > 1 and aeam["interior_tiles"]:
+            # distance from the atoms of the tiles that run before the halo arrives to the nearest remote ghost
+            info = ctx.dd_info()
+            xa = ctx.md_download_x_all(info["nlocal"] + info["nself"] + info["nrecv"])
+            rs = info["nlocal"] + info["nself"]
+            inner = xa[:min(aeam["interior_tiles"] * 32, info["nlocal"])]
+            near = min(float(np.linalg.norm(xa[rs:] - p, axis=1).min()) for p in inner)
         ctx.close()
         return dict(tags=tags, x=a["x"], v=a["v"], f=a["f"], th0=th0, th=th, counts0=counts0, left=left,
-                    builds=d.builds, aeam=aeam, overlapped=d.aeam_overlapped, prunes=prunes)
+                    builds=d.builds, aeam=aeam, overlapped=d.aeam_overlapped, prunes=prunes, near=near)
 
     if world == 1:
         res = [rank_fn(0, None)]
@@ -259,6 +267,8 @@ def test_aeam_exchanges_behind_the_interior_tiles(oracle, world, temp, drift):
         assert 0 < a["interior_tiles"] < a["tiles"]          # every brick has an interior and a shell
         assert a["ghost_forces"]                             # 3 % angular atoms: some sit in the shell
         assert 0 < r["overlapped"] <= steps                  # steps on the phased path ...
+        assert r["near"] > 5.0                               # no remote ghost within reach of an early tile (the tile
+        #                                                      that straddles the end of the interior atoms holds few)
         if drift or temp > 700:
             assert r["prunes"]["prunings"] > 1               # ... and prunings (those steps take the blocking path)
     frac = sum(r["aeam"]["interior_tiles"] for r in many["ranks"]) / sum(r["aeam"]["tiles"] for r in many["ranks"])

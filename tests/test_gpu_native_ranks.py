@@ -64,7 +64,7 @@ def test_whole_steps_on_n_ranks_follow_the_one_rank_trajectory(results, style, w
     assert r["late"] == [0] * world and r["late_one"] == 0
     assert min(r["nrecv"]) > 0                                          # every rank has REMOTE ghosts
     # the first steps were the library's overlap-policy trial (every order in turn); all ranks kept the same one
-    assert len(set(r["policy"])) == 1 and r["policy"][0] in ("split", "lead", "blocking", "first")
+    assert len(set(r["policy"])) == 1 and r["policy"][0] in ("split", "lead", "blocking", "first", "inline")
     assert not any(r["policy_fixed"]) and min(r["policy_trial_ms"]) > 0.0
     if style == "aeam":
         assert all(r["ghost_forces"])                                   # 3 % angular atoms: some sit in a shell
@@ -83,14 +83,14 @@ def test_pure_metal_bricks_skip_the_reverse_exchange_on_every_rank(results, worl
 
 
 def test_every_overlap_policy_by_itself_gives_the_trajectory(results):
-    """MDP_OVERLAP_POLICY fixes the order of compute against exchanges (no trial): split / lead / blocking / first"""
+    """MDP_OVERLAP_POLICY fixes the order of compute against exchanges (no trial): split / lead / blocking / first / inline"""
     r = _case(results, "fixed_policies")
-    assert len(r) == 7
+    assert len(r) == 9
     for name, c in r.items():
         assert c["owned_once"] and c["dx"] < 1e-8 and c["df"] < 1e-7, name
         assert max(c["pe_rel"]) < 1e-10, name
         assert set(c["policy"]) == {name.split("_")[1]} and all(c["policy_fixed"]), name
-        if name == "aeam_blocking":
+        if name in ("aeam_blocking", "aeam_inline"):
             assert c["overlapped"] == [0, 0]                            # no step on the phased order
         elif name.startswith("aeam"):
             assert min(c["overlapped"]) > 0
