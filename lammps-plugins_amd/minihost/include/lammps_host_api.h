@@ -114,11 +114,13 @@ class Domain { // the members of LAMMPS' Domain the adapters read (box of this s
   double xprd = 1.0, yprd = 1.0, zprd = 1.0, xy = 0.0, xz = 0.0, yz = 0.0;
   double boxlo[3] = {0, 0, 0}, boxhi[3] = {1, 1, 1};
   double h[6] = {1, 1, 1, 0, 0, 0}; // xprd, yprd, zprd, yz, xz, xy
+  double sublo_lamda[3] = {0, 0, 0}, subhi_lamda[3] = {1, 1, 1}; // this rank's brick (`minilmp -np N`: one of N)
 };
 
 class Comm {
  public:
   int me = 0, nprocs = 1, nthreads = 1;
+  int procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0};
   virtual ~Comm() = default;
   virtual void forward_comm(Pair *pair) = 0;
   virtual void reverse_comm(Pair *pair) = 0;

@@ -1,4 +1,4 @@
-// minilmp -- a small single-process MD host that implements the slice of LAMMPS the two pair-style
+// minilmp -- a small MD host that implements the slice of LAMMPS the two pair-style
 // plugins need: input-script subset, lattice/create_atoms, periodic ghost
 // images (triclinic), binned full(+ghost) neighbor lists in LAMMPS' paged int** form, the Verlet
 // loop of fix nve (and a simple Nose-Hoover fix nvt), thermo output in LAMMPS' log format, and
@@ -8,6 +8,13 @@
 // `in.rebomos-bulk` run against rebomosplugin.so exactly as `lmp -in in.rebomos-bulk` would
 // (host mode of the C-ABI: x up / f down across PCIe every step).  It is NOT LAMMPS: a plugin
 // built against these headers loads here only.
+//
+// `minilmp -np N`: N ranks as N threads of this process, each with its own host objects (as N MPI processes of LAMMPS
+// have), a brick of the box in lamda space on LAMMPS' processor grid, ghosts from the neighbouring bricks, migration
+// at reneighborings, Comm::forward_comm / reverse_comm of a pair style BETWEEN ranks through its pack / unpack
+// callbacks, thermo sums over ranks.  `in.rebomos-bulk` on four ranks then runs as log.rebomos-bulk.4 shows it
+// (2 by 2 by 1 grid, Nlocal 72, Nghost 2768 / 2775, the same thermo rows).  Every rank script-parses the whole input
+// and creates ALL atoms (identical IDs on every rank and for every N); the bricks keep their own at the first `run`.
 #include "lammps_host_api.h"
 
 #include <dlfcn.h>
@@ -16,6 +23,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <fstream>
 #include <functional>
@@ -35,16 +45,18 @@ struct HostAbort : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+static thread_local int t_rank = 0; // (`-np N`: the rank this thread is)
+
 void Error::all(const std::string &file, int line, const std::string &msg)
 {
   std::ostringstream o;
-  o << "ERROR: " << msg << " (" << file << ":" << line << ")";
+  if (t_rank == 0) o << "ERROR: " << msg << " (" << file << ":" << line << ")"; // (every rank stops; rank 0 says why)
   throw HostAbort(o.str());
 }
 void Error::one(const std::string &file, int line, const std::string &msg)
 {
   std::ostringstream o;
-  o << "ERROR on proc 0: " << msg << " (" << file << ":" << line << ")";
+  o << "ERROR on proc " << t_rank << ": " << msg << " (" << file << ":" << line << ")";
   throw HostAbort(o.str());
 }
 void Error::warning(const std::string &file, int line, const std::string &msg)
@@ -161,6 +173,54 @@ struct Region {
 
 struct Host;
 
+// ranks other than 0 keep quiet on stdout
+thread_local bool t_mute = false;
+#define printf(...) (t_mute ? 0 : std::printf(__VA_ARGS__))
+
+// the ranks of `-np N` (threads) meet here: a barrier that a failed rank breaks, scratch for sums over ranks
+struct World {
+  int n = 1;
+  std::vector<Host *> host;
+  std::vector<double> red;
+  static constexpr int kRed = 16;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  long generation = 0;
+  bool dead = false;
+  explicit World(int n_) : n(n_), host(n_, nullptr), red((size_t) n_ * kRed, 0.0) {}
+  void barrier()
+  {
+    if (n == 1) return;
+    std::unique_lock<std::mutex> lk(m);
+    if (dead) throw HostAbort("");
+    const long g = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+      return;
+    }
+    cv.wait(lk, [&] { return generation != g || dead; });
+    if (generation == g) throw HostAbort(""); // (another rank failed and said why)
+  }
+  void kill()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    dead = true;
+    cv.notify_all();
+  }
+};
+
+struct GhostRec {
+  int src, idx; // owner rank and its index there
+  Vec3 shift;
+};
+struct MoveRec {
+  double x[3], v[3];
+  int type, tag;
+};
+
 struct PeriodicComm : Comm {
   Host *h = nullptr;
   void forward_comm(Pair *pair) override;
@@ -206,6 +266,18 @@ struct Host {
   std::vector<Vec3> ghost_shift;
   std::vector<double> xhold;
 
+  // `-np N`: this rank's brick, its ghosts from other ranks, what it sends them
+  World *world = nullptr;
+  int me = 0, np = 1;
+  bool decomposed = false;              // the bricks kept their own atoms (first `run`)
+  double slo[3] = {0, 0, 0}, shi[3] = {1, 1, 1};
+  std::vector<GhostRec> ghosts;         // ordered by owner rank
+  std::vector<int> from_first, from_count;       // my ghosts owned by rank q: [from_first[q], + from_count[q])
+  std::vector<std::vector<int>> sendlist;        // my atoms that are ghosts on rank r, in r's order
+  std::vector<std::vector<MoveRec>> outbox;      // atoms leaving for rank r
+  std::vector<std::vector<double>> cbuf;         // pair-style comm buffers, one per peer
+  long natoms_all = 0;
+
   // neighbor storage
   std::vector<int> nb_store, ilist_v, numneigh_v;
   std::vector<std::pair<int, int>> excl_types; // neigh_modify exclude type M N
@@ -221,6 +293,161 @@ struct Host {
   double nvt_t0 = 0, nvt_t1 = 0, nvt_damp = 0.1, nvt_eta_dot = 0.0;
   long step = 0;
   bool quiet = false;
+
+  bool multi() const { return np > 1 && decomposed; }
+
+  // sums over ranks, in rank order on every rank (so all ranks hold the same bits)
+  void sum(double *v, int k)
+  {
+    if (!multi()) return;
+    for (int i = 0; i < k; i++) world->red[(size_t) me * World::kRed + i] = v[i];
+    world->barrier();
+    for (int i = 0; i < k; i++) {
+      double t = 0.0;
+      for (int q = 0; q < np; q++) t += world->red[(size_t) q * World::kRed + i];
+      v[i] = t;
+    }
+    world->barrier();
+  }
+  bool any(bool flag)
+  {
+    double v = flag ? 1.0 : 0.0;
+    sum(&v, 1);
+    return v != 0.0;
+  }
+  std::vector<double> gather(double v)
+  {
+    std::vector<double> out(np, v);
+    if (!multi()) return out;
+    world->red[(size_t) me * World::kRed] = v;
+    world->barrier();
+    for (int q = 0; q < np; q++) out[q] = world->red[(size_t) q * World::kRed];
+    world->barrier();
+    return out;
+  }
+
+  // ---------------------------------------------------------------- bricks (`-np N`)
+  // LAMMPS' processor grid (ProcMap::onelevel_grid / best_factors): the factorisation of N with the least surface
+  // between bricks, first found on ties; ranks on it as MPI_Cart_create places them (x slowest)
+  void choose_grid()
+  {
+    const double a[3] = {prd[0], 0, 0}, b[3] = {tilt[0], prd[1], 0}, c[3] = {tilt[1], tilt[2], prd[2]};
+    auto cross_len = [](const double *u, const double *v) {
+      const double x = u[1] * v[2] - u[2] * v[1], y = u[2] * v[0] - u[0] * v[2], z = u[0] * v[1] - u[1] * v[0];
+      return sqrt(x * x + y * y + z * z);
+    };
+    const double ab = cross_len(a, b), ac = cross_len(a, c), bc = cross_len(b, c);
+    double best = 1e300;
+    int g[3] = {np, 1, 1};
+    for (int i = 1; i <= np; i++) {
+      if (np % i) continue;
+      for (int j = 1; j <= np / i; j++) {
+        if ((np / i) % j) continue;
+        const int k = np / i / j;
+        const double surf = ab / i / j + ac / i / k + bc / j / k;
+        if (surf < best) {
+          best = surf;
+          g[0] = i; g[1] = j; g[2] = k;
+        }
+      }
+    }
+    for (int d = 0; d < 3; d++) comm.procgrid[d] = g[d];
+    comm.myloc[0] = me / (g[1] * g[2]);
+    comm.myloc[1] = (me / g[2]) % g[1];
+    comm.myloc[2] = me % g[2];
+    for (int d = 0; d < 3; d++) {
+      slo[d] = (double) comm.myloc[d] / g[d];
+      shi[d] = (double) (comm.myloc[d] + 1) / g[d];
+      domain.sublo_lamda[d] = slo[d];
+      domain.subhi_lamda[d] = shi[d];
+    }
+  }
+  int rank_of(const double *l) const
+  {
+    int loc[3];
+    for (int d = 0; d < 3; d++) loc[d] = std::min(comm.procgrid[d] - 1, std::max(0, (int) (l[d] * comm.procgrid[d])));
+    return (loc[0] * comm.procgrid[1] + loc[1]) * comm.procgrid[2] + loc[2];
+  }
+
+  // owned atoms := the given ones (no ghosts)
+  void set_owned(const std::vector<double> &x, const std::vector<double> &v, const std::vector<int> &ty, const std::vector<int> &tg)
+  {
+    const int n = (int) ty.size();
+    atom.nlocal = n;
+    atom.nghost = 0;
+    set_views(n);
+    std::copy(x.begin(), x.end(), xs.begin());
+    std::copy(ty.begin(), ty.end(), types.begin());
+    std::copy(tg.begin(), tg.end(), tags.begin());
+    set_vviews();
+    std::copy(v.begin(), v.end(), vs.begin());
+  }
+
+  // first `run` on N ranks: every rank holds all atoms (wrapped); each keeps those of its brick
+  void decompose()
+  {
+    if (np == 1 || decomposed) return;
+    const int n = atom.nlocal;
+    natoms_all = n;
+    std::vector<double> x, v;
+    std::vector<int> ty, tg;
+    for (int i = 0; i < n; i++) {
+      double l[3];
+      x2lamda(xrow[i], l);
+      if (rank_of(l) != me) continue;
+      x.insert(x.end(), xs.begin() + 3 * (size_t) i, xs.begin() + 3 * (size_t) i + 3);
+      v.insert(v.end(), vs.begin() + 3 * (size_t) i, vs.begin() + 3 * (size_t) i + 3);
+      ty.push_back(types[i]);
+      tg.push_back(tags[i]);
+    }
+    set_owned(x, v, ty, tg);
+    world->host[me] = this;
+    outbox.assign(np, {});
+    cbuf.assign(np, {});
+    decomposed = true;
+  }
+
+  // Comm::exchange: atoms that left the brick move to the rank that owns them now (positions are wrapped)
+  void exchange()
+  {
+    if (!multi()) return;
+    const int n = atom.nlocal;
+    std::vector<double> x, v;
+    std::vector<int> ty, tg;
+    for (auto &o : outbox) o.clear();
+    for (int i = 0; i < n; i++) {
+      double l[3];
+      x2lamda(xrow[i], l);
+      const int dest = rank_of(l);
+      if (dest == me) {
+        x.insert(x.end(), xs.begin() + 3 * (size_t) i, xs.begin() + 3 * (size_t) i + 3);
+        v.insert(v.end(), vs.begin() + 3 * (size_t) i, vs.begin() + 3 * (size_t) i + 3);
+        ty.push_back(types[i]);
+        tg.push_back(tags[i]);
+      } else {
+        MoveRec r;
+        for (int d = 0; d < 3; d++) {
+          r.x[d] = xs[3 * (size_t) i + d];
+          r.v[d] = vs[3 * (size_t) i + d];
+        }
+        r.type = types[i];
+        r.tag = tags[i];
+        outbox[dest].push_back(r);
+      }
+    }
+    world->barrier();
+    for (int q = 0; q < np; q++) {
+      if (q == me) continue;
+      for (const MoveRec &r : world->host[q]->outbox[me]) {
+        x.insert(x.end(), r.x, r.x + 3);
+        v.insert(v.end(), r.v, r.v + 3);
+        ty.push_back(r.type);
+        tg.push_back(r.tag);
+      }
+    }
+    world->barrier();
+    set_owned(x, v, ty, tg);
+  }
 
   Host()
   {
@@ -337,6 +564,10 @@ struct Host {
 
   void build_ghosts()
   {
+    if (multi()) {
+      build_ghosts_multi();
+      return;
+    }
     const int n = atom.nlocal;
     const double cut = comm_cutoff();
     // lamda-space half widths: cut * |row_d(h^-1)|
@@ -392,8 +623,96 @@ struct Host {
     refresh_ghosts();
   }
 
-  void refresh_ghosts() // forward comm of x on one periodic rank
+  void lamda_halo(double c[3]) const // lamda-space half widths of the ghost shell: cut * |row_d(h^-1)|
   {
+    const double cut = comm_cutoff();
+    const double hinv00 = 1.0 / prd[0], hinv11 = 1.0 / prd[1], hinv22 = 1.0 / prd[2];
+    const double hinv01 = -tilt[0] / (prd[0] * prd[1]);
+    const double hinv02 = (tilt[0] * tilt[2] - prd[1] * tilt[1]) / (prd[0] * prd[1] * prd[2]);
+    const double hinv12 = -tilt[2] / (prd[1] * prd[2]);
+    c[0] = cut * sqrt(hinv00 * hinv00 + hinv01 * hinv01 + hinv02 * hinv02);
+    c[1] = cut * sqrt(hinv11 * hinv11 + hinv12 * hinv12);
+    c[2] = cut * hinv22;
+  }
+
+  // Comm::borders on N ranks: every atom of any rank (and any periodic image of it) inside this brick widened by the
+  // ghost cutoff in lamda space -- what LAMMPS' six sequential swaps collect --, grouped by the rank that owns it
+  void build_ghosts_multi()
+  {
+    const int n = atom.nlocal;
+    double c[3], h[3][3];
+    lamda_halo(c);
+    h_matrix(h);
+    int r[3];
+    for (int d = 0; d < 3; d++) r[d] = (int) ceil(c[d]);
+    world->barrier(); // (every rank's owned atoms are final)
+    std::vector<GhostRec> recs;
+    std::vector<double> gx;
+    std::vector<int> gty, gtg;
+    from_first.assign(np, 0);
+    from_count.assign(np, 0);
+    for (int q = 0; q < np; q++) {
+      const Host *o = world->host[q];
+      const int nq = o->atom.nlocal;
+      from_first[q] = (int) recs.size();
+      std::vector<double> lam((size_t) 3 * nq);
+      for (int i = 0; i < nq; i++) o->x2lamda(o->xs.data() + 3 * (size_t) i, lam.data() + 3 * (size_t) i);
+      for (int sx = -r[0]; sx <= r[0]; sx++)
+        for (int sy = -r[1]; sy <= r[1]; sy++)
+          for (int sz = -r[2]; sz <= r[2]; sz++) {
+            if (q == me && !sx && !sy && !sz) continue;
+            const int s[3] = {sx, sy, sz};
+            Vec3 sh;
+            for (int d = 0; d < 3; d++) sh[d] = h[d][0] * sx + h[d][1] * sy + h[d][2] * sz;
+            for (int i = 0; i < nq; i++) {
+              bool in = true;
+              for (int d = 0; d < 3 && in; d++) {
+                const double l = lam[3 * (size_t) i + d] + s[d];
+                in = l >= slo[d] - c[d] && l < shi[d] + c[d];
+              }
+              if (!in) continue;
+              recs.push_back({q, i, sh});
+              for (int d = 0; d < 3; d++) gx.push_back(o->xs[3 * (size_t) i + d] + sh[d]);
+              gty.push_back(o->types[i]);
+              gtg.push_back(o->tags[i]);
+            }
+          }
+      from_count[q] = (int) recs.size() - from_first[q];
+    }
+    world->barrier(); // (nobody reads my arrays any more: they may move)
+    const int ng = (int) recs.size();
+    std::vector<double> xo(xs.begin(), xs.begin() + 3 * (size_t) n);
+    std::vector<int> to(types.begin(), types.begin() + n), go(tags.begin(), tags.begin() + n);
+    set_views(n + ng);
+    std::copy(xo.begin(), xo.end(), xs.begin());
+    std::copy(to.begin(), to.end(), types.begin());
+    std::copy(go.begin(), go.end(), tags.begin());
+    std::copy(gx.begin(), gx.end(), xs.begin() + 3 * (size_t) n);
+    std::copy(gty.begin(), gty.end(), types.begin() + n);
+    std::copy(gtg.begin(), gtg.end(), tags.begin() + n);
+    atom.nghost = ng;
+    ghosts.swap(recs);
+    world->barrier(); // (every rank's ghost records are published)
+    sendlist.assign(np, {});
+    for (int q = 0; q < np; q++) {
+      const Host *o = world->host[q];
+      for (int g = o->from_first[me]; g < o->from_first[me] + o->from_count[me]; g++) sendlist[q].push_back(o->ghosts[g].idx);
+    }
+    world->barrier();
+  }
+
+  void refresh_ghosts() // forward comm of x
+  {
+    if (multi()) {
+      const int n = atom.nlocal;
+      world->barrier(); // (every rank has moved its atoms)
+      for (size_t g = 0; g < ghosts.size(); g++) {
+        const double *xo = world->host[ghosts[g].src]->xs.data() + 3 * (size_t) ghosts[g].idx;
+        for (int d = 0; d < 3; d++) xs[3 * (n + g) + d] = xo[d] + ghosts[g].shift[d];
+      }
+      world->barrier();
+      return;
+    }
     const int n = atom.nlocal, ng = atom.nghost;
     for (int g = 0; g < ng; g++)
       for (int d = 0; d < 3; d++) xs[3 * (size_t) (n + g) + d] = xs[3 * (size_t) ghost_owner[g] + d] + ghost_shift[g][d];
@@ -401,6 +720,17 @@ struct Host {
 
   void fold_ghost_forces() // reverse comm of f
   {
+    if (multi()) {
+      world->barrier(); // (every rank's forces of this step are in its array)
+      for (int q = 0; q < np; q++) {
+        const Host *o = world->host[q];
+        const double *fo = o->fs.data() + 3 * (size_t) (o->atom.nlocal + o->from_first[me]);
+        for (size_t k = 0; k < sendlist[q].size(); k++)
+          for (int d = 0; d < 3; d++) fs[3 * (size_t) sendlist[q][k] + d] += fo[3 * k + d];
+      }
+      world->barrier();
+      return;
+    }
     const int n = atom.nlocal, ng = atom.nghost;
     for (int g = 0; g < ng; g++)
       for (int d = 0; d < 3; d++) fs[3 * (size_t) ghost_owner[g] + d] += fs[3 * (size_t) (n + g) + d];
@@ -514,17 +844,18 @@ struct Host {
   }
 
   // ---------------------------------------------------------------- thermo
-  double kinetic() const
+  double kinetic() // (a sum over ranks: called by every rank)
   {
     double ke = 0;
     for (int i = 0; i < atom.nlocal; i++) {
       const double *v = vs.data() + 3 * (size_t) i;
       ke += masses[types[i]] * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     }
+    sum(&ke, 1);
     return 0.5 * MVV2E * ke;
   }
-  double dof() const { return 3.0 * atom.nlocal - 3.0; }
-  double temperature() const { return dof() > 0 ? 2.0 * kinetic() / (dof() * BOLTZ) : 0.0; }
+  double dof() const { return 3.0 * (multi() ? (double) natoms_all : (double) atom.nlocal) - 3.0; }
+  double temperature() { return dof() > 0 ? 2.0 * kinetic() / (dof() * BOLTZ) : 0.0; }
 
   void print_thermo_header()
   {
@@ -547,8 +878,10 @@ struct Host {
 
   void print_thermo()
   {
-    const double ke = kinetic(), t = temperature(), pe = pair ? pair->eng_vdwl : 0.0;
-    const double *vir = pair->virial;
+    const double ke = kinetic(), t = dof() > 0 ? 2.0 * ke / (dof() * BOLTZ) : 0.0;
+    double tot[4] = {pair ? pair->eng_vdwl : 0.0, pair->virial[0], pair->virial[1], pair->virial[2]};
+    sum(tot, 4);
+    const double pe = tot[0], *vir = tot + 1;
     const double press = (dof() * BOLTZ * t + vir[0] + vir[1] + vir[2]) / (3.0 * volume()) * NKTV2P;
     std::string s;
     for (auto &c : thermo_cols) {
@@ -612,9 +945,11 @@ struct Host {
     update.laststep = step + nsteps;
     skin = neighbor.skin;
     wrap_owned();
+    if (np > 1 && !decomposed) decompose();
+    else exchange();
     build_ghosts();
     build_neighbor_lists();
-    set_vviews();
+    if (!multi()) set_vviews();
     if (fix) fix->init(); // (LAMMPS::init: force->init() before modify->init())
     printf("Neighbor list info ...\n  update: every = %d steps, delay = %d steps, check = %s\n", neighbor.every, neighbor.delay,
            neighbor.dist_check ? "yes" : "no");
@@ -644,10 +979,11 @@ struct Host {
         bool nflag = fix->force_reneighbor && fix->next_reneighbor == step;
         if (!nflag) {
           neighbor.ago++;
-          if (neighbor.ago >= neighbor.delay && neighbor.ago % neighbor.every == 0) nflag = neighbor.dist_check ? check_distance() : true;
+          if (neighbor.ago >= neighbor.delay && neighbor.ago % neighbor.every == 0) nflag = neighbor.dist_check ? any(check_distance()) : true;
         }
         if (nflag) {
           wrap_owned();
+          exchange();
           build_ghosts();
           build_neighbor_lists();
         }
@@ -680,8 +1016,9 @@ struct Host {
           xs[3 * (size_t) i + d] += dt * v;
         }
       }
-      if (check_distance()) {
+      if (any(check_distance())) {
         wrap_owned();
+        exchange();
         build_ghosts();
         build_neighbor_lists();
       } else {
@@ -691,7 +1028,7 @@ struct Host {
       const bool out = every > 0 && (step % every == 0);
       const bool last = k == nsteps;
       compute_forces((out || last) ? 1 : 0, (out || last) ? 2 : 0);
-      for (int i = 0; i < n; i++) {
+      for (int i = 0; i < atom.nlocal; i++) { // (nlocal: atoms may have changed ranks at the reneighboring)
         const double s = dtf / masses[types[i]];
         for (int d = 0; d < 3; d++) vs[3 * (size_t) i + d] += s * fs[3 * (size_t) i + d];
       }
@@ -706,14 +1043,36 @@ struct Host {
     }
     const double loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (fix) fix->post_run(); // (Modify::post_run, behind Verlet::run in Run::command)
-    printf("Loop time of %g on 1 procs for %ld steps with %d atoms\n\n", loop, nsteps, atom.nlocal);
+    const long nat = multi() ? natoms_all : (long) atom.nlocal;
+    printf("Loop time of %g on %d procs for %ld steps with %ld atoms\n\n", loop, np, nsteps, nat);
     if (nsteps > 0 && loop > 0) {
       const double sps = nsteps / loop;
       printf("Performance: %.3f ns/day, %.3f hours/ns, %.3f timesteps/s, %.3f katom-step/s\n", sps * dt * 86.4,
-             1.0 / (sps * dt * 3.6), sps, sps * atom.nlocal / 1000.0);
+             1.0 / (sps * dt * 3.6), sps, sps * nat / 1000.0);
     }
     long nn = 0;
     for (int i = 0; i < atom.nlocal; i++) nn += numneigh_v[i];
+    if (multi()) { // per-rank counts as LAMMPS' Finish prints them (ave / max / min), and rank by rank
+      const std::vector<double> nl = gather(atom.nlocal), ng = gather(atom.nghost), nf = gather((double) nn);
+      auto line = [&](const char *name, const std::vector<double> &v) {
+        double a = 0, hi = v[0], lo = v[0];
+        for (double x : v) {
+          a += x;
+          hi = std::max(hi, x);
+          lo = std::min(lo, x);
+        }
+        printf("%-10s %10g ave %11g max %11g min\n", name, a / v.size(), hi, lo);
+        return a;
+      };
+      printf("\n");
+      line("Nlocal:", nl);
+      line("Nghost:", ng);
+      const double tot = line("FullNghs:", nf);
+      for (int q = 0; q < np; q++) printf("rank %d: Nlocal %d  Nghost %d  FullNghs %ld\n", q, (int) nl[q], (int) ng[q], (long) nf[q]);
+      printf("\nTotal # of neighbors = %ld\nAve neighs/atom = %g\nNeighbor list builds = %d\n\n", (long) tot, nat ? tot / nat : 0.0,
+             nbuilds - nbuild0);
+      return;
+    }
     printf("\nNlocal:    %d\nNghost:    %d\nFullNghs:  %ld\nAve neighs/atom = %g\nNeighbor list builds = %d\n\n", atom.nlocal,
            atom.nghost, nn, atom.nlocal ? (double) nn / atom.nlocal : 0.0, nbuilds - nbuild0 - 0);
   }
@@ -722,6 +1081,19 @@ struct Host {
 void PeriodicComm::forward_comm(Pair *pair)
 {
   // owner -> ghost through the style's own pack/unpack callbacks (one double per atom)
+  if (h->multi()) { // between ranks: one buffer per peer, packed by the owner, unpacked into the peer's block of ghosts
+    const int nf = std::max(1, pair->comm_forward), np = h->np, me = h->me;
+    for (int r = 0; r < np; r++) {
+      h->cbuf[r].resize(h->sendlist[r].size() * (size_t) nf);
+      if (!h->sendlist[r].empty()) pair->pack_forward_comm((int) h->sendlist[r].size(), h->sendlist[r].data(), h->cbuf[r].data(), 0, nullptr);
+    }
+    h->world->barrier();
+    for (int q = 0; q < np; q++)
+      if (h->from_count[q])
+        pair->unpack_forward_comm(h->from_count[q], h->atom.nlocal + h->from_first[q], h->world->host[q]->cbuf[me].data());
+    h->world->barrier();
+    return;
+  }
   const int ng = h->atom.nghost, n = h->atom.nlocal;
   if (!ng) return;
   std::vector<double> buf((size_t) ng * std::max(1, pair->comm_forward));
@@ -732,6 +1104,19 @@ void PeriodicComm::forward_comm(Pair *pair)
 
 void PeriodicComm::reverse_comm(Pair *pair)
 {
+  if (h->multi()) {
+    const int nr = std::max(1, pair->comm_reverse), np = h->np, me = h->me;
+    for (int q = 0; q < np; q++) {
+      h->cbuf[q].resize((size_t) h->from_count[q] * nr);
+      if (h->from_count[q]) pair->pack_reverse_comm(h->from_count[q], h->atom.nlocal + h->from_first[q], h->cbuf[q].data());
+    }
+    h->world->barrier();
+    for (int r = 0; r < np; r++)
+      if (!h->sendlist[r].empty())
+        pair->unpack_reverse_comm((int) h->sendlist[r].size(), h->sendlist[r].data(), h->world->host[r]->cbuf[me].data());
+    h->world->barrier();
+    return;
+  }
   const int ng = h->atom.nghost, n = h->atom.nlocal;
   if (!ng) return;
   std::vector<double> buf((size_t) ng * std::max(1, pair->comm_reverse));
@@ -829,7 +1214,7 @@ double gaussian(uint64_t &s)
   return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
 }
 
-Host *g_host = nullptr;
+thread_local Host *g_host = nullptr; // (the host of this rank thread, for the plugin registration callback)
 
 struct Script {
   Host &H;
@@ -858,6 +1243,7 @@ struct Script {
   void create_atoms(const std::vector<std::string> &w)
   {
     if (!H.box_exists) H.error.all(FLERR, "Create_atoms command before simulation box is defined");
+    if (H.decomposed) H.error.all(FLERR, "minilmp -np N: create_atoms after the first run is not supported");
     const int deftype = std::stoi(w[1]);
     std::vector<int> btype(H.basis.size(), deftype);
     for (size_t k = 3; k + 2 < w.size() + 0; k++)
@@ -941,6 +1327,7 @@ struct Script {
 
   void replicate(int nx, int ny, int nz)
   {
+    if (H.decomposed) H.error.all(FLERR, "minilmp -np N: replicate after the first run is not supported");
     const int n0 = H.atom.nlocal;
     double h[3][3];
     H.h_matrix(h);
@@ -971,6 +1358,10 @@ struct Script {
     H.tilt[2] *= nz;
     H.atom.natoms = nn;
     printf("Replicated to %d atoms\n", nn);
+    if (H.np > 1) {
+      H.choose_grid();
+      printf("  %d by %d by %d MPI processor grid\n", H.comm.procgrid[0], H.comm.procgrid[1], H.comm.procgrid[2]);
+    }
   }
 
   void command(const std::string &raw)
@@ -1071,6 +1462,10 @@ struct Script {
                lo[2], hi[0], hi[1], hi[2], tl[0], tl[1], tl[2]);
       else
         printf("Created orthogonal box = (%.8g %.8g %.8g) to (%.8g %.8g %.8g)\n", lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+      if (H.np > 1) { // (a later `replicate` scales every edge alike here or not at all in the tests; LAMMPS re-maps too)
+        H.choose_grid();
+        printf("  %d by %d by %d MPI processor grid\n", H.comm.procgrid[0], H.comm.procgrid[1], H.comm.procgrid[2]);
+      }
     } else if (c == "create_atoms") {
       need(3);
       create_atoms(w);
@@ -1168,6 +1563,11 @@ struct Script {
           count++;
         }
       }
+      {
+        double cnt = count;
+        H.sum(&cnt, 1);
+        count = (int) cnt;
+      }
       printf("Setting atom values ...\n  %d settings made for type/fraction\n", count);
     } else if (c == "velocity") {
       need(5);
@@ -1185,11 +1585,16 @@ struct Script {
         }
         mt += m;
       }
+      {
+        double t4[4] = {p[0], p[1], p[2], mt};
+        H.sum(t4, 4);
+        p[0] = t4[0]; p[1] = t4[1]; p[2] = t4[2]; mt = t4[3];
+      }
       for (int i = 0; i < n; i++)
         for (int d = 0; d < 3; d++) H.vs[3 * (size_t) i + d] -= p[d] / mt;
       const double t = H.temperature();
       if (t > 0)
-        for (auto &v : H.vs) v *= sqrt(T / t);
+        for (int i = 0; i < 3 * n; i++) H.vs[i] *= sqrt(T / t);
     } else if (c == "fix") {
       need(4);
       if (w[3] == "nve")
@@ -1251,40 +1656,75 @@ struct Script {
 
 int main(int argc, char **argv)
 {
-  Host H;
   std::string infile;
+  bool quiet = false;
+  int np = 1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if ((a == "-in" || a == "-i") && i + 1 < argc)
       infile = argv[++i];
+    else if (a == "-np" && i + 1 < argc)
+      np = std::max(1, atoi(argv[++i]));
     else if (a == "-quiet")
-      H.quiet = true;
+      quiet = true;
     else if (a == "-h" || a == "-help") {
-      printf("usage: minilmp -in script   (subset of LAMMPS input; see INTEGRATION.md)\n");
+      printf("usage: minilmp [-np N] -in script   (subset of LAMMPS input; -np N: N ranks as threads; see INTEGRATION.md)\n");
       return 0;
     }
   }
   printf("minilmp (mini-host for the MI355X pair-style plugins; API subset of LAMMPS %s)\n", LAMMPS_VERSION);
-  try {
-    Script S(H);
-    if (infile.empty())
-      S.file(std::cin);
-    else {
-      std::ifstream f(infile);
-      if (!f) {
-        fprintf(stderr, "ERROR: Cannot open input script %s\n", infile.c_str());
-        return 1;
-      }
-      S.file(f);
+  std::string text;
+  if (infile.empty()) {
+    std::stringstream ss;
+    ss << std::cin.rdbuf();
+    text = ss.str();
+  } else {
+    std::ifstream f(infile);
+    if (!f) {
+      fprintf(stderr, "ERROR: Cannot open input script %s\n", infile.c_str());
+      return 1;
     }
-    delete H.pair;
-    H.pair = nullptr;
-  } catch (const HostAbort &e) {
-    fprintf(stderr, "%s\n", e.what());
-    return 1;
-  } catch (const std::exception &e) {
-    fprintf(stderr, "ERROR: %s\n", e.what());
-    return 1;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    text = ss.str();
   }
+  World world(np);
+  std::vector<int> rc(np, 0);
+  // one rank: the whole host in this thread.  N ranks: N threads, each with its own host objects, as N MPI processes have
+  auto rank_main = [&](int me) {
+    t_mute = me != 0;
+    t_rank = me;
+    try {
+      Host H;
+      H.quiet = quiet;
+      H.world = &world;
+      H.me = H.comm.me = me;
+      H.np = H.comm.nprocs = np;
+      world.host[me] = &H;
+      Script S(H);
+      std::istringstream in(text);
+      S.file(in);
+      world.barrier(); // (no rank tears its atoms down while another still reads them)
+      delete H.pair;
+      H.pair = nullptr;
+    } catch (const HostAbort &e) {
+      if (e.what()[0]) fprintf(stderr, "%s\n", e.what());
+      rc[me] = 1;
+      world.kill();
+    } catch (const std::exception &e) {
+      fprintf(stderr, "ERROR: %s\n", e.what());
+      rc[me] = 1;
+      world.kill();
+    }
+  };
+  if (np == 1)
+    rank_main(0);
+  else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < np; r++) th.emplace_back(rank_main, r);
+    for (auto &t : th) t.join();
+  }
+  for (int r = 0; r < np; r++)
+    if (rc[r]) return 1;
   return 0;
 }

@@ -25,7 +25,7 @@ self() { tag=$1; port=$2; shift 2
   echo "$tag rc=$?"; show $O/$tag.json; grep -h "overlap policy" $O/$tag.err; }
 run1 rebo_plain --replicate 12 12 12 --temp 300 --steps 200 --warmup 10
 self self_rebo 29541 --replicate 12 12 12 --temp 300 --steps 200 --warmup 10
-for p in split lead blocking first; do MDP_OVERLAP_POLICY=$p self self_rebo_$p 29543 --replicate 12 12 12 --temp 300 --steps 200 --warmup 10; done
+for p in split lead blocking first inline; do MDP_OVERLAP_POLICY=$p self self_rebo_$p 29543 --replicate 12 12 12 --temp 300 --steps 200 --warmup 10; done
 run1 aeam_plain --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10
 self self_aeam 29542 --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10
-for p in split lead blocking; do MDP_OVERLAP_POLICY=$p self self_aeam_$p 29544 --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10; done
+for p in split lead blocking inline; do MDP_OVERLAP_POLICY=$p self self_aeam_$p 29544 --workload aeam --replicate 63 63 63 --temp 863 --steps 200 --warmup 10; done

@@ -16,8 +16,8 @@ PKG = os.path.join(ROOT, "lammps-plugins_amd")
 MINILMP = os.path.join(PKG, "minilmp")
 
 
-def _run(script_text=None, script_file=None, timeout=300, env=None):
-    args = [MINILMP] + (["-in", script_file] if script_file else [])
+def _run(script_text=None, script_file=None, timeout=300, env=None, np=1):
+    args = [MINILMP] + (["-np", str(np)] if np > 1 else []) + (["-in", script_file] if script_file else [])
     p = subprocess.run(args, input=script_text, capture_output=True, text=True, cwd=PKG, timeout=timeout,
                        env=dict(os.environ, **env) if env else None)
     return p.returncode, p.stdout, p.stderr
