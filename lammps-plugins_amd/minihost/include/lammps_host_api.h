@@ -27,7 +27,12 @@
 #endif
 #define NEIGHMASK 0x1FFFFFFF
 
-typedef int MPI_Comm; // single-process host: the communicator is a token
+typedef int MPI_Comm; // the communicator is a token: one process, `minilmp -np N` runs its ranks as threads
+typedef int MPI_Datatype;
+#define MPI_BYTE 1
+// the one MPI call a style of these plugins makes (fix nve/mdp on several ranks hands RCCL's unique id from rank 0 to
+// the others): defined by the host executable for its rank threads, resolved from it when the plugin is loaded
+extern "C" int MPI_Bcast(void *buffer, int count, MPI_Datatype datatype, int root, MPI_Comm comm);
 
 namespace LAMMPS_NS {
 
@@ -96,8 +101,15 @@ class Memory {
   }
 };
 
+class AtomVec { // Atom::avec: per-atom array storage of the atom style
+ public:
+  virtual ~AtomVec() = default;
+  virtual void grow(int n) = 0; // room for n atoms (owned + ghost) in x, v, f, type, tag; contents kept (AtomVec::grow)
+};
+
 class Atom {
  public:
+  AtomVec *avec = nullptr;
   double **x = nullptr, **f = nullptr, **v = nullptr;
   int *type = nullptr;
   tagint *tag = nullptr;
@@ -130,6 +142,7 @@ class Force {
  public:
   int newton_pair = 1;
   double ftm2v = 1.0 / 1.0364269e-4; // metal units
+  double mvv2e = 1.0364269e-4;
   Pair *pair = nullptr;
 };
 

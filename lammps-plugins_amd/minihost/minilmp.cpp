@@ -182,6 +182,7 @@ struct World {
   int n = 1;
   std::vector<Host *> host;
   std::vector<double> red;
+  std::vector<char> bbuf; // MPI_Bcast
   static constexpr int kRed = 16;
   std::mutex m;
   std::condition_variable cv;
@@ -221,6 +222,13 @@ struct MoveRec {
   int type, tag;
 };
 
+struct HostAtomVec : AtomVec {
+  Host *h = nullptr;
+  void grow(int n) override;
+};
+
+thread_local World *t_world = nullptr; // (the world of this rank thread, for MPI_Bcast)
+
 struct PeriodicComm : Comm {
   Host *h = nullptr;
   void forward_comm(Pair *pair) override;
@@ -236,6 +244,7 @@ struct Host {
   Neighbor neighbor;
   NeighList list;
   PeriodicComm comm;
+  HostAtomVec avec;
   Domain domain;
   Update update;
   Output output;
@@ -461,6 +470,8 @@ struct Host {
     lmp.update = &update;
     lmp.output = &output;
     comm.h = this;
+    avec.h = this;
+    atom.avec = &avec;
   }
 
   // ---------------------------------------------------------------- geometry
@@ -540,6 +551,17 @@ struct Host {
   {
     const int n = atom.nlocal;
     vs.resize((size_t) 3 * std::max(n, 1));
+    vrow.resize(n + 1);
+    for (int i = 0; i < n; i++) vrow[i] = vs.data() + 3 * (size_t) i;
+    atom.v = vrow.data();
+  }
+
+  // AtomVec::grow as a style calls it: room for n atoms, contents kept (fix nve/mdp brings back more atoms than it took)
+  void grow_arrays(int n)
+  {
+    if (n <= (int) types.size()) return;
+    set_views(n); // (std::vector::resize keeps what is there)
+    vs.resize((size_t) 3 * n, 0.0);
     vrow.resize(n + 1);
     for (int i = 0; i < n; i++) vrow[i] = vs.data() + 3 * (size_t) i;
     atom.v = vrow.data();
@@ -974,7 +996,7 @@ struct Host {
         output.next = output.next_thermo = std::min<long>(nt, first + nsteps);
       }
       if (fix) { // Verlet::run with a time-integration fix style from a plugin
-        fix->initial_integrate(2);
+        fix->initial_integrate((every > 0 && step % every == 0) || k == nsteps ? 2 : 0); // (ev_set: this step's vflag)
         // Neighbor::decide(): fixes that ask for a reneighboring on this step, then every / delay / check
         bool nflag = fix->force_reneighbor && fix->next_reneighbor == step;
         if (!nflag) {
@@ -1051,7 +1073,7 @@ struct Host {
              1.0 / (sps * dt * 3.6), sps, sps * nat / 1000.0);
     }
     long nn = 0;
-    for (int i = 0; i < atom.nlocal; i++) nn += numneigh_v[i];
+    for (int i = 0; i < std::min<int>(atom.nlocal, (int) numneigh_v.size()); i++) nn += numneigh_v[i];
     if (multi()) { // per-rank counts as LAMMPS' Finish prints them (ave / max / min), and rank by rank
       const std::vector<double> nl = gather(atom.nlocal), ng = gather(atom.nghost), nf = gather((double) nn);
       auto line = [&](const char *name, const std::vector<double> &v) {
@@ -1077,6 +1099,8 @@ struct Host {
            atom.nghost, nn, atom.nlocal ? (double) nn / atom.nlocal : 0.0, nbuilds - nbuild0 - 0);
   }
 };
+
+void HostAtomVec::grow(int n) { h->grow_arrays(n); }
 
 void PeriodicComm::forward_comm(Pair *pair)
 {
@@ -1654,6 +1678,18 @@ struct Script {
 
 } // namespace
 
+// the one MPI call a plugin style makes (lammps_host_api.h): root's bytes to every rank thread
+extern "C" int MPI_Bcast(void *buffer, int count, MPI_Datatype, int root, MPI_Comm)
+{
+  World *w = t_world;
+  if (!w || w->n == 1 || count <= 0) return 0;
+  if (t_rank == root) w->bbuf.assign((const char *) buffer, (const char *) buffer + count);
+  w->barrier();
+  if (t_rank != root) memcpy(buffer, w->bbuf.data(), (size_t) count);
+  w->barrier();
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   std::string infile;
@@ -1694,6 +1730,7 @@ int main(int argc, char **argv)
   auto rank_main = [&](int me) {
     t_mute = me != 0;
     t_rank = me;
+    t_world = &world;
     try {
       Host H;
       H.quiet = quiet;

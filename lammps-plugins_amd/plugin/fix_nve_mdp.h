@@ -8,6 +8,11 @@
    creator.v2; virtuals USER-BFIELD/fix_bfield.h:33-38).
 
    fix ID all nve/mdp [hostcheck yes|no]      (default no: see fix_nve_mdp.cpp)
+
+   On several MPI ranks the fix runs the library's own domain decomposition (csrc/domain.hip: one brick per rank on
+   Comm's processor grid, halo / migration / `check yes` decision on the device, RCCL between the GPUs) on a context of
+   its own, from the atoms each rank owns at setup; the host's Comm and Neighbor idle for the length of the run and get
+   the atoms back -- wherever they migrated to -- on output steps and at the end (fix_nve_mdp.cpp, "bricks").
 -------------------------------------------------------------------------------------------------- */
 #ifdef FIX_CLASS
 // clang-format off
@@ -30,6 +35,7 @@ class FixNVEMDP : public Fix {
   ~FixNVEMDP() override;
   int setmask() override;
   void init() override;
+  void setup(int) override;
   void initial_integrate(int) override;
   void final_integrate() override;
   void post_run() override;
@@ -44,8 +50,18 @@ class FixNVEMDP : public Fix {
   int saved_delay;     // ... from this value, which the destructor restores
   static constexpr int kDelayTaken = 1 << 30;
 
+  // several ranks ("bricks")
+  int bricks;          // comm->nprocs > 1: the steps run on bctx
+  mdp_ctx *bctx;       // the fix's own context: this rank's brick
+  mdp_ctx **bricks_slot;   // the pair style's pointer to it (set while a run is under way: its compute() ends the steps there)
+  int *bricks_ev;      // the pair style's copy of "this step was opened with energy / virial"
+  int style_id, comm_up, pending_final, step_ev;
+
   mdp_ctx *ctx() const { return ctxp ? *ctxp : nullptr; }
   void to_host(bool forces);
+  void init_bricks();
+  void bricks_to_host();
+  void fail(mdp_ctx *c);
 };
 
 }    // namespace LAMMPS_NS

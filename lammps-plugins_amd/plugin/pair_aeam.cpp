@@ -46,6 +46,9 @@ PairAEAM::PairAEAM(LAMMPS *lmp) : Pair(lmp)
   cutforcesq = cutmax = 0.0;
   dev = nullptr;
   nve_linked = 0;
+  bricks = nullptr;
+  bricks_ev = 0;
+  style_id = 2;
   potfile = nullptr;
   tables_built = false;
   nelements = 0;
@@ -199,9 +202,36 @@ double PairAEAM::init_one(int i, int j)
   return cutmax;
 }
 
+// fix nve/mdp on several ranks: the step was opened by its initial_integrate (mdp_dd_comm_step_begin on the fix's own
+// context: integrate, reneighbor or start the halo, the density of the tiles that reach no remote ghost); this is the
+// rest of the step -- fp out and the ghosts' three-body forces back between the bricks on the device, not through
+// pack_forward_comm / Comm::reverse_comm.  The host's atom arrays are not read and not written.
+void PairAEAM::compute_bricks()
+{
+  if (eflag_atom || vflag_atom)
+    error->all(FLERR, "Pair style aeam (MI355X): per-atom energy / virial is not available while fix nve/mdp keeps the atoms on its bricks");
+  const int want = (eflag_global || vflag_global) ? 1 : 0;
+  if (want && !bricks_ev)
+    error->all(FLERR, "Pair style aeam (MI355X): energy / virial asked for on a step fix nve/mdp opened without them");
+  const int ev = bricks_ev ? 1 : 0;
+  if (mdp_dd_comm_step_end(bricks, ev, ev, ev ? 0 : 1) != MDP_OK)
+    error->one(FLERR, std::string("Pair style aeam (MI355X): ") + mdp_last_error(bricks));
+  if (want) {
+    double t[9];
+    if (mdp_md_thermo(bricks, t) != MDP_OK) error->one(FLERR, std::string("Pair style aeam (MI355X): ") + mdp_last_error(bricks));
+    if (eflag_global) eng_vdwl = t[1];
+    if (vflag_global)
+      for (int k = 0; k < 6; k++) virial[k] = t[2 + k];
+  }
+}
+
 void PairAEAM::compute(int eflag, int vflag)
 {
   ev_init(eflag, vflag);
+  if (bricks) {
+    compute_bricks();
+    return;
+  }
 
   if (atom->nmax > nmax) {
     memory->destroy(rho);
@@ -269,6 +299,11 @@ void *PairAEAM::extract(const char *str, int &dim)
   dim = 0;
   if (strcmp(str, "mdp_ctx") == 0) return (void *) &dev;
   if (strcmp(str, "mdp_nve_linked") == 0) return (void *) &nve_linked;
+  // ... and on several ranks, where the fix runs the bricks on a context of its own: the style's tables for it
+  if (strcmp(str, "mdp_bricks_ctx") == 0) return (void *) &bricks;
+  if (strcmp(str, "mdp_bricks_ev") == 0) return (void *) &bricks_ev;
+  if (strcmp(str, "mdp_style") == 0) return (void *) &style_id;
+  if (strcmp(str, "mdp_aeam_tables") == 0) return tables_built ? (void *) &tables : nullptr;
   return nullptr;
 }
 

@@ -39,6 +39,9 @@ class PairAEAM : public Pair {
 
  protected:
   int nve_linked;             // set by fix nve/mdp: x, v and f of the owned atoms stay on the device between reneighborings
+  mdp_ctx *bricks;            // set by fix nve/mdp on several ranks: its context holds this rank's brick, whole steps run there
+  int bricks_ev;              // ... and whether it opened the current step with energy / virial
+  int style_id;               // MDP_STYLE_AEAM (what the fix sets its own context up with)
   int nmax;                   // allocated size of the per-atom host arrays
   double cutforcesq, cutmax;
   double *rho, *fp;           // host mirrors: rho (owned), fp = Fptmp*F' (owned, then ghosts via forward_comm)
@@ -58,6 +61,7 @@ class PairAEAM : public Pair {
   void allocate();
   void open_device();
   void fail_one(int code, const char *what);
+  void compute_bricks();
 };
 
 }    // namespace LAMMPS_NS

@@ -47,6 +47,9 @@ PairREBOMoS::PairREBOMoS(LAMMPS *lmp) : Pair(lmp)
 
   dev = nullptr;
   nve_linked = 0;
+  bricks = nullptr;
+  bricks_ev = 0;
+  style_id = 1;
   params_read = false;
   cut3rebo = 0.0;
   nall_uploaded = -1;
@@ -177,9 +180,35 @@ double PairREBOMoS::init_one(int i, int j)
   return cut3rebo;
 }
 
+// fix nve/mdp on several ranks: the step was opened by its initial_integrate (mdp_dd_comm_step_begin on the fix's own
+// context: integrate, reneighbor or start the halo, centres that need no remote ghost); this is the rest of the step.
+// The host's atom arrays are not read and not written; energy and virial of this rank's atoms on the steps that ask.
+void PairREBOMoS::compute_bricks()
+{
+  if (eflag_atom || vflag_atom)
+    error->all(FLERR, "Pair style rebomos (MI355X): per-atom energy / virial is not available while fix nve/mdp keeps the atoms on its bricks");
+  const int want = (eflag_global || vflag_global) ? 1 : 0;
+  if (want && !bricks_ev)
+    error->all(FLERR, "Pair style rebomos (MI355X): energy / virial asked for on a step fix nve/mdp opened without them");
+  const int ev = bricks_ev ? 1 : 0;
+  if (mdp_dd_comm_step_end(bricks, ev, ev, ev ? 0 : 1) != MDP_OK)
+    error->one(FLERR, std::string("Pair style rebomos (MI355X): ") + mdp_last_error(bricks));
+  if (want) {
+    double t[9];
+    if (mdp_md_thermo(bricks, t) != MDP_OK) error->one(FLERR, std::string("Pair style rebomos (MI355X): ") + mdp_last_error(bricks));
+    if (eflag_global) eng_vdwl = t[1];
+    if (vflag_global)
+      for (int k = 0; k < 6; k++) virial[k] = t[2 + k];
+  }
+}
+
 void PairREBOMoS::compute(int eflag, int vflag)
 {
   ev_init(eflag, vflag);
+  if (bricks) {
+    compute_bricks();
+    return;
+  }
 
   const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
   const bool linked = nve_linked && comm->nprocs == 1;
@@ -237,6 +266,12 @@ void *PairREBOMoS::extract(const char *str, int &dim)
   dim = 0;
   if (strcmp(str, "mdp_ctx") == 0) return (void *) &dev;
   if (strcmp(str, "mdp_nve_linked") == 0) return (void *) &nve_linked;
+  // ... and on several ranks, where the fix runs the bricks on a context of its own: the style's parameters for it
+  if (strcmp(str, "mdp_bricks_ctx") == 0) return (void *) &bricks;
+  if (strcmp(str, "mdp_bricks_ev") == 0) return (void *) &bricks_ev;
+  if (strcmp(str, "mdp_style") == 0) return (void *) &style_id;
+  if (strcmp(str, "mdp_rebomos_params") == 0) return params_read ? (void *) &params : nullptr;
+  if (strcmp(str, "mdp_map") == 0) return (void *) map;
   return nullptr;
 }
 

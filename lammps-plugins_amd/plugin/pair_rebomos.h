@@ -37,6 +37,9 @@ class PairREBOMoS : public Pair {
   mdp_ctx *dev;                 // device context (one GPU per rank)
   bool host_list = false;       // MDP_REBOMOS_HOST_LIST=1: lists from the rows LAMMPS built (mdp_rebomos_host_list)
   int nve_linked;               // set by fix nve/mdp: x, v and f of the owned atoms stay on the device between reneighborings
+  mdp_ctx *bricks;              // set by fix nve/mdp on several ranks: its context holds this rank's brick, whole steps run there
+  int bricks_ev;                // ... and whether it opened the current step with energy / virial
+  int style_id;                 // MDP_STYLE_REBOMOS (what the fix sets its own context up with)
   mdp_rebomos_params params;    // the 61 file scalars after mixing
   bool params_read;
   double cut3rebo;              // 3 * rcmax_MM, the list cutoff the style asks the host for
@@ -46,6 +49,7 @@ class PairREBOMoS : public Pair {
   void allocate();
   void open_device();
   void fail_one(int code, const char *what);
+  void compute_bricks();
 };
 
 }    // namespace LAMMPS_NS

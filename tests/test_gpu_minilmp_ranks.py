@@ -68,3 +68,92 @@ def test_an_error_on_every_rank_is_said_once_and_stops_all_ranks():
     rc, out, err = _run(text, np=4, timeout=60)
     assert rc == 1
     assert err.count("Incorrect args for pair coefficients") == 1
+
+
+# ---- fix nve/mdp on several ranks: the library's bricks behind the plugin surface -------------------------------------
+# (the ranks share the one card, so RCCL is the test double of tests/native, as in test_gpu_native_ranks.py)
+
+def _double_env():
+    import subprocess
+    from lammps_plugins_amd.host import capi
+    if not os.path.exists(capi.FAKE_RCCL):
+        subprocess.run(["make", "-C", PKG, "rccl-double"], check=True)
+    return dict(MDP_RCCL_LIBRARY=capi.FAKE_RCCL, MDP_FAKE_RCCL_TIMEOUT_S="60", MDP_FIX_STATS="1")
+
+
+def test_fix_nve_mdp_on_four_ranks_reproduces_the_reference_4_rank_log():
+    """in.rebomos-bulk with `fix integrate all nve/mdp` on 2 x 2 x 1 ranks: each rank's 72 atoms go to its brick on the
+    device at setup, the steps run there (mdp_dd_comm_step_begin in initial_integrate, _end in Pair::compute), the thermo
+    rows are log.rebomos-bulk.4:54-56"""
+    log = json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+    rc, out, err = _run(script_file="examples/in.rebomos-bulk.nve-mdp.mi355x", np=4, env=_double_env())
+    assert rc == 0, err
+    assert "  2 by 2 by 1 MPI processor grid" in out
+    rows = _thermo_rows(out)
+    assert [int(r[0]) for r in rows] == [0, 10, 20]
+    for got, ref in zip(rows, log["thermo"]):
+        assert got[1] == pytest.approx(ref["temp"], abs=6e-6)
+        assert got[2] == pytest.approx(ref["press"], abs=6e-3)
+        assert got[3] == pytest.approx(ref["pe"], abs=6e-5)
+        assert got[4] == pytest.approx(ref["ke"], abs=6e-8)
+    assert re.search(r"fix nve/mdp: 4 bricks, \d+ reneighborings on the device, 2 returns of the atoms to the host", out)
+    assert "Neighbor list builds = 0" in out                               # (the host built its lists at setup only)
+
+
+def _aeam_mdp(tail=None):
+    text = open(os.path.join(PKG, "examples", "in.aeam-alsi.nve-mdp.mi355x")).read()
+    assert "run 400" in text and "thermo 100" in text
+    return text.replace("thermo 100", "thermo 25").replace("run 400", tail or "run 100")
+
+
+@pytest.mark.parametrize("np", [2, 4, 8])
+def test_fix_nve_mdp_aeam_on_n_ranks_prints_the_one_rank_thermo(np):
+    """sample.in's system with its neighbor settings, 100 steps from 863 K: the bricks reneighbor by the flag that rides
+    in the halo and atoms change bricks; on output steps the host gets back the atoms each brick owns by then (other
+    counts than it handed over) and prints the thermo rows of the one-rank run"""
+    rc1, out1, err1 = _run(_aeam_mdp())
+    assert rc1 == 0, err1
+    rc, out, err = _run(_aeam_mdp(), np=np, env=_double_env())
+    assert rc == 0, err
+    r1, rn = _thermo_rows(out1), _thermo_rows(out)
+    assert len(r1) == len(rn) == 5
+    for a, b in zip(rn, r1):
+        assert a[0] == b[0]
+        for u, v in zip(a[1:], b[1:]):
+            assert u == pytest.approx(v, rel=2e-8, abs=1e-6)
+    m = re.search(r"fix nve/mdp: (\d+) bricks, (\d+) reneighborings on the device, (\d+) returns of the atoms", out)
+    assert m and int(m.group(1)) == np and int(m.group(2)) >= 3 and int(m.group(3)) == 4
+    counts = [int(x) for x in re.findall(r"rank \d+: Nlocal (\d+)", out)]
+    assert len(counts) == np and sum(counts) == 32000 and len(set(counts)) > 1   # (what came back is what the bricks own now)
+
+
+def test_fix_nve_mdp_on_four_ranks_continues_over_two_runs():
+    """run 50 + run 50: at the end of a run the atoms are the host's again (on the ranks they migrated to), the second
+    run's setup is the host's own (exchange, borders, lists, host-mode forces) and hands them to the bricks anew"""
+    rc1, out1, err1 = _run(_aeam_mdp(), np=4, env=_double_env())
+    assert rc1 == 0, err1
+    rc, out, err = _run(_aeam_mdp("run 50\nrun 50"), np=4, env=_double_env())
+    assert rc == 0, err
+    whole, parts = _thermo_rows(out1), _thermo_rows(out)
+    assert [int(r[0]) for r in parts] == [0, 25, 50, 50, 75, 100]
+    for a, b in zip(parts[:3] + parts[4:], whole):
+        for u, v in zip(a, b):
+            assert u == pytest.approx(v, rel=2e-8, abs=1e-6)
+
+
+def test_fix_nve_mdp_rebomos_hot_on_four_ranks_equals_the_hosts_fix_nve():
+    """2 304 atoms of MoS2 from 1 500 K with 0.4 A of skin, 300 steps: many reneighborings on the bricks; thermo rows of
+    the host's own `fix nve` on one rank"""
+    from test_gpu_fix_nve_mdp import REBO_HOT, _script
+    base = _script("in.rebomos-bulk.mi355x", **REBO_HOT)
+    rc0, out0, err0 = _run(base)
+    assert rc0 == 0, err0
+    rc, out, err = _run(base.replace("fix integrate all nve", "fix integrate all nve/mdp"), np=4, env=_double_env())
+    assert rc == 0, err
+    r0, r1 = _thermo_rows(out0), _thermo_rows(out)
+    assert len(r0) == len(r1) == 7
+    for a, b in zip(r1, r0):
+        for u, v in zip(a, b):
+            assert u == pytest.approx(v, rel=5e-7, abs=1e-5)
+    m = re.search(r"fix nve/mdp: 4 bricks, (\d+) reneighborings on the device", out)
+    assert m and int(m.group(1)) > 5
