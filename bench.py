@@ -376,7 +376,7 @@ def binding_block(workload, rep, world, dominant_short):
 
 
 # ------------------------------------------------------------------------------------------------ the drop-in path
-def plugin_load_run(example, subs, timeout=900):
+def plugin_load_run(example, subs, timeout=900, np=1):
     """`minilmp -in <example>` as a FRESH child process (this process holds no context any more): the reference's plugin
     surface -- plugin load, pair_style, fix nve/mdp, run -- on the mini-host.  Returns ms per step from the host's own
     `Loop time` line, the fix's download count and the thermo rows."""
@@ -386,13 +386,14 @@ def plugin_load_run(example, subs, timeout=900):
         if old not in text:
             raise RuntimeError(f"{example}: '{old}' not found")
         text = text.replace(old, new)
-    p = subprocess.run([os.path.join(pkg, "minilmp")], input=text, capture_output=True, text=True, cwd=pkg, timeout=timeout,
-                       env=dict(os.environ, MDP_FIX_STATS="1"))
+    p = subprocess.run([os.path.join(pkg, "minilmp")] + (["-np", str(np)] if np > 1 else []), input=text, capture_output=True,
+                       text=True, cwd=pkg, timeout=timeout, env=dict(os.environ, MDP_FIX_STATS="1"))
     if p.returncode != 0:
         raise RuntimeError(f"minilmp failed ({p.returncode}): {p.stderr[-400:]}")
     import re
-    m = re.search(r"Loop time of ([0-9.eE+-]+) on 1 procs for (\d+) steps with (\d+) atoms", p.stdout)
+    m = re.search(r"Loop time of ([0-9.eE+-]+) on \d+ procs for (\d+) steps with (\d+) atoms", p.stdout)
     d = re.search(r"fix nve/mdp: (\d+) downloads", p.stdout)
+    br = re.search(r"fix nve/mdp: (\d+) bricks, (\d+) reneighborings on the device, (\d+) returns of the atoms", p.stdout)
     rows, on = [], False
     for line in p.stdout.splitlines():
         w = line.split()
@@ -406,7 +407,8 @@ def plugin_load_run(example, subs, timeout=900):
     builds = re.search(r"Neighbor list builds = (\d+)", p.stdout)
     return dict(ms_per_step=round(float(m.group(1)) / int(m.group(2)) * 1e3, 4), steps=int(m.group(2)), atoms=int(m.group(3)),
                 Matom_steps_per_s=round(int(m.group(3)) * int(m.group(2)) / float(m.group(1)) / 1e6, 2),
-                downloads=int(d.group(1)) if d else None, thermo_rows=rows,
+                downloads=int(d.group(1)) if d else (int(br.group(3)) if br else None), thermo_rows=rows, ranks=np,
+                bricks=int(br.group(1)) if br else None, device_reneighborings=int(br.group(2)) if br else None,
                 neighbor_settings_in_effect=(f"every {nb.group(1)} delay {nb.group(2)} check {nb.group(3)}" if nb else None),
                 host_neighbor_list_builds=int(builds.group(1)) if builds else None,
                 check_yes_decided_on_device="check yes decided on the device" in p.stdout, input="examples/" + example)
@@ -926,6 +928,40 @@ def main():
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] ddhost run failed: {e}")
         out["secondary"] = sec
+    # ---- N ranks: the two C++ hosts on the same N GPUs, as children of rank 0 after the timed region (the other ranks wait
+    # at the barrier below).  One thread per GPU in ONE process each: `ddhost -ranks N` through the C-ABI alone, and
+    # `minilmp -np N` through the plugin surface with fix nve/mdp on the library's bricks.  Informational; a failure is logged.
+    plain_rebomos = args.workload == "rebomos" and args.temp == 0.0 and args.strain is None   # (any --replicate: the children take it)
+    if world > 1 and rank == 0 and plain_rebomos and not args.no_secondary and native:
+        sec = {}
+        pkg = os.path.join(ROOT, "lammps-plugins_amd")
+        import re
+        try:
+            p = subprocess.run([os.path.join(pkg, "ddhost"), "-ranks", str(world), "-replicate", *map(str, args.replicate),
+                                "-steps", "100", "-thermo", str(THERMO_EVERY["rebomos"])], cwd=pkg, capture_output=True, text=True, timeout=300)
+            m = re.search(r"Loop time of ([0-9.eE+-]+) on (\d+) procs for (\d+) steps with (\d+) atoms", p.stdout)
+            if p.returncode != 0 or not m:
+                raise RuntimeError(f"ddhost failed ({p.returncode}): {p.stderr[-300:]}")
+            pol = re.search(r"Overlap policy = (\w+)", p.stdout)
+            sec["cpp_host_resident_ranks"] = dict(
+                ranks=int(m.group(2)), ms_per_step=round(float(m.group(1)) / int(m.group(3)) * 1e3, 4), steps=int(m.group(3)),
+                atoms=int(m.group(4)), Matom_steps_per_s=round(int(m.group(4)) * int(m.group(3)) / float(m.group(1)) / 1e6, 2),
+                overlap_policy=pol.group(1) if pol else None, test_double="TEST DOUBLE" in p.stdout,
+                note="minihost/ddhost.cpp: the same system on the same GPUs, one host thread per GPU in one process, through "
+                     "include/mdpair_hip.h alone; the first steps are the overlap-policy trial (inside the loop time)")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] ddhost on {world} ranks failed: {e}")
+        try:
+            rep = " ".join(map(str, args.replicate))
+            pl = plugin_load_run("in.rebomos-4m.nve-mdp.mi355x", {"replicate 24 24 24": "replicate " + rep, "thermo 50": "thermo 100",
+                                                                    "run 100": "run 200"}, timeout=420, np=world)
+            pl["note"] = ("the same system through the reference's plugin surface on N ranks of the mini-host (threads, one GPU each): "
+                          "plugin load, pair_style rebomos, fix nve/mdp on the library's bricks (INTEGRATION.md section 2)")
+            sec["plugin_load_nve_mdp_ranks"] = pl
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] plugin-load run on {world} ranks failed: {e}")
+        if sec:
+            out["secondary"] = sec
     # the CPU baseline runs on rank 0 AFTER every timed region (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu_baseline:
         attach_cpu_baseline(out, args.workload, 8.0)

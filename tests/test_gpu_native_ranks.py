@@ -139,3 +139,20 @@ def test_failing_library_transport_falls_back_to_torch_and_says_so():
     assert "library transport" in line["transport_fallback"] and "exit code" in line["transport_fallback"]
     assert line["n_gpus"] == 2 and "staged" in line["config"]["transport"]
     assert line["config"]["rccl_library_is_test_double"] is False
+
+
+@pytest.mark.timeout(900)
+def test_bench_on_n_ranks_also_runs_the_two_cpp_hosts_on_the_same_ranks():
+    """a plain REBO-MoS line on N ranks carries `secondary`: `ddhost -ranks N` (the C-ABI alone) and `minilmp -np N` with
+    fix nve/mdp on the library's bricks (the plugin surface), started by rank 0 behind the timed region"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--replicate", "6", "6", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=_env("60"), capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    sec = line["secondary"]
+    assert sec["cpp_host_resident_ranks"]["ranks"] == 2 and sec["cpp_host_resident_ranks"]["test_double"] is True
+    pl = sec["plugin_load_nve_mdp_ranks"]
+    assert pl["ranks"] == 2 and pl["bricks"] == 2 and pl["atoms"] == 288 * 6 * 6 * 4 and pl["steps"] == 200
+    # the same system, started from rest, in three hosts: potential energy per atom of the first thermo row
+    assert pl["thermo_rows"][0][3] / pl["atoms"] == pytest.approx(line["config"]["pe_per_atom_start_eV"], abs=2e-6)
