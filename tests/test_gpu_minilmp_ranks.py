@@ -157,3 +157,22 @@ def test_fix_nve_mdp_rebomos_hot_on_four_ranks_equals_the_hosts_fix_nve():
             assert u == pytest.approx(v, rel=5e-7, abs=1e-5)
     m = re.search(r"fix nve/mdp: 4 bricks, (\d+) reneighborings on the device", out)
     assert m and int(m.group(1)) > 5
+
+
+def test_rebomos_hot_host_mode_on_four_ranks_equals_one_rank():
+    """the same hot MoS2 cell in HOST MODE (the host's own fix nve, exchange and borders at its many reneighborings, ghosts
+    of other ranks uploaded with the owned atoms every step): rows of the one-rank run"""
+    from test_gpu_fix_nve_mdp import REBO_HOT, _script
+    base = _script("in.rebomos-bulk.mi355x", **REBO_HOT)
+    rc0, out0, err0 = _run(base)
+    assert rc0 == 0, err0
+    rc, out, err = _run(base, np=4)
+    assert rc == 0, err
+    r0, r1 = _thermo_rows(out0), _thermo_rows(out)
+    assert len(r0) == len(r1) == 7
+    for a, b in zip(r1, r0):
+        for u, v in zip(a, b):
+            assert u == pytest.approx(v, rel=5e-7, abs=1e-5)
+    assert re.search(r"Neighbor list builds = (\d+)", out).group(1) == re.search(r"Neighbor list builds = (\d+)", out0).group(1)
+    counts = [int(x) for x in re.findall(r"rank \d+: Nlocal (\d+)", out)]
+    assert sum(counts) == 2304
