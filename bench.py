@@ -908,6 +908,24 @@ def main():
                 sec["plugin_load_nve_mdp_aeam"] = pl
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] plugin-load AEAM run failed: {e}")
+            try:   # `bricks yes`: the same inputs with the library's decomposition (one brick) running the steps -- lists and
+                   # reneighborings on the device too, the host's Neighbor idle for the length of the run
+                plb = plugin_load_run("in.rebomos-4m.nve-mdp.mi355x", {"thermo 50": "thermo 100", "run 100": "run 300",
+                                                                        "fix integrate all nve/mdp": "fix integrate all nve/mdp bricks yes"})
+                base_rows = {int(r[0]): r[1:5] for r in sec.get("plugin_load_nve_mdp", {}).get("thermo_rows", [])}
+                worst = max([abs(a - b) / max(abs(b), 1.0) for r in plb["thermo_rows"] if int(r[0]) in base_rows
+                             for a, b in zip(r[1:5], base_rows[int(r[0])])] or [float("inf")])
+                plb["thermo_rows_vs_default_fix"] = {"max_rel_diff": float(worst), "equal_to_printed_digits": bool(worst < 5e-8)}
+                plb["note"] = "as plugin_load_nve_mdp with `fix integrate all nve/mdp bricks yes`"
+                sec["plugin_load_nve_mdp_bricks"] = plb
+                pla = plugin_load_run("in.aeam-alsi.nve-mdp.mi355x", {"region MeSi block 0 20 0 20 0 20": "region MeSi block 0 63 0 63 0 63",
+                                                                       "run 400": "run 300",
+                                                                       "fix integrate all nve/mdp": "fix integrate all nve/mdp bricks yes"})
+                pla["note"] = ("BASELINE.json configs[2]'s size (63^3 fcc cells, 1 000 188 atoms, 0.75 % Si, NVE from 863 K, neigh_modify every 1 "
+                               "delay 1 check yes) through plugin load aeamplugin.so + fix nve/mdp bricks yes: every reneighboring on the device")
+                sec["plugin_load_nve_mdp_aeam1m_bricks"] = pla
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] plugin-load runs with bricks yes failed: {e}")
             try:   # the same system driven by the C++ host of minihost/ddhost.cpp: resident mode through the C-ABI, no Python in the loop
                 pkg = os.path.join(ROOT, "lammps-plugins_amd")
                 p = subprocess.run([os.path.join(pkg, "ddhost"), "-ranks", "1", "-replicate", *map(str, DEFAULT_REPLICATE["rebomos"]),

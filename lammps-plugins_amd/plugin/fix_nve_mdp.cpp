@@ -20,6 +20,13 @@
    On one MPI rank the pair style keeps the periodic images itself (mdp_set_box_host), so ghosts follow their owners
    without the host's forward_comm.
 
+   `fix ID all nve/mdp bricks yes` on ONE rank runs the mode described next with a single brick (no communicator): the
+   periodic images, the lists and every reneighboring are then the device's too (mdp_md_integrate_check, mdp_dd_reneighbor,
+   mdp_md_compute) and the host's Neighbor idles for the length of the run -- 2.88 against 3.08 ms per step at 3.98 M atoms
+   from rest, and for hot runs the difference between a reneighboring of 2 ms on the device and one on the host (sample.in's
+   alloy at 1.0 M atoms: 1.12 ms per step).  Not the default on one rank: per-atom energy / virial and a non-periodic box
+   need the mode above.
+
    Several ranks ("bricks").  There the host's Comm owns ghosts and migration, on host arrays -- which is what this fix
    takes out of the steps.  So it runs the library's own decomposition instead, as minihost/ddhost.cpp does without a
    LAMMPS around it:
@@ -64,13 +71,14 @@ using namespace FixConst;
 
 FixNVEMDP::FixNVEMDP(LAMMPS *lmp, int narg, char **arg)
     : Fix(lmp, narg, arg), ctxp(nullptr), pair_linked(nullptr), downloads(0), hostcheck(0), took_delay(0), saved_delay(0),
-      bricks(0), bctx(nullptr), bricks_slot(nullptr), bricks_ev(nullptr), style_id(0), comm_up(0), pending_final(0), step_ev(0)
+      bricks(0), bricks_kw(0), bctx(nullptr), bricks_slot(nullptr), bricks_ev(nullptr), style_id(0), comm_up(0), pending_final(0), step_ev(0)
 {
-  if (narg != 3 && narg != 5) error->all(FLERR, "Illegal fix nve/mdp command");
-  if (narg == 5) {
-    const std::string key = arg[3], val = arg[4];
-    if (key != "hostcheck" || (val != "yes" && val != "no")) error->all(FLERR, "Illegal fix nve/mdp command");
-    hostcheck = val == "yes";
+  if (narg < 3 || (narg - 3) % 2) error->all(FLERR, "Illegal fix nve/mdp command");
+  for (int k = 3; k + 1 < narg; k += 2) {
+    const std::string key = arg[k], val = arg[k + 1];
+    if ((key != "hostcheck" && key != "bricks") || (val != "yes" && val != "no")) error->all(FLERR, "Illegal fix nve/mdp command");
+    if (key == "hostcheck") hostcheck = val == "yes";
+    else bricks_kw = val == "yes";
   }
   time_integrate = 1;
   force_reneighbor = 1;
@@ -101,7 +109,7 @@ void FixNVEMDP::init()
   pair_linked = static_cast<int *>(force->pair->extract("mdp_nve_linked", dim));
   if (!ctxp || !pair_linked || !ctx())
     error->all(FLERR, "Fix nve/mdp requires a pair style of this plugin (rebomos or aeam)");
-  if (comm->nprocs != 1) {
+  if (comm->nprocs != 1 || bricks_kw) { // several ranks, or `bricks yes` on one: the library's decomposition runs the steps
     init_bricks();
     return;
   }
@@ -128,7 +136,7 @@ void FixNVEMDP::init_bricks()
   const int *sid = static_cast<int *>(force->pair->extract("mdp_style", dim));
   if (!bricks_slot || !bricks_ev || !sid)
     error->all(FLERR, "Fix nve/mdp requires a pair style of this plugin (rebomos or aeam)");
-  if (hostcheck) error->all(FLERR, "Fix nve/mdp: hostcheck yes is for one MPI rank (on several the host's arrays are not current)");
+  if (hostcheck) error->all(FLERR, "Fix nve/mdp: hostcheck yes needs the host's arrays current: one MPI rank without `bricks yes`");
   if (!domain->xperiodic || !domain->yperiodic || !domain->zperiodic)
     error->all(FLERR, "Fix nve/mdp on several MPI ranks needs a periodic box");
   style_id = *sid;
@@ -197,6 +205,13 @@ void FixNVEMDP::setup(int /*vflag*/)
   dd.rank = comm->me;
   dd.cutghost = cutghost;
   if (mdp_dd_setup(bctx, &dd) != MDP_OK) fail(bctx);
+  if (comm->nprocs == 1) { // one brick: its periodic images are the library's, no communicator
+    if (mdp_dd_reneighbor(bctx) != MDP_OK) fail(bctx);
+    if (mdp_md_compute(bctx, 0, 0) != MDP_OK) fail(bctx);
+    pending_final = 0;
+    *bricks_slot = bctx;
+    return;
+  }
   if (!comm_up) { // RCCL's unique id: rank 0 makes it, MPI hands it round
     unsigned char uid[128];
     memset(uid, 0, sizeof uid);
@@ -261,9 +276,18 @@ void FixNVEMDP::initial_integrate(int vflag)
   if (bricks) {
     const bigint now = update->ntimestep;
     step_ev = (vflag || now == output->next || now == update->laststep) ? 1 : 0;
-    *bricks_ev = step_ev;
-    int ren = 0;
-    if (mdp_dd_comm_step_begin(bctx, pending_final, -1, step_ev, step_ev, &ren) != MDP_OK) fail(bctx);
+    *bricks_ev = step_ev | (comm->nprocs == 1 ? 2 : 0);
+    if (comm->nprocs == 1) { // one brick: the deferred on-device `check yes` flag, the lists rebuilt on the device when it fired
+      int moved = 0, dangerous = 0;
+      if (mdp_md_integrate_check(bctx, pending_final, &moved, &dangerous) != MDP_OK) fail(bctx);
+      if (moved) {
+        if (mdp_dd_reneighbor(bctx) != MDP_OK) fail(bctx);
+        one_rank_builds++;
+      }
+    } else {
+      int ren = 0;
+      if (mdp_dd_comm_step_begin(bctx, pending_final, -1, step_ev, step_ev, &ren) != MDP_OK) fail(bctx);
+    }
     pending_final = step_ev ? 0 : 1; // (Pair::compute ends the step with the half-kick deferred on steps without output)
     return;
   }
@@ -285,7 +309,9 @@ void FixNVEMDP::post_run()
 {
   if (bricks) {
     long long info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void) mdp_dd_comm_step_info(bctx, info);
+    if (comm->nprocs > 1) (void) mdp_dd_comm_step_info(bctx, info);
+    else info[3] = one_rank_builds;
+    one_rank_builds = 0;
     if (comm->me == 0 && getenv("MDP_FIX_STATS"))
       printf("fix nve/mdp: %d bricks, %lld reneighborings on the device, %ld returns of the atoms to the host in this run\n", comm->nprocs,
              info[3], downloads);

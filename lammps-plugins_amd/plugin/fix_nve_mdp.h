@@ -7,7 +7,7 @@
    A plugin registering a fix style is what the reference repository itself does (USER-BFIELD/bfieldplugin.cpp:15-29,
    creator.v2; virtuals USER-BFIELD/fix_bfield.h:33-38).
 
-   fix ID all nve/mdp [hostcheck yes|no]      (default no: see fix_nve_mdp.cpp)
+   fix ID all nve/mdp [hostcheck yes|no] [bricks yes|no]     (defaults no, no: see fix_nve_mdp.cpp)
 
    On several MPI ranks the fix runs the library's own domain decomposition (csrc/domain.hip: one brick per rank on
    Comm's processor grid, halo / migration / `check yes` decision on the device, RCCL between the GPUs) on a context of
@@ -51,7 +51,9 @@ class FixNVEMDP : public Fix {
   static constexpr int kDelayTaken = 1 << 30;
 
   // several ranks ("bricks")
-  int bricks;          // comm->nprocs > 1: the steps run on bctx
+  int bricks;          // comm->nprocs > 1, or `bricks yes`: the steps run on bctx
+  int bricks_kw;       // `bricks yes`
+  long one_rank_builds = 0;
   mdp_ctx *bctx;       // the fix's own context: this rank's brick
   mdp_ctx **bricks_slot;   // the pair style's pointer to it (set while a run is under way: its compute() ends the steps there)
   int *bricks_ev;      // the pair style's copy of "this step was opened with energy / virial"

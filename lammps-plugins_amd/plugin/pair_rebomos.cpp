@@ -188,11 +188,16 @@ void PairREBOMoS::compute_bricks()
   if (eflag_atom || vflag_atom)
     error->all(FLERR, "Pair style rebomos (MI355X): per-atom energy / virial is not available while fix nve/mdp keeps the atoms on its bricks");
   const int want = (eflag_global || vflag_global) ? 1 : 0;
-  if (want && !bricks_ev)
+  if (want && !(bricks_ev & 1))
     error->all(FLERR, "Pair style rebomos (MI355X): energy / virial asked for on a step fix nve/mdp opened without them");
-  const int ev = bricks_ev ? 1 : 0;
-  if (mdp_dd_comm_step_end(bricks, ev, ev, ev ? 0 : 1) != MDP_OK)
-    error->one(FLERR, std::string("Pair style rebomos (MI355X): ") + mdp_last_error(bricks));
+  const int ev = (bricks_ev & 1) ? 1 : 0;
+  int rc;
+  if (bricks_ev & 2) { // one rank (`bricks yes`): no exchange to wait for -- compute, then the half-kick now or with the next step's
+    rc = mdp_md_compute(bricks, ev, ev);
+    if (rc == MDP_OK) rc = ev ? mdp_md_final_integrate(bricks) : mdp_md_defer_final(bricks);
+  } else
+    rc = mdp_dd_comm_step_end(bricks, ev, ev, ev ? 0 : 1);
+  if (rc != MDP_OK) error->one(FLERR, std::string("Pair style rebomos (MI355X): ") + mdp_last_error(bricks));
   if (want) {
     double t[9];
     if (mdp_md_thermo(bricks, t) != MDP_OK) error->one(FLERR, std::string("Pair style rebomos (MI355X): ") + mdp_last_error(bricks));

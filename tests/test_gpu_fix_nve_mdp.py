@@ -94,6 +94,58 @@ def test_aeam_run_equals_the_hosts_fix_nve():
         assert a[3] == pytest.approx(b[3], rel=1e-8)
 
 
+def test_bricks_yes_on_one_rank_reproduces_the_reference_log():
+    """`fix ID all nve/mdp bricks yes`: the library's decomposition with ONE brick runs the steps -- lists, reneighborings
+    and the periodic images on the device, the host's Neighbor idle for the length of the run (log.rebomos-bulk.1:54-56)"""
+    log = json.load(open(os.path.join(GOLDEN, "rebomos_bulk_log.json")))
+    text = _script("in.rebomos-bulk.nve-mdp.mi355x", **{"fix integrate all nve/mdp": "fix integrate all nve/mdp bricks yes"})
+    rc, out, err = _run(text, env={"MDP_FIX_STATS": "1"})
+    assert rc == 0, err
+    rows = _thermo_rows(out)
+    assert [int(r[0]) for r in rows] == [0, 10, 20]
+    for got, ref in zip(rows, log["thermo"]):
+        assert got[1] == pytest.approx(ref["temp"], abs=6e-6)
+        assert got[2] == pytest.approx(ref["press"], abs=6e-3)
+        assert got[3] == pytest.approx(ref["pe"], abs=6e-5)
+        assert got[4] == pytest.approx(ref["ke"], abs=6e-8)
+    assert "fix nve/mdp: 1 bricks, 0 reneighborings on the device, 2 returns of the atoms to the host" in out
+
+
+def test_bricks_yes_hot_runs_equal_the_hosts_fix_nve_and_reneighbor_on_the_device():
+    """the hot MoS2 cell (300 steps, 0.4 A of skin) and sample.in's alloy (200 steps from 863 K) with `bricks yes` on one
+    rank: thermo rows of the host's own `fix nve`; every reneighboring happened on the device, the host built its lists
+    once (at setup)"""
+    base = _script("in.rebomos-bulk.mi355x", **REBO_HOT)
+    rc0, out0, err0 = _run(base)
+    assert rc0 == 0, err0
+    rc1, out1, err1 = _run(base.replace("fix integrate all nve", "fix integrate all nve/mdp bricks yes"), env={"MDP_FIX_STATS": "1"})
+    assert rc1 == 0, err1
+    r0, r1 = _thermo_rows(out0), _thermo_rows(out1)
+    assert len(r0) == len(r1) == 7
+    for a, b in zip(r1, r0):
+        for u, v in zip(a, b):
+            assert u == pytest.approx(v, rel=5e-7, abs=1e-5)
+    m = re.search(r"fix nve/mdp: 1 bricks, (\d+) reneighborings on the device, (\d+) returns", out1)
+    assert m and int(m.group(1)) > 5 and int(m.group(2)) == 6     # (output steps 50 ... 300)
+    assert "Neighbor list builds = 0" in out1                 # (the host's, during the run)
+    a0 = _script("in.aeam-alsi.mi355x", **{"run 400": "run 200"})
+    rc2, out2, err2 = _run(a0, timeout=600)
+    assert rc2 == 0, err2
+    rc3, out3, err3 = _run(_script("in.aeam-alsi.nve-mdp.mi355x", **{"run 400": "run 200", "fix integrate all nve/mdp":
+                                                                       "fix integrate all nve/mdp bricks yes"}), timeout=600)
+    assert rc3 == 0, err3
+    for a, b in zip(_thermo_rows(out2)[:3], _thermo_rows(out3)[:3]):
+        assert a[1] == pytest.approx(b[1], rel=1e-6) and a[2] == pytest.approx(b[2], rel=1e-8) and a[3] == pytest.approx(b[3], rel=1e-8)
+
+
+def test_fix_nve_mdp_keywords_are_checked():
+    for bad in ("bricks maybe", "hostcheck", "speed fast"):
+        rc, out, err = _run(_script("in.rebomos-bulk.nve-mdp.mi355x", **{"fix integrate all nve/mdp": "fix integrate all nve/mdp " + bad}))
+        assert rc == 1 and "Illegal fix nve/mdp command" in err
+    rc, out, err = _run(_script("in.rebomos-bulk.nve-mdp.mi355x", **{"fix integrate all nve/mdp": "fix integrate all nve/mdp bricks yes hostcheck yes"}))
+    assert rc == 1 and "hostcheck yes needs the host's arrays current" in err
+
+
 def test_fix_nve_mdp_needs_a_pair_style_of_the_plugin():
     script = _script("in.rebomos-bulk.nve-mdp.mi355x").replace("pair_style rebomos\n", "").replace(
         "pair_coeff * * ../tests/golden/potentials/MoS.REBO.set5b M S\n", "")
