@@ -1742,8 +1742,12 @@ int main(int argc, char **argv)
       std::istringstream in(text);
       S.file(in);
       world.barrier(); // (no rank tears its atoms down while another still reads them)
+      // LAMMPS::destroy(): Force (and its pair style) goes before Modify (and its fixes)
       delete H.pair;
       H.pair = nullptr;
+      H.force.pair = nullptr;
+      delete H.fix;
+      H.fix = nullptr;
     } catch (const HostAbort &e) {
       if (e.what()[0]) fprintf(stderr, "%s\n", e.what());
       rc[me] = 1;

@@ -71,7 +71,7 @@ using namespace FixConst;
 
 FixNVEMDP::FixNVEMDP(LAMMPS *lmp, int narg, char **arg)
     : Fix(lmp, narg, arg), ctxp(nullptr), pair_linked(nullptr), downloads(0), hostcheck(0), took_delay(0), saved_delay(0),
-      bricks(0), bricks_kw(0), bctx(nullptr), bricks_slot(nullptr), bricks_ev(nullptr), style_id(0), comm_up(0), pending_final(0), step_ev(0)
+      linked_to(nullptr), bricks(0), bricks_kw(0), bctx(nullptr), bricks_slot(nullptr), bricks_ev(nullptr), style_id(0), comm_up(0), pending_final(0), step_ev(0)
 {
   if (narg < 3 || (narg - 3) % 2) error->all(FLERR, "Illegal fix nve/mdp command");
   for (int k = 3; k + 1 < narg; k += 2) {
@@ -87,13 +87,17 @@ FixNVEMDP::FixNVEMDP(LAMMPS *lmp, int narg, char **arg)
 
 FixNVEMDP::~FixNVEMDP()
 {
-  if (took_delay) neighbor->delay = saved_delay;
-  if (pair_linked) *pair_linked = 0;
-  if (bricks_slot) *bricks_slot = nullptr;
+  // LAMMPS::destroy() deletes Neighbor and Force (and with it the pair style) BEFORE Modify and its fixes, and a new
+  // `pair_style` command replaces the pair object under a fix that lives on: what was extracted from the pair style is
+  // touched only while force->pair is still the object it came from
+  if (took_delay && neighbor) neighbor->delay = saved_delay;
+  const bool pair_alive = force && force->pair && force->pair == linked_to;
+  if (pair_alive && pair_linked) *pair_linked = 0;
+  if (pair_alive && bricks_slot) *bricks_slot = nullptr;
   if (bctx) {
     if (comm_up) (void) mdp_dd_comm_destroy(bctx);
     mdp_destroy(bctx);
-  } else if (ctx())
+  } else if (pair_alive && ctx())
     (void) mdp_hnve_off(ctx());
 }
 
@@ -105,6 +109,7 @@ void FixNVEMDP::init()
 {
   if (!force->pair) error->all(FLERR, "Fix nve/mdp requires a pair style");
   int dim = 0;
+  linked_to = force->pair;
   ctxp = static_cast<mdp_ctx **>(force->pair->extract("mdp_ctx", dim));
   pair_linked = static_cast<int *>(force->pair->extract("mdp_nve_linked", dim));
   if (!ctxp || !pair_linked || !ctx())

@@ -50,6 +50,7 @@ class FixNVEMDP : public Fix {
   int saved_delay;     // ... from this value, which the destructor restores
   static constexpr int kDelayTaken = 1 << 30;
 
+  class Pair *linked_to; // the pair style ctxp / pair_linked / bricks_slot point into (see the destructor)
   // several ranks ("bricks")
   int bricks;          // comm->nprocs > 1, or `bricks yes`: the steps run on bctx
   int bricks_kw;       // `bricks yes`
