@@ -973,6 +973,9 @@ struct Host {
     build_neighbor_lists();
     if (!multi()) set_vviews();
     if (fix) fix->init(); // (LAMMPS::init: force->init() before modify->init())
+    // Neighbor::init(), behind Modify::init() in LAMMPS::init(): its check of the settings a fix may have touched
+    if (neighbor.delay > 0 && neighbor.delay % neighbor.every != 0)
+      error.all(FLERR, "Neighbor delay must be 0 or multiple of every setting");
     printf("Neighbor list info ...\n  update: every = %d steps, delay = %d steps, check = %s\n", neighbor.every, neighbor.delay,
            neighbor.dist_check ? "yes" : "no");
     printf("  max neighbors/atom: %d, page size: %d\n  master list distance cutoff = %g\n  ghost atom cutoff = %g\n",

@@ -101,6 +101,13 @@ FixNVEMDP::~FixNVEMDP()
     (void) mdp_hnve_off(ctx());
 }
 
+// Neighbor::init() -- which runs behind Modify::init() -- insists that a non-zero delay be a multiple of `every`
+int FixNVEMDP::taken_delay() const
+{
+  const int every = neighbor->every > 0 ? neighbor->every : 1;
+  return kDelayTaken - kDelayTaken % every;
+}
+
 void FixNVEMDP::fail(mdp_ctx *c) { error->one(FLERR, std::string("Fix nve/mdp: ") + (c ? mdp_last_error(c) : "no device context")); }
 
 int FixNVEMDP::setmask() { return INITIAL_INTEGRATE | FINAL_INTEGRATE; }
@@ -127,7 +134,7 @@ void FixNVEMDP::init()
   if (!hostcheck && neighbor->dist_check) {
     if (!took_delay) saved_delay = neighbor->delay;
     took_delay = 1;
-    neighbor->delay = kDelayTaken;
+    neighbor->delay = taken_delay();
   }
 }
 
@@ -165,7 +172,7 @@ void FixNVEMDP::init_bricks()
   // neither a check nor a reneighboring of the host's during the run: both read arrays that are not current
   if (!took_delay) saved_delay = neighbor->delay;
   took_delay = 1;
-  neighbor->delay = kDelayTaken;
+  neighbor->delay = taken_delay();
   next_reneighbor = -1;
 }
 

@@ -65,6 +65,7 @@ class FixNVEMDP : public Fix {
   void init_bricks();
   void bricks_to_host();
   void fail(mdp_ctx *c);
+  int taken_delay() const;
 };
 
 }    // namespace LAMMPS_NS
