@@ -151,6 +151,10 @@ void FixNVEMDP::init_bricks()
   if (hostcheck) error->all(FLERR, "Fix nve/mdp: hostcheck yes needs the host's arrays current: one MPI rank without `bricks yes`");
   if (!domain->xperiodic || !domain->yperiodic || !domain->zperiodic)
     error->all(FLERR, "Fix nve/mdp on several MPI ranks needs a periodic box");
+  // the library numbers its bricks as MPI_Cart_create numbers LAMMPS' default grid (`processors * * * map cart`: the last
+  // dimension fastest); another mapping (map xyz, numa, a custom file) would hand every rank another rank's brick
+  if ((comm->myloc[0] * comm->procgrid[1] + comm->myloc[1]) * comm->procgrid[2] + comm->myloc[2] != comm->me)
+    error->all(FLERR, "Fix nve/mdp on several MPI ranks needs the default mapping of ranks to the processor grid (processors ... map cart)");
   style_id = *sid;
   if (!bctx) {
     const int ndev = mdp_device_count();
