@@ -150,7 +150,7 @@ void FixNVEMDP::init_bricks()
     error->all(FLERR, "Fix nve/mdp requires a pair style of this plugin (rebomos or aeam)");
   if (hostcheck) error->all(FLERR, "Fix nve/mdp: hostcheck yes needs the host's arrays current: one MPI rank without `bricks yes`");
   if (!domain->xperiodic || !domain->yperiodic || !domain->zperiodic)
-    error->all(FLERR, "Fix nve/mdp on several MPI ranks needs a periodic box");
+    error->all(FLERR, "Fix nve/mdp on several MPI ranks (or with bricks yes) needs a periodic box");
   // the library numbers its bricks as MPI_Cart_create numbers LAMMPS' default grid (`processors * * * map cart`: the last
   // dimension fastest); another mapping (map xyz, numa, a custom file) would hand every rank another rank's brick
   if ((comm->myloc[0] * comm->procgrid[1] + comm->myloc[1]) * comm->procgrid[2] + comm->myloc[2] != comm->me)
