@@ -269,22 +269,31 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
     x.y += dt * vy;
     x.z += dt * vz;
     xq[i] = x;
+    // The triggers are read one compute late and fire early by a fixed margin that stands for two steps of motion (0.07 /
+    // 0.1 A: 35 / 50 A/ps at 1 fs).  An atom faster than that -- the tail of a 5 000 K melt -- fires by its OWN two steps
+    // instead (this step's speed, a quarter on top for its acceleration): whatever it may reach before the answer is
+    // read is then still inside the limit.  (profiles/prune_fuzz.py found the case.)
+    const double two_steps = (CHECK || SC.xa || SC.xp) ? 2.5 * dt * sqrt(vx * vx + vy * vy + vz * vz) : 0.0;
+    auto reaches = [two_steps](const double d2, const double hardsq_) { // will the atom be beyond `hard` two steps on?
+      const double rem = sqrt(hardsq_) - two_steps;
+      return rem <= 0.0 || d2 > rem * rem;
+    };
     if (CHECK) {
       const double dx = x.x - xhold[3 * (size_t) i], dy = x.y - xhold[3 * (size_t) i + 1], dz = x.z - xhold[3 * (size_t) i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
-      t = d2 > trigsq;
+      t = d2 > trigsq || reaches(d2, hardsq);
       h = d2 > hardsq;
     }
     if (SC.xa) {
       const double dx = x.x - SC.xa[3 * (size_t) i], dy = x.y - SC.xa[3 * (size_t) i + 1], dz = x.z - SC.xa[3 * (size_t) i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
-      sa = d2 > SC.trig_a;
+      sa = d2 > SC.trig_a || reaches(d2, SC.hard_a);
       sah = d2 > SC.hard_a;
     }
     if (SC.xp) {
       const double dx = x.x - SC.xp[3 * (size_t) i], dy = x.y - SC.xp[3 * (size_t) i + 1], dz = x.z - SC.xp[3 * (size_t) i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
-      sp = d2 > SC.trig_p;
+      sp = d2 > SC.trig_p || reaches(d2, SC.hard_p);
       sph = d2 > SC.hard_p;
     }
   }
@@ -295,11 +304,14 @@ __global__ void nve_advance_kernel(int nlocal, double dtf, double dt, const doub
     }
     if (__ballot(h) && (threadIdx.x & 63) == 0) flag[1] = 1;
   }
-  if (SC.flag && (threadIdx.x & 63) == 0) {
-    if (__ballot(sa)) SC.flag[0] = 1;
-    if (__ballot(sah)) SC.flag[1] = 1;
-    if (__ballot(sp)) SC.flag[2] = 1;
-    if (__ballot(sph)) SC.flag[3] = 1;
+  if (SC.flag) { // (the wave votes with ALL its lanes, then lane 0 stores: a vote inside the lane-0 branch would count lane 0 alone)
+    const bool wa = __any(sa), wah = __any(sah), wp = __any(sp), wph = __any(sph);
+    if ((threadIdx.x & 63) == 0) {
+      if (wa) SC.flag[0] = 1;
+      if (wah) SC.flag[1] = 1;
+      if (wp) SC.flag[2] = 1;
+      if (wph) SC.flag[3] = 1;
+    }
   }
 }
 
@@ -428,6 +440,13 @@ __global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf
   if (k < n) {
     const size_t i = (size_t) first + k;
     double4 x = xq[i];
+    // (what the slot held is the ghost's position of the step before: its last step is its speed -- see nve_advance_kernel)
+    const double ox = buf[3 * (size_t) k] - x.x, oy = buf[3 * (size_t) k + 1] - x.y, oz = buf[3 * (size_t) k + 2] - x.z;
+    const double two_steps = (SC.xa || SC.xp) ? 2.5 * sqrt(ox * ox + oy * oy + oz * oz) : 0.0;
+    auto reaches = [two_steps](const double d2, const double hardsq_) {
+      const double rem = sqrt(hardsq_) - two_steps;
+      return rem <= 0.0 || d2 > rem * rem;
+    };
     x.x = buf[3 * (size_t) k];
     x.y = buf[3 * (size_t) k + 1];
     x.z = buf[3 * (size_t) k + 2];
@@ -436,21 +455,24 @@ __global__ void unpack_x_kernel(int n, int first, const double *__restrict__ buf
     if (SC.xa) {
       const double dx = x.x - SC.xa[3 * i], dy = x.y - SC.xa[3 * i + 1], dz = x.z - SC.xa[3 * i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
-      sa = d2 > SC.trig_a;
+      sa = d2 > SC.trig_a || reaches(d2, SC.hard_a);
       sah = d2 > SC.hard_a;
     }
     if (SC.xp) {
       const double dx = x.x - SC.xp[3 * i], dy = x.y - SC.xp[3 * i + 1], dz = x.z - SC.xp[3 * i + 2];
       const double d2 = dx * dx + dy * dy + dz * dz;
-      sp = d2 > SC.trig_p;
+      sp = d2 > SC.trig_p || reaches(d2, SC.hard_p);
       sph = d2 > SC.hard_p;
     }
   }
-  if (SC.flag && (threadIdx.x & 63) == 0) {
-    if (__ballot(sa)) SC.flag[4] = 1;
-    if (__ballot(sah)) SC.flag[5] = 1;
-    if (__ballot(sp)) SC.flag[6] = 1;
-    if (__ballot(sph)) SC.flag[7] = 1;
+  if (SC.flag) { // (all lanes vote, lane 0 stores -- see nve_advance_kernel)
+    const bool wa = __any(sa), wah = __any(sah), wp = __any(sp), wph = __any(sph);
+    if ((threadIdx.x & 63) == 0) {
+      if (wa) SC.flag[4] = 1;
+      if (wah) SC.flag[5] = 1;
+      if (wp) SC.flag[6] = 1;
+      if (wph) SC.flag[7] = 1;
+    }
   }
 }
 

@@ -598,6 +598,46 @@ def test_pruned_rows_give_the_trajectory_of_the_rows_as_built(style, monkeypatch
     assert np.abs(xa_ - xb).max() < 1e-9 and np.abs(va_ - vb).max() < 1e-7
 
 
+def test_one_fast_atom_in_a_cold_crystal_keeps_the_pruned_rows_valid(monkeypatch):
+    """The displacement votes behind the pruned rows and the style's own lists must count EVERY atom.  (Until round 6 the
+    vote sat inside the branch only lane 0 of a wave takes, so one atom in 64 was looked at -- in a thermal system some
+    lane-0 atom always moves about as far as the fastest, which hid it; profiles/prune_fuzz.py found a 5 000 K run where
+    it did not.)  Here ONE S atom of a crystal at rest is shot at 40 A/ps through the lattice, and it is chosen so that
+    it does not sit on lane 0 of its wave in the device's order: it crosses Lennard-Jones cutoffs of atoms that do not
+    move at all.  The run on pruned rows must stay on the run that walks the rows as built."""
+    s = S.replicate(S.rebomos_bulk_cell(), (3, 3, 2))
+    # the device's order (a function of the positions): an S atom at a slot that is no multiple of 64, nor next to one
+    ctx, cutghost = _rebo_ctx()
+    d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP, v0=np.zeros((s.n, 3)))
+    typ = ctx.md_download_int("type", d.nlocal)
+    slot = next(k for k in range(100, d.nlocal) if typ[k] == 2 and 8 <= k % 64 <= 56)
+    shot = int(d.tags_local[slot])
+    ctx.close()
+    out = {}
+    for tag, env in (("pruned", {"MDP_PRUNE": "1", "MDP_PRUNE_BUFFER": "0.3"}), ("as built", {"MDP_PRUNE": "0"})):
+        for k in ("MDP_PRUNE", "MDP_PRUNE_BUFFER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx, cutghost = _rebo_ctx()
+        v0 = np.zeros((s.n, 3))
+        v0[np.nonzero(s.tag == shot)[0][0]] = np.array([25.0, 22.0, 22.0])          # 40 A/ps: 0.04 A per step
+        d = resident.DeviceDomain(ctx, capi.STYLE_REBOMOS, s, cutghost, 2.0, MAP, v0=v0)
+        tags = d.tags_local
+        assert int(tags[slot]) == shot
+        d.compute(0, 0)
+        for step in range(70):
+            d.step(0, 0, rebuild="auto")
+        got = ctx.md_download(d.nlocal, want=("x", "v"))
+        order = np.argsort(d.tags_local)
+        out[tag] = (got["x"][order], got["v"][order], ctx.md_prune_stats(), int(tags[slot]))
+        ctx.close()
+    xp, vp, sp, tp = out["pruned"]
+    xb, vb, sb, tb = out["as built"]
+    assert tp == tb and sp["prunings"] >= 5 and sb["prunings"] == 0    # the projectile alone re-prunes the rows every few steps
+    assert np.abs(xp - xb).max() < 1e-10 and np.abs(vp - vb).max() < 1e-8
+
+
 def test_upload_x_invalidates_the_pruned_rows(monkeypatch):
     """mdp_md_upload_x rewrites the positions outside the integrator (here: every atom moved by up to 0.5 A, more
     than half of any pruning buffer).  The compute that follows must prune afresh and check the style's own lists
