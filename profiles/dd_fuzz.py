@@ -20,13 +20,13 @@ def main():
         ranks = rng.choice([2, 3, 4, 6, 8])
         if style == "rebomos":
             rep = rng.choice([(3, 3, 2), (4, 2, 2), (2, 4, 3), (5, 3, 2), (3, 2, 4)])
-            temp = rng.choice([300, 900, 1500])
+            temp = rng.choice([300, 900, 1500, 3000, 5000])
             box = S.replicate(S.rebomos_bulk_cell(), rep).box
             extra = []
         else:
             n = rng.choice([12, 14, 16, 18])
             rep = (n, n, n)
-            temp = rng.choice([300, 863, 1200])
+            temp = rng.choice([300, 863, 1200, 3000])
             box = S.fcc_cell(4.045, n).box
             extra = ["-frac2", rng.choice([0.0, 0.0075, 0.03, 0.08])]
         drift = [rng.choice([-60, -30, 0, 25, 40, 70]) for _ in range(3)]

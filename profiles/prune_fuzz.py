@@ -1,6 +1,7 @@
 """Randomised check of the dynamic row pruning and of the pair queues (one GPU, minihost/ddhost.cpp): random hot / drifting /
 strained-by-temperature runs with the kernels walking PRUNED rows (default) against the same run with MDP_PRUNE=0 (rows as
-built) and against MDP_LJ_QUEUE=1 / 0 (cubic-branch pairs queued / found by a second walk).  The validity of pruned rows
+built), against MDP_LJ_QUEUE=1 / 0 (cubic-branch pairs queued / found by a second walk) and against other inner skins of the
+style's own lists (MDP_INNER_SKIN: other rebuild steps, the same pairs).  The validity of pruned rows
 rests on a displacement trigger read one step late with a margin: a pair missed because of it would show here as a
 trajectory that leaves its twin.  usage: python3 profiles/prune_fuzz.py <cases> <seed>"""
 import os, sys, random, tempfile, time
@@ -34,8 +35,9 @@ def main():
         res = {}
         with tempfile.TemporaryDirectory() as d:
             try:
-                for name, env in (("pruned", {}), ("as_built", {"MDP_PRUNE": "0"}), ("queued", {"MDP_LJ_QUEUE": "1"}), ("walked", {"MDP_LJ_QUEUE": "0"})):
-                    if style == "aeam" and name in ("queued", "walked"): continue
+                for name, env in (("pruned", {}), ("as_built", {"MDP_PRUNE": "0"}), ("queued", {"MDP_LJ_QUEUE": "1"}), ("walked", {"MDP_LJ_QUEUE": "0"}),
+                                  ("inner_skin_0.3", {"MDP_INNER_SKIN": "0.3"}), ("inner_skin_1.2", {"MDP_INNER_SKIN": "1.2"})):
+                    if style == "aeam" and name not in ("pruned", "as_built"): continue
                     out, _ = run(common + ["-dump", os.path.join(d, name)], env)
                     res[name] = T._dump(os.path.join(d, name), 1) + (out.split("Neighbor list builds = ")[1].split()[0],)
                 ref = res["as_built"]
