@@ -31,7 +31,10 @@ def main():
                 s = FC._rebomos(fac, amp, sd, rep); desc = f"fac {fac:.3f} amp {amp:.3f} seed {sd} rep {rep}"
                 eng = FC.engine(style, s, orc, P=P); want = FC.oracle_outputs(style, eng, s.x)
                 xa = eng.all_positions(s.x)
-                rctx.set_atoms_host(eng.nlocal, xa, eng.type_all, eng.tag_all, 2, map_=[0, 0, 1]); rctx.set_skin(2.0)
+                lists = rng.choice(["device", "host_csr"]); desc += f" lists {lists}"
+                rctx.set_atoms_host(eng.nlocal, xa, eng.type_all, eng.tag_all, 2, map_=[0, 0, 1])
+                if lists == "device": rctx.set_skin(2.0)
+                else: rctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, 2.0)
                 g = rctx.rebomos_compute_host(eng.nlocal, eflag=3, vflag=5)
                 g0 = rctx.rebomos_compute_host(eng.nlocal, eflag=0, vflag=0)
                 fs = max(1.0, float(np.abs(want["f"]).max()))
@@ -43,10 +46,17 @@ def main():
                 nc, frac, amp, sd = rng.choice([4, 5, 6, 7]), rng.choice([0.0, 0.0075, 0.03, 0.08, 0.2, 0.5]), rng.uniform(0.0, 0.3), rng.randrange(10**6)
                 s = FC._aeam_cell(nc, frac, amp, sd); desc = f"cells {nc} frac {frac} amp {amp:.3f} seed {sd}"
                 eng = FC.engine(style, s, orc, T=T); want = FC.oracle_outputs(style, eng, s.x)
-                cut = float(af.cut_table(tabs).max()) + 1.0
-                xa, type_all, tag_all, owner, _, nloc, _ = S.with_ghosts(s, cut)
-                ctx = capi.Context(0); ctx.aeam_set_tables(tabs); ctx.aeam_device_lists(True)
-                ctx.set_atoms_host(nloc, xa, type_all, tag_all, 2, map_=None); ctx.set_skin(1.0)
+                lists = rng.choice(["device", "host_csr"]); desc += f" lists {lists}"
+                ctx = capi.Context(0); ctx.aeam_set_tables(tabs)
+                if lists == "device":
+                    cut = float(af.cut_table(tabs).max()) + 1.0
+                    xa, type_all, tag_all, owner, _, nloc, _ = S.with_ghosts(s, cut)
+                    ctx.aeam_device_lists(True)
+                    ctx.set_atoms_host(nloc, xa, type_all, tag_all, 2, map_=None); ctx.set_skin(1.0)
+                else:
+                    xa, owner, nloc = eng.all_positions(s.x), eng.owner, eng.nlocal
+                    ctx.set_atoms_host(nloc, xa, eng.type_all, eng.tag_all, 2, map_=None)
+                    ctx.set_neighbors_csr_host(eng.nn, eng.off, eng.nb, 1.0)
                 d = ctx.aeam_density_host(nloc, eflag=3)
                 r = ctx.aeam_force_host(len(xa), nloc, np.concatenate([d["fp"], d["fp"][owner]]), eflag=3, vflag=5)
                 d0 = ctx.aeam_density_host(nloc, eflag=0)
