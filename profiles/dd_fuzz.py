@@ -32,17 +32,20 @@ def main():
         drift = [rng.choice([-60, -30, 0, 25, 40, 70]) for _ in range(3)]
         steps = rng.choice([40, 60, 90])
         sd = rng.randrange(1, 10**7)
-        common = ["-style", style, "-replicate", *rep, "-steps", steps, "-thermo", steps, "-temp", temp, "-seed", sd, "-drift", *drift] + extra
+        thermo = rng.choice([steps, 10, 7])     # (energy / virial steps in mid-run: the other kernel variants, sums over ranks)
+        common = ["-style", style, "-replicate", *rep, "-steps", steps, "-thermo", thermo, "-temp", temp, "-seed", sd, "-drift", *drift] + extra
         with tempfile.TemporaryDirectory() as d:
             try:
-                T._ddhost(["-ranks", 1, "-dump", os.path.join(d, "one")] + common)
-                out, _ = T._ddhost(["-ranks", ranks, "-dump", os.path.join(d, "many")] + common, double=True)
+                _, rows1 = T._ddhost(["-ranks", 1, "-dump", os.path.join(d, "one")] + common)
+                out, rowsn = T._ddhost(["-ranks", ranks, "-dump", os.path.join(d, "many")] + common, double=True)
                 x1, v1 = T._dump(os.path.join(d, "one"), 1)
                 xn, vn = T._dump(os.path.join(d, "many"), ranks)
                 dx = xn - x1
                 dx -= np.round(box.x2lamda(dx + box.lo)) @ box.h.T
                 ex, ev = float(np.abs(dx).max()), float(np.abs(vn - v1).max())
-                ok = ex < 1e-8 and ev < 1e-7
+                ok = ex < 1e-8 and ev < 1e-7 and len(rows1) == len(rowsn) and len(rows1) >= 2
+                for a, b in zip(rowsn, rows1):       # step temp press pe ke as printed (%.8g or better)
+                    ok = ok and all(abs(u - v) <= 2e-7 * max(abs(v), 1.0) for u, v in zip(a, b))
                 builds = out.split("Neighbor list builds = ")[1].split()[0]
             except Exception as e:  # noqa: BLE001
                 ok, ex, ev, builds = False, -1, -1, str(e)[-200:]
