@@ -51,6 +51,7 @@
 #include "fix_nve_mdp.h"
 
 #include "atom.h"
+#include "atom_vec.h"
 #include "comm.h"
 #include "domain.h"
 #include "error.h"
