@@ -45,6 +45,10 @@ def main():
             else:
                 nc, frac, amp, sd = rng.choice([4, 5, 6, 7]), rng.choice([0.0, 0.0075, 0.03, 0.08, 0.2, 0.5]), rng.uniform(0.0, 0.3), rng.randrange(10**6)
                 s = FC._aeam_cell(nc, frac, amp, sd); desc = f"cells {nc} frac {frac} amp {amp:.3f} seed {sd}"
+                if rng.random() < 0.5:   # a sheared (triclinic) box: same lamda coordinates in a tilted cell
+                    L = float(s.box.prd[0]); tilt = np.array([rng.uniform(-0.12, 0.12) * L for _ in range(3)])
+                    nb = S.Box(s.box.lo.copy(), s.box.prd.copy(), tilt)
+                    s = S.System(nb, nb.lamda2x(s.box.x2lamda(s.x)), s.type, s.tag, s.mass); desc += f" tilt {np.round(tilt, 2).tolist()}"
                 eng = FC.engine(style, s, orc, T=T); want = FC.oracle_outputs(style, eng, s.x)
                 lists = rng.choice(["device", "host_csr"]); desc += f" lists {lists}"
                 ctx = capi.Context(0); ctx.aeam_set_tables(tabs)

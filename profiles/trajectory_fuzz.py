@@ -29,6 +29,10 @@ def main():
             else:
                 n = rng.choice([4, 5, 6]); temp = rng.choice([300, 863, 2500]); skin = 1.0
                 s = S.fcc_cell(4.045, n, frac_type2=rng.choice([0.0, 0.03, 0.2]), seed=sd); s.mass[1:3] = af.mass[:2]
+                if rng.random() < 0.5:   # a sheared (triclinic) box
+                    L = float(s.box.prd[0]); tilt = np.array([rng.uniform(-0.06, 0.06) * L for _ in range(3)])
+                    nb = S.Box(s.box.lo.copy(), s.box.prd.copy(), tilt)
+                    s = S.System(nb, nb.lamda2x(s.box.x2lamda(s.x)), s.type, s.tag, s.mass)
             v0 = S.gaussian_velocities(s, float(temp), seed=sd + 1)
             shot = rng.random() < 0.4
             if shot: v0[rng.randrange(s.n)] += np.array([rng.choice([-1, 1]) * 22.0, 20.0, 18.0])   # a projectile at ~35 A/ps
@@ -50,7 +54,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok, msg = False, f"exception {str(e)[-200:]}"
         bad += 0 if ok else 1
-        print(f"{'ok ' if ok else 'BAD'} case {k} {style} n {s.n} T {temp} shot {shot} seed {sd} inner {os.environ.get('MDP_INNER_SKIN')} {msg}", flush=True)
+        print(f"{'ok ' if ok else 'BAD'} case {k} {style} n {s.n} tilt {np.round(s.box.tilt, 1).tolist()} T {temp} shot {shot} seed {sd} inner {os.environ.get('MDP_INNER_SKIN')} {msg}", flush=True)
     print(f"{ncase} cases, {bad} bad, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 main()
